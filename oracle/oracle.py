@@ -1,0 +1,223 @@
+"""ctypes binding of the CPU oracle (oracle/annonet_oracle.cpp).  TEST INFRASTRUCTURE ONLY.
+
+Importable only from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg; the
+product package (annonet_amd) never imports it.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+IGNORE = 65535
+
+
+class Layer(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("type", "k", "stride", "pad", "cin", "cout", "in_a", "in_b", "has_bn", "has_bias")] + \
+               [(n, C.c_int64) for n in ("w_off", "b_off", "g_off", "beta_off", "rs_off")]
+
+
+class Tile(C.Structure):
+    _fields_ = [("full", C.c_long * 4), ("unique", C.c_long * 4)]
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    src = os.path.join(_HERE, "annonet_oracle.cpp")
+    if force or not os.path.exists(so) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(so)):
+        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        L.orc_last_error.restype = C.c_char_p
+        L.orc_net_create.restype = C.c_void_p
+        L.orc_net_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_int]
+        L.orc_net_destroy.argtypes = [C.c_void_p]
+        L.orc_net_layer_count.argtypes = [C.c_void_p]
+        L.orc_net_layer.argtypes = [C.c_void_p, C.c_int, C.POINTER(Layer)]
+        for f in ("orc_net_param_count", "orc_net_running_count"):
+            getattr(L, f).restype = C.c_int64
+            getattr(L, f).argtypes = [C.c_void_p]
+        for f in ("orc_net_params", "orc_net_momentum", "orc_net_grads", "orc_net_running"):
+            getattr(L, f).restype = C.POINTER(C.c_float)
+            getattr(L, f).argtypes = [C.c_void_p]
+        L.orc_net_running_updates.restype = C.POINTER(C.c_double)
+        L.orc_net_running_updates.argtypes = [C.c_void_p]
+        L.orc_net_set_hyper.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_ulong]
+        L.orc_required_input_dim.argtypes = [C.c_void_p]
+        L.orc_recommended_input_dim.argtypes = [C.c_int, C.c_int]
+        L.orc_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.orc_layer_output.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64]
+        L.orc_layer_dims.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        L.orc_layer_dact.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]
+        L.orc_train_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                     C.c_double, C.c_int, C.POINTER(C.c_double)]
+        L.orc_set_weights.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p]
+        L.orc_random_rect_containing_point.argtypes = [C.c_uint32, C.c_uint32, C.c_long, C.c_long, C.c_long, C.c_long, C.POINTER(C.c_long)]
+        L.orc_outpaint.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_long, C.c_long, C.c_long, C.c_long]
+        L.orc_get_tiles.restype = C.c_int64
+        L.orc_get_tiles.argtypes = [C.c_long] * 6 + [C.POINTER(Tile), C.c_int64]
+        L.orc_infer.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                C.c_long, C.c_long, C.c_long, C.c_long, C.POINTER(Tile), C.c_int64, C.c_void_p, C.c_void_p]
+        L.orc_count_steps_without_decrease.restype = C.c_int64
+        L.orc_count_steps_without_decrease.argtypes = [C.c_void_p, C.c_int64, C.c_double]
+        _LIB = L
+    return _LIB
+
+
+def _check(rc):
+    if rc != 0:
+        raise RuntimeError(lib().orc_last_error().decode())
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class OracleNet:
+    def __init__(self, levels=2, in_ch=3, classes=3, scaler=1.0, min_filters=1):
+        self.L = lib()
+        self.h = self.L.orc_net_create(levels, in_ch, classes, scaler, min_filters)
+        if not self.h:
+            raise RuntimeError(self.L.orc_last_error().decode())
+        self.levels, self.in_ch, self.classes = levels, in_ch, classes
+        n = self.L.orc_net_layer_count(self.h)
+        self.layers = []
+        for i in range(n):
+            l = Layer()
+            self.L.orc_net_layer(self.h, i, C.byref(l))
+            self.layers.append(l)
+        self.n_params = self.L.orc_net_param_count(self.h)
+        self.n_running = self.L.orc_net_running_count(self.h)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.orc_net_destroy(self.h)
+            self.h = None
+
+    def _view(self, fn, n):
+        return np.ctypeslib.as_array(fn(self.h), shape=(n,))
+
+    @property
+    def params(self):
+        return self._view(self.L.orc_net_params, self.n_params)
+
+    @property
+    def momentum(self):
+        return self._view(self.L.orc_net_momentum, self.n_params)
+
+    @property
+    def grads(self):
+        return self._view(self.L.orc_net_grads, self.n_params)
+
+    @property
+    def running(self):
+        return self._view(self.L.orc_net_running, self.n_running)
+
+    @property
+    def running_updates(self):
+        nbn = sum(1 for l in self.layers if l.has_bn)
+        return np.ctypeslib.as_array(self.L.orc_net_running_updates(self.h), shape=(nbn,))
+
+    def set_hyper(self, lr=0.1, wd=0.0005, mom=0.9, bn_window=100):
+        self.L.orc_net_set_hyper(self.h, lr, wd, mom, bn_window)
+
+    def required_input_dim(self):
+        return self.L.orc_required_input_dim(self.h)
+
+    def recommended_input_dim(self, n):
+        return self.L.orc_recommended_input_dim(self.levels, n)
+
+    def forward(self, images):
+        """images: u8 [N,H,W,C] -> logits fp32 [N,K,H,W] (inference mode)."""
+        images = np.ascontiguousarray(images, dtype=np.uint8)
+        n, h, w, c = images.shape
+        assert c == self.in_ch
+        out = np.empty((n, self.classes, h, w), dtype=np.float32)
+        _check(self.L.orc_forward(self.h, _p(images), n, h, w, _p(out)))
+        return out
+
+    def layer_output(self, i, which=0):
+        dims = (C.c_int * 4)()
+        self.L.orc_layer_dims(self.h, i, dims)
+        out = np.empty(tuple(dims), dtype=np.float32)
+        _check(self.L.orc_layer_output(self.h, i, which, _p(out), out.size))
+        return out
+
+    def layer_dact(self, i):
+        dims = (C.c_int * 4)()
+        self.L.orc_layer_dims(self.h, i, dims)
+        out = np.empty(tuple(dims), dtype=np.float32)
+        _check(self.L.orc_layer_dact(self.h, i, _p(out), out.size))
+        return out
+
+    def train_step(self, images, labels, weights, loss_scale_n=None, apply_update=True):
+        images = np.ascontiguousarray(images, dtype=np.uint8)
+        labels = np.ascontiguousarray(labels, dtype=np.uint16)
+        weights = np.ascontiguousarray(weights, dtype=np.float32)
+        n, h, w, c = images.shape
+        loss = C.c_double(0)
+        _check(self.L.orc_train_step(self.h, _p(images), _p(labels), _p(weights), n, h, w,
+                                     float(loss_scale_n if loss_scale_n else n), int(apply_update), C.byref(loss)))
+        return loss.value
+
+    def infer(self, image, gains=None, detection_levels=None, max_tile=(1024, 1024), overlap=None, tiles=None,
+              want_blended=False):
+        image = np.ascontiguousarray(image, dtype=np.uint8)
+        H, W, c = image.shape
+        ov = self.required_input_dim() if overlap is None else overlap
+        res = np.empty((H, W), dtype=np.uint16)
+        bl = np.empty((self.classes, H, W), dtype=np.float32) if want_blended else None
+        g = np.ascontiguousarray(gains, dtype=np.float64) if gains is not None else None
+        d = np.ascontiguousarray(detection_levels, dtype=np.float64) if detection_levels is not None else None
+        tarr, nt = None, 0
+        if tiles is not None:
+            nt = len(tiles)
+            tarr = (Tile * nt)()
+            for i, (full, uniq) in enumerate(tiles):
+                tarr[i].full[:] = full
+                tarr[i].unique[:] = uniq
+        _check(self.L.orc_infer(self.h, _p(image), H, W, _p(g), _p(d), max_tile[0], max_tile[1], ov, ov, tarr, nt, _p(res), _p(bl)))
+        return (res, bl) if want_blended else res
+
+
+def set_weights(labels, class_weight, image_weight):
+    labels = np.ascontiguousarray(labels, dtype=np.uint16)
+    out = np.empty(labels.shape, dtype=np.float32)
+    _check(lib().orc_set_weights(_p(labels), labels.shape[0], labels.shape[1], class_weight, image_weight, _p(out)))
+    return out
+
+
+def random_rect_containing_point(draw_x, draw_y, px, py, w, h):
+    r = (C.c_long * 4)()
+    _check(lib().orc_random_rect_containing_point(draw_x, draw_y, px, py, w, h, r))
+    return tuple(r)
+
+
+def outpaint(img, inside):
+    img = np.ascontiguousarray(img, dtype=np.uint8).copy()
+    nr, nc = img.shape[:2]
+    ch = 1 if img.ndim == 2 else img.shape[2]
+    _check(lib().orc_outpaint(_p(img), nr, nc, ch, *inside))
+    return img
+
+
+def get_tiles(width, height, max_w, max_h, ov_x, ov_y):
+    n = lib().orc_get_tiles(width, height, max_w, max_h, ov_x, ov_y, None, 0)
+    if n < 0:
+        raise RuntimeError(lib().orc_last_error().decode())
+    arr = (Tile * max(n, 1))()
+    n = lib().orc_get_tiles(width, height, max_w, max_h, ov_x, ov_y, arr, n)
+    return [(tuple(arr[i].full), tuple(arr[i].unique)) for i in range(n)]
+
+
+def count_steps_without_decrease(values, probability_of_decrease=0.51):
+    v = np.ascontiguousarray(values, dtype=np.float64)
+    return lib().orc_count_steps_without_decrease(_p(v), v.size, probability_of_decrease)
