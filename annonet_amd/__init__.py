@@ -1,0 +1,9 @@
+"""annonet_amd — MI355X-native (gfx950) implementation of annonet's hot path: the segmentation net's training step and
+tiled sliding-window inference, behind the reference's NetPimpl / tiling / annonet_infer interface.
+
+The compute lives in annonet_amd/lib/libannonet_hip.so (hand-written HIP, C ABI in include/annonet_hip.h); this package
+is the thin host-side mirror used by tests and bench.py.  There is no CPU fallback.
+"""
+from ._lib import ANH_BF16, ANH_FP32, LABEL_IGNORE, AnnonetHipError, build, lib  # noqa: F401
+from .netpimpl import (RuntimeNet, TrainingNet, annonet_infer, count_steps_without_decrease, net_config, net_layers,  # noqa: F401
+                       outpaint, random_rect_containing_point, set_weights, tiling)

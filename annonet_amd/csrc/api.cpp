@@ -1,0 +1,645 @@
+// api.cpp — the C ABI (include/annonet_hip.h) over Engine.  Exceptions stop here: every entry point returns a
+// status code and leaves the message in a thread-local string (anh_last_error).
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <fstream>
+#include <memory>
+#include <unordered_set>
+
+#include "common.h"
+#include "engine.h"
+#include "hostlogic.h"
+
+using namespace anh;
+
+namespace {
+thread_local std::string g_error;
+
+template <typename F>
+int guarded(F&& f) {
+    try { f(); return ANH_OK; }
+    catch (const Error& e) { g_error = e.what(); return e.code; }
+    catch (const std::bad_alloc&) { g_error = "host allocation failed"; return ANH_ERR_OOM; }
+    catch (const std::exception& e) { g_error = e.what(); return ANH_ERR_INTERNAL; }
+}
+
+const char kRuntimeMagic[8] = {'A', 'N', 'H', 'R', 'T', '0', '0', '1'};
+const char kStateMagic[8] = {'A', 'N', 'H', 'T', 'S', '0', '0', '1'};
+
+struct BlobHeader {
+    char magic[8];
+    int32_t levels, in_channels, classes, min_filters;
+    double width_scaler;
+    int64_t n_params, n_running;
+};
+}  // namespace
+
+struct anh_runtime {
+    std::unique_ptr<Engine> eng;
+};
+
+struct anh_trainer {
+    anh_net_config cfg{2, 3, 3, 1.0, 1, ANH_BF16};
+    uint64_t seed = 0;
+    std::unique_ptr<Engine> eng;
+    LrSchedule sched;
+    double weight_decay = 0.0005, momentum = 0.9;
+    unsigned long bn_window = 100;
+    std::string sync_path;
+    double sync_seconds = 0;
+    std::chrono::steady_clock::time_point last_sync = std::chrono::steady_clock::now();
+    bool verbose = false;
+    unsigned long steps = 0;
+    double last_loss = 0;
+    // losses travel back asynchronously: pinned slots + events, consumed in order
+    float* loss_ring = nullptr;
+    struct PendingLoss { hipEvent_t ev; int slot; };
+    std::deque<PendingLoss> pending;
+    std::vector<hipEvent_t> free_events;
+    int next_slot = 0;
+    std::vector<uint8_t> pack_img;
+    std::vector<uint16_t> pack_lab;
+    std::vector<float> pack_w;
+
+    Engine& engine() {
+        if (!eng) fail(ANH_ERR_INVALID, "TrainingNet::Initialize has not been called");
+        return *eng;
+    }
+    void consume(bool wait) {
+        while (!pending.empty()) {
+            PendingLoss p = pending.front();
+            if (wait) HIP_CHECK(hipEventSynchronize(p.ev));
+            else {
+                hipError_t q = hipEventQuery(p.ev);
+                if (q == hipErrorNotReady) { (void)hipGetLastError(); break; }
+                HIP_CHECK(q);
+            }
+            pending.pop_front();
+            free_events.push_back(p.ev);
+            last_loss = (double)loss_ring[p.slot];
+            sched.record(last_loss);
+        }
+    }
+    ~anh_trainer() {
+        for (auto& p : pending) (void)hipEventDestroy(p.ev);
+        for (auto e : free_events) (void)hipEventDestroy(e);
+        if (loss_ring) (void)hipHostFree(loss_ring);
+    }
+};
+
+extern "C" {
+
+const char* anh_last_error(void) { return g_error.c_str(); }
+void anh_free(void* p) { std::free(p); }
+
+int anh_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+int anh_set_device(int device) {
+    return guarded([&] { HIP_CHECK(hipSetDevice(device)); });
+}
+
+// ---- dimension maths / spec ----
+int anh_required_input_dim(const anh_net_config* cfg) {
+    int r = -1;
+    guarded([&] { ANH_REQUIRE(cfg, "null config"); r = Spec::build(*cfg).required_input_dim(); });
+    return r;
+}
+int anh_recommended_input_dim(int levels, int n) {
+    if (levels < 0 || levels > 3) { g_error = "level count must be 0..3"; return -1; }
+    return Spec::recommended_input_dim(levels, n);
+}
+int anh_net_layer_count(const anh_net_config* cfg) {
+    int r = -1;
+    guarded([&] { ANH_REQUIRE(cfg, "null config"); r = (int)Spec::build(*cfg).layers.size(); });
+    return r;
+}
+int anh_net_layer(const anh_net_config* cfg, int index, anh_layer_desc* out) {
+    return guarded([&] {
+        ANH_REQUIRE(cfg && out, "null argument");
+        Spec s = Spec::build(*cfg);
+        ANH_REQUIRE(index >= 0 && index < (int)s.layers.size(), "layer index out of range");
+        *out = s.layers[index];
+    });
+}
+int64_t anh_net_param_count(const anh_net_config* cfg) {
+    int64_t r = -1;
+    guarded([&] { ANH_REQUIRE(cfg, "null config"); r = Spec::build(*cfg).n_params; });
+    return r;
+}
+int64_t anh_net_running_count(const anh_net_config* cfg) {
+    int64_t r = -1;
+    guarded([&] { ANH_REQUIRE(cfg, "null config"); r = Spec::build(*cfg).n_running; });
+    return r;
+}
+
+// ---- RuntimeNet ----
+int anh_runtime_create(const anh_net_config* cfg, anh_runtime** out) {
+    return guarded([&] {
+        ANH_REQUIRE(cfg && out, "null argument");
+        auto h = std::make_unique<anh_runtime>();
+        h->eng = std::make_unique<Engine>(*cfg, false);
+        *out = h.release();
+    });
+}
+void anh_runtime_destroy(anh_runtime* h) { delete h; }
+int anh_runtime_config(const anh_runtime* h, anh_net_config* out) {
+    return guarded([&] { ANH_REQUIRE(h && out, "null argument"); *out = h->eng->spec.cfg; });
+}
+int anh_runtime_set_params(anh_runtime* h, const float* params, int64_t n_params, const float* running, int64_t n_running) {
+    return guarded([&] {
+        ANH_REQUIRE(h && params && running, "null argument");
+        ANH_REQUIRE(n_params == h->eng->spec.n_params && n_running == h->eng->spec.n_running, "parameter blob size mismatch");
+        h->eng->set_params(params, running);
+    });
+}
+int anh_runtime_get_params(const anh_runtime* h, float* params, int64_t n_params, float* running, int64_t n_running) {
+    return guarded([&] {
+        ANH_REQUIRE(h, "null handle");
+        ANH_REQUIRE((!params || n_params == h->eng->spec.n_params) && (!running || n_running == h->eng->spec.n_running), "parameter blob size mismatch");
+        h->eng->get_params(params, running);
+    });
+}
+int anh_runtime_serialize(const anh_runtime* h, void** blob, size_t* size) {
+    return guarded([&] {
+        ANH_REQUIRE(h && blob && size, "null argument");
+        const Spec& s = h->eng->spec;
+        const size_t bytes = sizeof(BlobHeader) + (size_t)(s.n_params + s.n_running) * 4;
+        char* p = (char*)std::malloc(bytes);
+        if (!p) fail(ANH_ERR_OOM, "host allocation failed");
+        BlobHeader hd{};
+        std::memcpy(hd.magic, kRuntimeMagic, 8);
+        hd.levels = s.cfg.levels; hd.in_channels = s.cfg.in_channels; hd.classes = s.cfg.classes; hd.min_filters = s.cfg.min_filters;
+        hd.width_scaler = s.cfg.width_scaler; hd.n_params = s.n_params; hd.n_running = s.n_running;
+        std::memcpy(p, &hd, sizeof hd);
+        try { h->eng->get_params((float*)(p + sizeof hd), (float*)(p + sizeof hd) + s.n_params); }
+        catch (...) { std::free(p); throw; }
+        *blob = p; *size = bytes;
+    });
+}
+int anh_runtime_deserialize(const void* blob, size_t size, int precision, anh_runtime** out) {
+    return guarded([&] {
+        ANH_REQUIRE(blob && out, "null argument");
+        if (size < sizeof(BlobHeader)) fail(ANH_ERR_IO, "runtime blob truncated");
+        BlobHeader hd;
+        std::memcpy(&hd, blob, sizeof hd);
+        if (std::memcmp(hd.magic, kRuntimeMagic, 8) != 0) fail(ANH_ERR_IO, "not an annonet_hip runtime blob");
+        anh_net_config cfg{hd.levels, hd.in_channels, hd.classes, hd.width_scaler, hd.min_filters, precision};
+        Spec s = Spec::build(cfg);
+        if (s.n_params != hd.n_params || s.n_running != hd.n_running || size != sizeof hd + (size_t)(hd.n_params + hd.n_running) * 4)
+            fail(ANH_ERR_IO, "runtime blob does not match its header");
+        auto h = std::make_unique<anh_runtime>();
+        h->eng = std::make_unique<Engine>(cfg, false);
+        const float* f = (const float*)((const char*)blob + sizeof hd);
+        h->eng->set_params(f, f + hd.n_params);
+        *out = h.release();
+    });
+}
+
+int anh_runtime_forward_device(anh_runtime* h, const uint8_t* d_image, int n, int height, int width, float* d_out_nchw) {
+    return guarded([&] {
+        ANH_REQUIRE(h && d_image && d_out_nchw, "null argument");
+        Src img;
+        img.kind = SRC_IMAGE; img.img = d_image; img.img_h = height; img.img_w = width;
+        img.img_sample_stride = (int64_t)height * width * h->eng->spec.cfg.in_channels;
+        h->eng->forward_inference(img, n, height, width, d_out_nchw);
+    });
+}
+
+int anh_runtime_forward(anh_runtime* h, const uint8_t* image, int n, int height, int width, const float** out, int* k, int* nr, int* nc) {
+    return guarded([&] {
+        ANH_REQUIRE(h && image && out, "null argument");
+        ANH_REQUIRE(n >= 1 && height >= 1 && width >= 1, "empty input");
+        Engine& e = *h->eng;
+        const int K = e.spec.cfg.classes, C = e.spec.cfg.in_channels;
+        const size_t in_bytes = (size_t)n * height * width * C, out_elems = (size_t)n * K * height * width;
+        e.stage_image.reserve(in_bytes);
+        e.stage_out.reserve(out_elems * 4);
+        HIP_CHECK(hipMemcpyAsync(e.stage_image.p, image, in_bytes, hipMemcpyHostToDevice, e.stream));
+        Src img;
+        img.kind = SRC_IMAGE; img.img = e.stage_image.as<uint8_t>(); img.img_h = height; img.img_w = width;
+        img.img_sample_stride = (int64_t)height * width * C;
+        e.forward_inference(img, n, height, width, e.stage_out.as<float>());
+        e.host_out.resize(out_elems);
+        HIP_CHECK(hipMemcpyAsync(e.host_out.data(), e.stage_out.p, out_elems * 4, hipMemcpyDeviceToHost, e.stream));
+        e.synchronize();
+        *out = e.host_out.data();
+        if (k) *k = K;
+        if (nr) *nr = height;
+        if (nc) *nc = width;
+    });
+}
+
+static std::vector<anh_tile> tiles_for(const anh_tiling_params* tiling, int width, int height) {
+    if (tiling) return make_tiles(width, height, *tiling);
+    anh_tile t;
+    t.full_rect = {0, 0, width - 1, height - 1};
+    t.unique_rect = t.full_rect;
+    return {t};
+}
+
+int anh_infer_device(anh_runtime* h, const uint8_t* d_image, int height, int width, const double* gains, const anh_tiling_params* tiling,
+                     const anh_tile* tiles, size_t n_tiles, uint16_t* d_result, float* d_blended) {
+    return guarded([&] {
+        ANH_REQUIRE(h && d_image && d_blended, "null argument");
+        std::vector<anh_tile> list = tiles ? std::vector<anh_tile>(tiles, tiles + n_tiles) : tiles_for(tiling, width, height);
+        h->eng->infer_device(d_image, height, width, gains, list, d_result, d_blended);
+    });
+}
+
+// detection-level filter (annonet_infer.cpp:187-239) on the host.  Seeds are looked up at (row, col): the reference
+// stores (r, c) but reads (point.y(), point.x()) — transposed (annonet_infer.cpp:210 vs :222); see DESIGN.md.
+static void detection_filter(const float* blended, int K, int H, int W, const double* det, uint16_t* labels) {
+    const size_t plane = (size_t)H * W;
+    std::vector<unsigned> blob(plane, 0);
+    std::vector<size_t> stack;
+    unsigned next_id = 1;
+    for (size_t start = 0; start < plane; ++start) {
+        if (labels[start] == 0 || blob[start]) continue;
+        const uint16_t lab = labels[start];
+        const unsigned id = next_id++;
+        blob[start] = id; stack.push_back(start);
+        while (!stack.empty()) {
+            const size_t cur = stack.back(); stack.pop_back();
+            const long r = (long)(cur / W), c = (long)(cur % W);
+            for (long dr = -1; dr <= 1; ++dr)
+                for (long dc = -1; dc <= 1; ++dc) {
+                    const long r2 = r + dr, c2 = c + dc;
+                    if (r2 < 0 || r2 >= H || c2 < 0 || c2 >= W) continue;
+                    const size_t j = (size_t)r2 * W + c2;
+                    if (blob[j] || labels[j] != lab) continue;
+                    blob[j] = id; stack.push_back(j);
+                }
+        }
+    }
+    std::unordered_set<unsigned> detected;
+    for (size_t i = 0; i < plane; ++i) {
+        const uint16_t lab = labels[i];
+        if (lab == 0 || lab == ANH_LABEL_IGNORE || lab >= K) continue;
+        const float clean = blended[i], mine = blended[(size_t)lab * plane + i];
+        if ((double)(mine - clean) > det[lab] - det[0]) detected.insert(blob[i]);
+    }
+    for (size_t i = 0; i < plane; ++i)
+        if (blob[i] && !detected.count(blob[i])) labels[i] = 0;
+}
+
+int anh_infer(anh_runtime* h, const uint8_t* image, int height, int width, const double* gains, const double* detection_levels,
+              const anh_tiling_params* tiling, uint16_t* result, float* blended_out) {
+    return guarded([&] {
+        ANH_REQUIRE(h && image && result, "null argument");
+        ANH_REQUIRE(height >= 1 && width >= 1, "empty image");
+        Engine& e = *h->eng;
+        const int K = e.spec.cfg.classes, C = e.spec.cfg.in_channels;
+        const size_t plane = (size_t)height * width;
+        std::vector<anh_tile> tiles = tiles_for(tiling, width, height);
+        e.stage_image.reserve(plane * C);
+        e.stage_blended.reserve(plane * K * 4);
+        e.stage_result.reserve(plane * 2);
+        HIP_CHECK(hipMemcpyAsync(e.stage_image.p, image, plane * C, hipMemcpyHostToDevice, e.stream));
+        e.infer_device(e.stage_image.as<uint8_t>(), height, width, gains, tiles, e.stage_result.as<uint16_t>(), e.stage_blended.as<float>());
+        HIP_CHECK(hipMemcpyAsync(result, e.stage_result.p, plane * 2, hipMemcpyDeviceToHost, e.stream));
+        bool use_det = false;
+        if (detection_levels) for (int k = 0; k < K; ++k) { ANH_REQUIRE(detection_levels[k] >= 0.0, "detection levels must be >= 0"); if (detection_levels[k] > 0.0) use_det = true; }
+        std::vector<float> tmp;
+        float* bl = blended_out;
+        if (use_det && !bl) { tmp.resize(plane * K); bl = tmp.data(); }
+        if (bl) HIP_CHECK(hipMemcpyAsync(bl, e.stage_blended.p, plane * K * 4, hipMemcpyDeviceToHost, e.stream));
+        e.synchronize();
+        if (use_det) detection_filter(bl, K, height, width, detection_levels, result);
+    });
+}
+
+int anh_runtime_set_stream(anh_runtime* h, void* s) { return guarded([&] { ANH_REQUIRE(h, "null handle"); h->eng->set_stream((hipStream_t)s); }); }
+int anh_runtime_synchronize(anh_runtime* h) { return guarded([&] { ANH_REQUIRE(h, "null handle"); h->eng->synchronize(); }); }
+
+// ---- TrainingNet ----
+int anh_trainer_create(anh_trainer** out) {
+    return guarded([&] { ANH_REQUIRE(out, "null argument"); *out = new anh_trainer(); });
+}
+void anh_trainer_destroy(anh_trainer* h) { delete h; }
+
+#define TRAINER_SETTER(name, body) \
+    return guarded([&] { ANH_REQUIRE(h, "null handle"); body; })
+
+static void require_not_built(anh_trainer* h) { ANH_REQUIRE(!h->eng, "the net is already built: set this before Initialize()"); }
+
+int anh_trainer_set_net_width(anh_trainer* h, double scaler, int min_filters) {
+    TRAINER_SETTER(net_width, { ANH_REQUIRE(scaler > 0 && min_filters >= 1, "bad net width");
+        if (h->eng) ANH_REQUIRE(scaler == h->cfg.width_scaler && min_filters == h->cfg.min_filters, "SetNetWidth after the net was built must not change it");
+        h->cfg.width_scaler = scaler; h->cfg.min_filters = min_filters; });
+}
+int anh_trainer_set_class_count(anh_trainer* h, size_t classes) {
+    TRAINER_SETTER(class_count, { ANH_REQUIRE(classes >= 1 && classes <= 64, "class count must be 1..64");
+        if (h->eng && (int)classes != h->cfg.classes) {  // dlib sets the output filter count lazily; rebuild with the new head
+            h->cfg.classes = (int)classes;
+            h->eng = std::make_unique<Engine>(h->cfg, true);
+            h->eng->random_init(h->seed);
+        }
+        h->cfg.classes = (int)classes; });
+}
+int anh_trainer_set_levels(anh_trainer* h, int levels) { TRAINER_SETTER(levels, { require_not_built(h); ANH_REQUIRE(levels >= 0 && levels <= 3, "level count must be 0..3"); h->cfg.levels = levels; }); }
+int anh_trainer_set_input_channels(anh_trainer* h, int c) { TRAINER_SETTER(channels, { require_not_built(h); ANH_REQUIRE(c == 1 || c == 3, "input channels must be 1 or 3"); h->cfg.in_channels = c; }); }
+int anh_trainer_set_precision(anh_trainer* h, int p) { TRAINER_SETTER(precision, { require_not_built(h); ANH_REQUIRE(p == ANH_FP32 || p == ANH_BF16, "unknown precision"); h->cfg.precision = p; }); }
+int anh_trainer_set_seed(anh_trainer* h, uint64_t seed) { TRAINER_SETTER(seed, { h->seed = seed; if (h->eng) h->eng->random_init(seed); }); }
+
+int anh_trainer_initialize(anh_trainer* h) {
+    return guarded([&] {
+        ANH_REQUIRE(h, "null handle");
+        h->eng = std::make_unique<Engine>(h->cfg, true);
+        h->eng->random_init(h->seed);
+        if (!h->loss_ring) HIP_CHECK(hipHostMalloc((void**)&h->loss_ring, 256 * sizeof(float), hipHostMallocDefault));
+    });
+}
+int anh_trainer_set_learning_rate(anh_trainer* h, double lr) { TRAINER_SETTER(lr, { ANH_REQUIRE(lr > 0, "learning rate must be positive"); h->sched.lr = lr; }); }
+int anh_trainer_set_learning_rate_shrink_factor(anh_trainer* h, double f) { TRAINER_SETTER(shrink, { ANH_REQUIRE(f > 0 && f <= 1, "shrink factor must be in (0,1]"); h->sched.shrink = f; }); }
+int anh_trainer_set_iterations_without_progress_threshold(anh_trainer* h, unsigned long n) { TRAINER_SETTER(thresh, { h->sched.threshold = n; }); }
+int anh_trainer_set_previous_loss_values_dump_amount(anh_trainer* h, unsigned long n) { TRAINER_SETTER(dump, { h->sched.dump_amount = n; }); }
+int anh_trainer_set_all_bn_running_stats_window_sizes(anh_trainer* h, unsigned long n) { TRAINER_SETTER(window, { ANH_REQUIRE(n >= 1, "window must be >= 1"); h->bn_window = n; }); }
+int anh_trainer_set_sgd(anh_trainer* h, double wd, double mom) { TRAINER_SETTER(sgd, { ANH_REQUIRE(wd >= 0 && mom >= 0 && mom < 1, "bad sgd parameters"); h->weight_decay = wd; h->momentum = mom; }); }
+int anh_trainer_be_verbose(anh_trainer* h) { TRAINER_SETTER(verbose, { h->verbose = true; }); }
+int anh_trainer_set_synchronization_file(anh_trainer* h, const char* path, double seconds) {
+    return guarded([&] {
+        ANH_REQUIRE(h && path, "null argument");
+        h->sync_path = path; h->sync_seconds = seconds;
+        h->last_sync = std::chrono::steady_clock::now();
+        std::ifstream probe(path, std::ios::binary);
+        if (probe.good() && h->eng) {  // dlib's trainer resumes from an existing synchronization file
+            probe.close();
+            const int rc = anh_trainer_load_state(h, path);
+            if (rc != ANH_OK) fail(rc, g_error);
+        }
+    });
+}
+double anh_trainer_get_learning_rate(const anh_trainer* h) {
+    if (!h) return 0;
+    try { const_cast<anh_trainer*>(h)->consume(false); } catch (...) {}
+    return h->sched.lr;
+}
+double anh_trainer_get_last_loss(anh_trainer* h) {
+    double v = NAN;
+    guarded([&] { ANH_REQUIRE(h, "null handle"); h->engine().synchronize(); h->consume(true); v = h->steps ? h->last_loss : h->engine().read_loss(); });
+    return v;
+}
+unsigned long anh_trainer_get_step_count(const anh_trainer* h) { return h ? h->steps : 0; }
+int anh_trainer_config(const anh_trainer* h, anh_net_config* out) { return guarded([&] { ANH_REQUIRE(h && out, "null argument"); *out = h->cfg; }); }
+
+int anh_trainer_forward_backward_device(anh_trainer* h, const uint8_t* d_images, const uint16_t* d_labels, const float* d_weights,
+                                        int n, int height, int width, double loss_scale_n) {
+    return guarded([&] {
+        ANH_REQUIRE(h && d_images && d_labels && d_weights, "null argument");
+        ANH_REQUIRE(loss_scale_n > 0, "loss scale batch must be positive");
+        Engine& e = h->engine();
+        Src img;
+        img.kind = SRC_IMAGE; img.img = d_images; img.img_h = height; img.img_w = width;
+        img.img_sample_stride = (int64_t)height * width * e.spec.cfg.in_channels;
+        e.forward_training(img, n, height, width);
+        e.backward(d_labels, d_weights, loss_scale_n);
+    });
+}
+
+int anh_trainer_apply_update(anh_trainer* h, double grad_scale) {
+    return guarded([&] {
+        ANH_REQUIRE(h, "null handle");
+        Engine& e = h->engine();
+        h->consume(false);
+        e.apply_update(h->sched.lr, h->weight_decay, h->momentum, grad_scale, h->bn_window);
+        // ship this step's loss (gradient bucket's trailing slot: already all-reduced under data parallelism)
+        if (h->pending.size() >= 200) h->consume(true);
+        hipEvent_t ev;
+        if (!h->free_events.empty()) { ev = h->free_events.back(); h->free_events.pop_back(); }
+        else HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        const int slot = h->next_slot;
+        h->next_slot = (h->next_slot + 1) % 256;
+        HIP_CHECK(hipMemcpyAsync(h->loss_ring + slot, e.grad_bucket() + e.spec.n_params, sizeof(float), hipMemcpyDeviceToHost, e.stream));
+        HIP_CHECK(hipEventRecord(ev, e.stream));
+        h->pending.push_back({ev, slot});
+        ++h->steps;
+        if (h->verbose && h->steps % 100 == 0) {
+            h->consume(false);
+            std::printf("step#: %lu  learning rate: %g  loss: %g  steps without apparent progress: %lu\n", h->steps, h->sched.lr, h->last_loss,
+                        h->sched.steps_without_progress);
+            std::fflush(stdout);
+        }
+        if (!h->sync_path.empty() && h->sync_seconds > 0) {
+            const auto now = std::chrono::steady_clock::now();
+            if (std::chrono::duration<double>(now - h->last_sync).count() >= h->sync_seconds) {
+                h->last_sync = now;
+                const int rc = anh_trainer_save_state(h, h->sync_path.c_str());
+                if (rc != ANH_OK) fail(rc, g_error);
+            }
+        }
+    });
+}
+
+int anh_trainer_step(anh_trainer* h, const uint8_t* const* images, const anh_wlabel* const* labels, int n, int height, int width) {
+    return guarded([&] {
+        ANH_REQUIRE(h && images && labels, "null argument");
+        ANH_REQUIRE(n >= 1 && height >= 1 && width >= 1, "empty mini-batch");
+        Engine& e = h->engine();
+        const int C = e.spec.cfg.in_channels, K = e.spec.cfg.classes;
+        const size_t plane = (size_t)height * width;
+        h->pack_img.resize((size_t)n * plane * C);
+        h->pack_lab.resize((size_t)n * plane);
+        h->pack_w.resize((size_t)n * plane);
+        for (int i = 0; i < n; ++i) {
+            ANH_REQUIRE(images[i] && labels[i], "null sample");
+            std::memcpy(h->pack_img.data() + (size_t)i * plane * C, images[i], plane * C);
+            for (size_t p = 0; p < plane; ++p) {
+                const anh_wlabel& wl = labels[i][p];
+                ANH_REQUIRE(wl.label == ANH_LABEL_IGNORE || wl.label < K, "label value exceeds the class count");
+                h->pack_lab[(size_t)i * plane + p] = wl.label;
+                h->pack_w[(size_t)i * plane + p] = wl.weight;
+            }
+        }
+        e.stage_image.reserve(h->pack_img.size());
+        e.stage_labels.reserve(h->pack_lab.size() * 2);
+        e.stage_weights.reserve(h->pack_w.size() * 4);
+        // synchronous copies: the host refills samples/labels right after StartTraining returns (annonet_train_main.cpp:585-586)
+        e.synchronize();
+        HIP_CHECK(hipMemcpy(e.stage_image.p, h->pack_img.data(), h->pack_img.size(), hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(e.stage_labels.p, h->pack_lab.data(), h->pack_lab.size() * 2, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(e.stage_weights.p, h->pack_w.data(), h->pack_w.size() * 4, hipMemcpyHostToDevice));
+        int rc = anh_trainer_forward_backward_device(h, e.stage_image.as<uint8_t>(), e.stage_labels.as<uint16_t>(), e.stage_weights.as<float>(), n, height, width, (double)n);
+        if (rc != ANH_OK) fail(rc, g_error);
+        rc = anh_trainer_apply_update(h, 1.0);
+        if (rc != ANH_OK) fail(rc, g_error);
+    });
+}
+
+int anh_trainer_grad_buffer(anh_trainer* h, void** d_ptr, int64_t* count) {
+    return guarded([&] { ANH_REQUIRE(h && d_ptr && count, "null argument"); *d_ptr = h->engine().grad_bucket(); *count = h->engine().spec.n_params + 1; });
+}
+int anh_trainer_get_params(anh_trainer* h, float* params, int64_t n_params, float* running, int64_t n_running) {
+    return guarded([&] {
+        ANH_REQUIRE(h, "null handle");
+        Engine& e = h->engine();
+        ANH_REQUIRE((!params || n_params == e.spec.n_params) && (!running || n_running == e.spec.n_running), "parameter blob size mismatch");
+        e.get_params(params, running);
+    });
+}
+int anh_trainer_set_params(anh_trainer* h, const float* params, int64_t n_params, const float* running, int64_t n_running) {
+    return guarded([&] {
+        ANH_REQUIRE(h && params && running, "null argument");
+        Engine& e = h->engine();
+        ANH_REQUIRE(n_params == e.spec.n_params && n_running == e.spec.n_running, "parameter blob size mismatch");
+        e.synchronize();
+        e.set_params(params, running);
+    });
+}
+int anh_trainer_get_grads(anh_trainer* h, float* grads, int64_t n_params) {
+    return guarded([&] { ANH_REQUIRE(h && grads, "null argument"); ANH_REQUIRE(n_params == h->engine().spec.n_params, "size mismatch"); h->engine().get_grads_canonical(grads); });
+}
+int anh_trainer_get_momentum(anh_trainer* h, float* m, int64_t n_params) {
+    return guarded([&] { ANH_REQUIRE(h && m, "null argument"); ANH_REQUIRE(n_params == h->engine().spec.n_params, "size mismatch"); h->engine().get_momentum(m); });
+}
+int anh_trainer_set_momentum(anh_trainer* h, const float* m, int64_t n_params) {
+    return guarded([&] { ANH_REQUIRE(h && m, "null argument"); ANH_REQUIRE(n_params == h->engine().spec.n_params, "size mismatch"); h->engine().set_momentum(m); });
+}
+
+int anh_trainer_snapshot_runtime(anh_trainer* h, int precision, anh_runtime** out) {
+    return guarded([&] {
+        ANH_REQUIRE(h && out, "null argument");
+        Engine& e = h->engine();
+        std::vector<float> p((size_t)e.spec.n_params), r((size_t)e.spec.n_running);
+        e.get_params(p.data(), r.data());  // synchronises: a step in flight finishes first (annonet_train_main.cpp:558)
+        anh_net_config cfg = e.spec.cfg;
+        cfg.precision = precision;
+        auto rt = std::make_unique<anh_runtime>();
+        rt->eng = std::make_unique<Engine>(cfg, false);
+        rt->eng->set_params(p.data(), r.data());
+        *out = rt.release();
+    });
+}
+
+int anh_trainer_save_state(anh_trainer* h, const char* path) {
+    return guarded([&] {
+        ANH_REQUIRE(h && path, "null argument");
+        Engine& e = h->engine();
+        e.synchronize();
+        h->consume(true);
+        const Spec& s = e.spec;
+        std::vector<float> p((size_t)s.n_params), m((size_t)s.n_params), r((size_t)s.n_running);
+        e.get_params(p.data(), r.data());
+        e.get_momentum(m.data());
+        const std::string tmp = std::string(path) + ".tmp";
+        {
+            std::ofstream f(tmp, std::ios::binary | std::ios::trunc);
+            if (!f) fail(ANH_ERR_IO, "cannot write " + tmp);
+            BlobHeader hd{};
+            std::memcpy(hd.magic, kStateMagic, 8);
+            hd.levels = s.cfg.levels; hd.in_channels = s.cfg.in_channels; hd.classes = s.cfg.classes; hd.min_filters = s.cfg.min_filters;
+            hd.width_scaler = s.cfg.width_scaler; hd.n_params = s.n_params; hd.n_running = s.n_running;
+            f.write((const char*)&hd, sizeof hd);
+            const uint64_t steps = h->steps, nh = h->sched.history.size(), budget = h->sched.check_budget;
+            f.write((const char*)&steps, 8); f.write((const char*)&h->sched.lr, 8); f.write((const char*)&budget, 8); f.write((const char*)&nh, 8);
+            for (double v : h->sched.history) f.write((const char*)&v, 8);
+            f.write((const char*)p.data(), p.size() * 4); f.write((const char*)m.data(), m.size() * 4); f.write((const char*)r.data(), r.size() * 4);
+            if (!f) fail(ANH_ERR_IO, "short write to " + tmp);
+        }
+        if (std::rename(tmp.c_str(), path) != 0) fail(ANH_ERR_IO, std::string("cannot move state file into place: ") + path);
+    });
+}
+
+int anh_trainer_load_state(anh_trainer* h, const char* path) {
+    return guarded([&] {
+        ANH_REQUIRE(h && path, "null argument");
+        Engine& e = h->engine();
+        std::ifstream f(path, std::ios::binary);
+        if (!f) fail(ANH_ERR_IO, std::string("cannot read ") + path);
+        BlobHeader hd;
+        f.read((char*)&hd, sizeof hd);
+        if (!f || std::memcmp(hd.magic, kStateMagic, 8) != 0) fail(ANH_ERR_IO, "not an annonet_hip trainer state file");
+        const Spec& s = e.spec;
+        if (hd.levels != s.cfg.levels || hd.in_channels != s.cfg.in_channels || hd.classes != s.cfg.classes || hd.n_params != s.n_params || hd.n_running != s.n_running)
+            fail(ANH_ERR_IO, "trainer state file was written for a different net");
+        uint64_t steps = 0, nh = 0, budget = 0;
+        double lr = 0;
+        f.read((char*)&steps, 8); f.read((char*)&lr, 8); f.read((char*)&budget, 8); f.read((char*)&nh, 8);
+        if (!f || nh > (1u << 26)) fail(ANH_ERR_IO, "trainer state file is corrupt");
+        std::deque<double> hist;
+        for (uint64_t i = 0; i < nh; ++i) { double v; f.read((char*)&v, 8); hist.push_back(v); }
+        std::vector<float> p((size_t)s.n_params), m((size_t)s.n_params), r((size_t)s.n_running);
+        f.read((char*)p.data(), p.size() * 4); f.read((char*)m.data(), m.size() * 4); f.read((char*)r.data(), r.size() * 4);
+        if (!f) fail(ANH_ERR_IO, "trainer state file is truncated");
+        e.synchronize();
+        e.set_params(p.data(), r.data());
+        e.set_momentum(m.data());
+        h->steps = (unsigned long)steps; h->sched.lr = lr; h->sched.check_budget = (unsigned long)budget; h->sched.history = hist;
+    });
+}
+
+int anh_trainer_set_stream(anh_trainer* h, void* s) { return guarded([&] { ANH_REQUIRE(h, "null handle"); h->engine().set_stream((hipStream_t)s); }); }
+int anh_trainer_synchronize(anh_trainer* h) {
+    return guarded([&] {
+        ANH_REQUIRE(h, "null handle");
+        h->engine().synchronize();
+        if (h->engine().read_error_flag_and_clear()) fail(ANH_ERR_INVALID, "a label value exceeds the class count");
+    });
+}
+int anh_trainer_layer_tensor(anh_trainer* h, int layer, int which, float* out, int64_t capacity, int dims4[4]) {
+    return guarded([&] { ANH_REQUIRE(h && dims4, "null argument"); h->engine().layer_tensor(layer, which, out, capacity, dims4); });
+}
+
+// ---- profiling ----
+static Engine* engine_of(void* handle, int is_trainer) {
+    ANH_REQUIRE(handle, "null handle");
+    return is_trainer ? &((anh_trainer*)handle)->engine() : ((anh_runtime*)handle)->eng.get();
+}
+int anh_profile_enable(void* handle, int is_trainer, int enable) {
+    return guarded([&] { Engine* e = engine_of(handle, is_trainer); e->synchronize(); e->prof.enabled = enable != 0; });
+}
+int anh_profile_reset(void* handle, int is_trainer) {
+    return guarded([&] { Engine* e = engine_of(handle, is_trainer); e->synchronize(); e->prof.reset(); });
+}
+int anh_profile_count(void* handle, int is_trainer) {
+    int n = -1;
+    guarded([&] { Engine* e = engine_of(handle, is_trainer); e->synchronize(); n = (int)e->prof.entries.size(); });
+    return n;
+}
+int anh_profile_entry(void* handle, int is_trainer, int index, char* name, size_t name_cap, double* total_ms, int64_t* launches, double* flops, double* bytes) {
+    return guarded([&] {
+        Engine* e = engine_of(handle, is_trainer);
+        ANH_REQUIRE(index >= 0 && index < (int)e->prof.entries.size(), "profile index out of range");
+        const Profiler::Entry& en = e->prof.entries[index];
+        if (name && name_cap) { std::strncpy(name, en.name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+        if (total_ms) *total_ms = en.total_ms;
+        if (launches) *launches = en.launches;
+        if (flops) *flops = en.flops;
+        if (bytes) *bytes = en.bytes;
+    });
+}
+
+// ---- host logic ----
+int anh_get_tiles(int width, int height, const anh_tiling_params* params, anh_tile** tiles, size_t* count) {
+    return guarded([&] {
+        ANH_REQUIRE(tiles && count, "null argument");
+        std::vector<anh_tile> t = tiles_for(params, width, height);
+        anh_tile* out = (anh_tile*)std::malloc(std::max<size_t>(1, t.size()) * sizeof(anh_tile));
+        if (!out) fail(ANH_ERR_OOM, "host allocation failed");
+        std::memcpy(out, t.data(), t.size() * sizeof(anh_tile));
+        *tiles = out; *count = t.size();
+    });
+}
+int anh_set_weights(const uint16_t* labels, int nr, int nc, double cw, double iw, anh_wlabel* out) {
+    return guarded([&] { ANH_REQUIRE(labels && out, "null argument"); set_weights(labels, nr, nc, cw, iw, out); });
+}
+int anh_random_rect_containing_point(uint32_t dx, uint32_t dy, long px, long py, long w, long hgt, anh_rect* out) {
+    return guarded([&] { ANH_REQUIRE(out, "null argument"); *out = random_rect_containing_point(dx, dy, px, py, w, hgt); });
+}
+int anh_outpaint(uint8_t* image, int nr, int nc, int channels, const anh_rect* inside) {
+    return guarded([&] { ANH_REQUIRE(image && inside, "null argument"); outpaint(image, nr, nc, channels, *inside); });
+}
+int64_t anh_count_steps_without_decrease(const double* values, int64_t n, double p) {
+    if (!values && n > 0) return -1;
+    return count_steps_without_decrease(values, n, p);
+}
+
+}  // extern "C"

@@ -1,0 +1,53 @@
+// common.h — error plumbing and small device-memory helpers shared by the library's translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/annonet_hip.h"
+
+namespace anh {
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+[[noreturn]] inline void fail(int code, const std::string& msg) { throw Error(code, msg); }
+
+#define ANH_REQUIRE(cond, msg) \
+    do { if (!(cond)) ::anh::fail(ANH_ERR_INVALID, std::string(msg) + " [" #cond "]"); } while (0)
+
+inline void hip_check(hipError_t e, const char* what, const char* file, int line) {
+    if (e == hipSuccess) return;
+    const int code = (e == hipErrorOutOfMemory) ? ANH_ERR_OOM : ANH_ERR_DEVICE;
+    (void)hipGetLastError();
+    fail(code, std::string(what) + ": " + hipGetErrorString(e) + " (" + file + ":" + std::to_string(line) + ")");
+}
+#define HIP_CHECK(expr) ::anh::hip_check((expr), #expr, __FILE__, __LINE__)
+
+// RAII device buffer (grow-only scratch)
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+    DevBuf& operator=(DevBuf&& o) noexcept { release(); p = o.p; bytes = o.bytes; o.p = nullptr; o.bytes = 0; return *this; }
+    ~DevBuf() { release(); }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+    void reserve(size_t n) {
+        if (n <= bytes) return;
+        release();
+        HIP_CHECK(hipMalloc(&p, n));
+        bytes = n;
+    }
+    template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+}  // namespace anh

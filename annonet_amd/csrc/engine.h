@@ -1,0 +1,115 @@
+// engine.h — owns one net's device state on one GPU and sequences the kernels for
+//   * RuntimeNet::Forward and annonet_infer()  (inference: bn folded to affine)
+//   * TrainingNet::StartTraining               (forward, loss, backward, SGD)
+// Everything is enqueued on one HIP stream; nothing synchronises unless the caller asks for host data.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "kernels.h"
+#include "spec.h"
+
+namespace anh {
+
+// Per-kernel-class timing with HIP events on the engine's stream (bench.py's roofline line reads this).
+class Profiler {
+  public:
+    struct Entry { std::string name; double total_ms = 0; int64_t launches = 0; double flops = 0, bytes = 0; };
+    bool enabled = false;
+    ~Profiler();
+    int begin(hipStream_t s, const char* name, double flops, double bytes);  // returns a token (or -1 when disabled)
+    void end(hipStream_t s, int token);
+    void collect();  // stream must be idle
+    void reset();
+    std::vector<Entry> entries;
+
+  private:
+    struct Pending { int entry; hipEvent_t start, stop; };
+    std::vector<Pending> pending_;
+    std::vector<hipEvent_t> pool_;
+    hipEvent_t get_event();
+};
+
+struct LayerState {
+    DevBuf raw;    // raw conv output y (storage dtype), [n][h][w][cout]
+    DevBuf dact;   // gradient w.r.t. this layer's post-activation output; becomes dy in place
+    DevBuf bn;     // mean, invstd, scale, shift (4*C floats) then var (C doubles)
+    float* mean = nullptr; float* invstd = nullptr; float* scale = nullptr; float* shift = nullptr; double* var = nullptr;
+    int n = 0, h_in = 0, w_in = 0, h = 0, w = 0;
+    bool dact_written = false;
+    double running_updates = 0;  // dlib bn_: number of running-stat updates so far (capped by the window)
+};
+
+class Engine {
+  public:
+    Engine(const anh_net_config& cfg, bool training);
+    ~Engine();
+    Engine(const Engine&) = delete;
+    Engine& operator=(const Engine&) = delete;
+
+    Spec spec;
+    DType dtype;
+    bool training;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = true;
+    Profiler prof;
+
+    // ---- parameters ----
+    void set_params(const float* params, const float* running);  // host canonical blobs
+    void get_params(float* params, float* running);              // synchronises
+    void get_grads_canonical(float* out);
+    void get_momentum(float* out);
+    void set_momentum(const float* in);
+    void random_init(uint64_t seed);
+    float* grad_bucket() { return grad.as<float>(); }  // n_params + 1 floats (last = loss)
+
+    // ---- forward ----
+    // image: SRC_IMAGE source (device u8).  Inference writes fp32 NCHW logits to d_out_nchw.
+    void forward_inference(const Src& image, int n, int h, int w, float* d_out_nchw);
+    void forward_training(const Src& image, int n, int h, int w);
+    // ---- training ----
+    void backward(const uint16_t* d_labels, const float* d_weights, double loss_scale_n);
+    void apply_update(double lr, double weight_decay, double momentum, double grad_scale, unsigned long bn_window);
+    double read_loss();  // synchronises
+    int read_error_flag_and_clear();
+    void layer_tensor(int layer, int which, float* out_host, int64_t capacity, int dims[4]);
+
+    // ---- tiled inference: annonet_infer.cpp:42-214 with image, blended planes and labels resident in HBM ----
+    void infer_device(const uint8_t* d_image, int H, int W, const double* gains_host, const std::vector<anh_tile>& tiles,
+                      uint16_t* d_labels, float* d_blended);
+
+    void synchronize();
+    void set_stream(hipStream_t s);
+
+    // scratch exposed to the C ABI layer (host-pointer entry points stage through these)
+    DevBuf stage_image, stage_labels, stage_weights, stage_out, stage_blended, stage_result;
+    std::vector<float> host_out;
+
+  private:
+    void plan_dims(int n, int h, int w);
+    Src layer_source(int li, const Src& image) const;
+    void run_conv_forward(int li, const Src& image, bool training_pass, float* d_out_nchw);
+    void refresh_compute_weights();
+    void fold_running_stats();  // inference: scale/shift from running stats, computed on the host
+    void ensure_training_buffers();
+    void conv_dispatch(const ConvArgs& a, const char* tag, double flops, double bytes);
+    void wgrad_dispatch(WgradArgs& a, const char* tag, double flops, double bytes);
+
+    std::vector<LayerState> ls;
+    std::vector<ParamSegment> segments_host;
+    DevBuf segments;
+    DevBuf master, momentum, grad, w_tm_f32, w_km_f32, w_tm_bf16, w_km_bf16, running;
+    DevBuf bn_partials, wgrad_partials, loss_partials, coef, logits, dlogits, scalars, gains_dev, tile_out;
+    double* loss_dev = nullptr;
+    int* error_flag = nullptr;
+    std::vector<float> host_params, host_running;  // mirror kept for inference folding / serialization
+    Src last_image{};
+    int last_n = 0, last_h = 0, last_w = 0;
+    bool have_forward = false;
+};
+
+}  // namespace anh

@@ -1,0 +1,528 @@
+#include "engine.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "hostlogic.h"
+
+namespace anh {
+
+// kernels_mfma.hip
+bool mfma_conv_supported(const ConvArgs& a);
+void launch_conv_mfma(const ConvArgs& a, hipStream_t s);
+bool mfma_wgrad_supported(const WgradArgs& a);
+void launch_wgrad_mfma(const WgradArgs& a, hipStream_t s);
+int64_t wgrad_mfma_scratch_floats(const WgradArgs& a);
+
+namespace {
+constexpr float kBnEps = 1e-4f;  // dlib DEFAULT_BATCH_NORM_EPS [UPSTREAM-UNVERIFIED]
+inline size_t elem_size(DType d) { return d == DT_BF16 ? 2 : 4; }
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------
+// Profiler
+// ---------------------------------------------------------------------------------------------------
+Profiler::~Profiler() {
+    for (auto& p : pending_) { (void)hipEventDestroy(p.start); (void)hipEventDestroy(p.stop); }
+    for (auto e : pool_) (void)hipEventDestroy(e);
+}
+hipEvent_t Profiler::get_event() {
+    if (!pool_.empty()) { hipEvent_t e = pool_.back(); pool_.pop_back(); return e; }
+    hipEvent_t e;
+    HIP_CHECK(hipEventCreate(&e));
+    return e;
+}
+int Profiler::begin(hipStream_t s, const char* name, double flops, double bytes) {
+    if (!enabled) return -1;
+    int idx = -1;
+    for (size_t i = 0; i < entries.size(); ++i) if (entries[i].name == name) { idx = (int)i; break; }
+    if (idx < 0) { entries.push_back(Entry{name}); idx = (int)entries.size() - 1; }
+    entries[idx].flops += flops;
+    entries[idx].bytes += bytes;
+    entries[idx].launches += 1;
+    Pending p{idx, get_event(), get_event()};
+    HIP_CHECK(hipEventRecord(p.start, s));
+    pending_.push_back(p);
+    return (int)pending_.size() - 1;
+}
+void Profiler::end(hipStream_t s, int token) {
+    if (token < 0) return;
+    HIP_CHECK(hipEventRecord(pending_[token].stop, s));
+}
+void Profiler::collect() {
+    for (auto& p : pending_) {
+        float ms = 0;
+        HIP_CHECK(hipEventElapsedTime(&ms, p.start, p.stop));
+        entries[p.entry].total_ms += ms;
+        pool_.push_back(p.start);
+        pool_.push_back(p.stop);
+    }
+    pending_.clear();
+}
+void Profiler::reset() { collect(); entries.clear(); }
+
+// ---------------------------------------------------------------------------------------------------
+// construction / parameters
+// ---------------------------------------------------------------------------------------------------
+Engine::Engine(const anh_net_config& cfg, bool training_) : spec(Spec::build(cfg)), training(training_) {
+    dtype = cfg.precision == ANH_BF16 ? DT_BF16 : DT_F32;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0) { (void)hipGetLastError(); fail(ANH_ERR_DEVICE, "no MI355X / HIP device visible"); }
+    HIP_CHECK(hipGetDevice(&device));
+    HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    const size_t np = (size_t)spec.n_params;
+    master.reserve(np * 4);
+    w_tm_f32.reserve(np * 4);
+    w_km_f32.reserve(np * 4);
+    if (dtype == DT_BF16) { w_tm_bf16.reserve(np * 2); w_km_bf16.reserve(np * 2); }
+    running.reserve(std::max<size_t>(1, (size_t)spec.n_running) * 4);
+    if (training) {
+        momentum.reserve(np * 4);
+        grad.reserve((np + 1) * 4);
+        HIP_CHECK(hipMemsetAsync(momentum.p, 0, np * 4, stream));
+        HIP_CHECK(hipMemsetAsync(grad.p, 0, (np + 1) * 4, stream));
+    }
+    scalars.reserve(64);
+    HIP_CHECK(hipMemsetAsync(scalars.p, 0, 64, stream));
+    loss_dev = scalars.as<double>();
+    error_flag = reinterpret_cast<int*>(scalars.as<char>() + 16);
+
+    for (size_t li = 0; li < spec.layers.size(); ++li) {
+        const anh_layer_desc& L = spec.layers[li];
+        ParamSegment f{L.w_off, spec.filter_count((int)li), 0, L.type, L.k, L.cin, L.cout};
+        segments_host.push_back(f);
+        if (L.has_bias) segments_host.push_back({L.b_off, L.cout, 1, 0, 1, 1, L.cout});
+        if (L.has_bn) {
+            segments_host.push_back({L.g_off, L.cout, 1, 0, 1, 1, L.cout});
+            segments_host.push_back({L.beta_off, L.cout, 1, 0, 1, 1, L.cout});
+        }
+    }
+    segments.reserve(segments_host.size() * sizeof(ParamSegment));
+    HIP_CHECK(hipMemcpyAsync(segments.p, segments_host.data(), segments_host.size() * sizeof(ParamSegment), hipMemcpyHostToDevice, stream));
+
+    ls.resize(spec.layers.size());
+    int max_c = 1;
+    for (size_t li = 0; li < spec.layers.size(); ++li) {
+        const int C = spec.layers[li].cout;
+        max_c = std::max(max_c, C);
+        LayerState& s = ls[li];
+        s.bn.reserve((size_t)C * (4 * sizeof(float) + sizeof(double)));
+        s.mean = s.bn.as<float>(); s.invstd = s.mean + C; s.scale = s.invstd + C; s.shift = s.scale + C;
+        s.var = reinterpret_cast<double*>(s.shift + C);
+    }
+    coef.reserve((size_t)max_c * 3 * sizeof(float));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    random_init(0);
+}
+
+Engine::~Engine() {
+    if (stream && own_stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
+}
+
+void Engine::set_stream(hipStream_t s) {
+    synchronize();
+    if (own_stream && stream) (void)hipStreamDestroy(stream);
+    if (s) { stream = s; own_stream = false; }
+    else { HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)); own_stream = true; }
+}
+
+void Engine::synchronize() {
+    HIP_CHECK(hipStreamSynchronize(stream));
+    if (prof.enabled) prof.collect();
+}
+
+void Engine::refresh_compute_weights() {
+    SgdArgs a;
+    a.segments = segments.as<ParamSegment>(); a.n_segments = (int)segments_host.size();
+    a.n_params = spec.n_params;
+    a.master = master.as<float>();
+    a.w_tm_f32 = w_tm_f32.as<float>(); a.w_km_f32 = w_km_f32.as<float>();
+    a.w_tm_bf16 = w_tm_bf16.p; a.w_km_bf16 = w_km_bf16.p;
+    a.apply = 0;
+    launch_sgd(a, stream);
+}
+
+// inference: bn layers act as dlib "affine" layers; fold gamma/beta/running stats on the host so that the
+// result is bit-identical to the oracle's fold.
+void Engine::fold_running_stats() {
+    std::vector<float> buf;
+    for (size_t li = 0; li < spec.layers.size(); ++li) {
+        const anh_layer_desc& L = spec.layers[li];
+        if (!L.has_bn) continue;
+        const int C = L.cout;
+        buf.assign((size_t)2 * C, 0.f);
+        const float* g = host_params.data() + L.g_off;
+        const float* b = host_params.data() + L.beta_off;
+        const float* rm = host_running.data() + L.rs_off;
+        const float* rv = rm + C;
+        for (int c = 0; c < C; ++c) {
+            const float invstd = 1.0f / std::sqrt(rv[c] + kBnEps);
+            buf[c] = g[c] * invstd;
+            buf[C + c] = std::fmaf(-rm[c], buf[c], b[c]);
+        }
+        HIP_CHECK(hipMemcpyAsync(ls[li].scale, buf.data(), (size_t)2 * C * sizeof(float), hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));  // buf is reused
+    }
+}
+
+void Engine::set_params(const float* params, const float* running_stats) {
+    host_params.assign(params, params + spec.n_params);
+    if (running_stats) host_running.assign(running_stats, running_stats + spec.n_running);
+    HIP_CHECK(hipMemcpyAsync(master.p, host_params.data(), (size_t)spec.n_params * 4, hipMemcpyHostToDevice, stream));
+    if (spec.n_running) HIP_CHECK(hipMemcpyAsync(running.p, host_running.data(), (size_t)spec.n_running * 4, hipMemcpyHostToDevice, stream));
+    refresh_compute_weights();
+    HIP_CHECK(hipStreamSynchronize(stream));
+    if (!training) fold_running_stats();
+}
+
+void Engine::get_params(float* params, float* running_stats) {
+    synchronize();
+    if (params) HIP_CHECK(hipMemcpy(params, master.p, (size_t)spec.n_params * 4, hipMemcpyDeviceToHost));
+    if (running_stats && spec.n_running) HIP_CHECK(hipMemcpy(running_stats, running.p, (size_t)spec.n_running * 4, hipMemcpyDeviceToHost));
+}
+
+void Engine::get_grads_canonical(float* out) {
+    ANH_REQUIRE(training, "not a training net");
+    DevBuf tmp;
+    tmp.reserve((size_t)spec.n_params * 4);
+    launch_tm_to_canonical(segments.as<ParamSegment>(), (int)segments_host.size(), spec.n_params, grad.as<float>(), tmp.as<float>(), stream);
+    synchronize();
+    HIP_CHECK(hipMemcpy(out, tmp.p, (size_t)spec.n_params * 4, hipMemcpyDeviceToHost));
+}
+
+void Engine::get_momentum(float* out) {
+    ANH_REQUIRE(training, "not a training net");
+    synchronize();
+    HIP_CHECK(hipMemcpy(out, momentum.p, (size_t)spec.n_params * 4, hipMemcpyDeviceToHost));
+}
+void Engine::set_momentum(const float* in) {
+    ANH_REQUIRE(training, "not a training net");
+    synchronize();
+    HIP_CHECK(hipMemcpy(momentum.p, in, (size_t)spec.n_params * 4, hipMemcpyHostToDevice));
+}
+
+// dlib-style initialisation [UPSTREAM-UNVERIFIED]: filters uniform in +-sqrt(6/(fan_in+fan_out)), bias 0, gamma 1, beta 0,
+// running mean 0 / variance 1.  splitmix64 keeps it reproducible across hosts.
+void Engine::random_init(uint64_t seed) {
+    std::vector<float> p((size_t)spec.n_params, 0.f), r((size_t)spec.n_running, 0.f);
+    uint64_t state = seed * 0x9E3779B97F4A7C15ull + 0x1234567ull;
+    auto next = [&]() {
+        uint64_t z = (state += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    };
+    for (size_t li = 0; li < spec.layers.size(); ++li) {
+        const anh_layer_desc& L = spec.layers[li];
+        const int64_t nw = spec.filter_count((int)li);
+        const double fan = (double)L.k * L.k * (L.cin + L.cout);
+        const double lim = std::sqrt(6.0 / fan);
+        for (int64_t i = 0; i < nw; ++i) {
+            const double u = (double)(next() >> 11) * (1.0 / 9007199254740992.0);
+            p[L.w_off + i] = (float)((2.0 * u - 1.0) * lim);
+        }
+        if (L.has_bn) for (int c = 0; c < L.cout; ++c) { p[L.g_off + c] = 1.f; r[L.rs_off + L.cout + c] = 1.f; }
+    }
+    set_params(p.data(), r.data());
+    for (auto& s : ls) s.running_updates = 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------------
+void Engine::plan_dims(int n, int h, int w) {
+    ANH_REQUIRE(n >= 1, "empty batch");
+    ANH_REQUIRE(spec.valid_input_dim(h) && spec.valid_input_dim(w),
+                "input size is not a valid net input dimension (see GetRecommendedInputDimension)");
+    const size_t es = elem_size(dtype);
+    size_t bn_need = 0;
+    for (size_t li = 0; li < spec.layers.size(); ++li) {
+        const anh_layer_desc& L = spec.layers[li];
+        LayerState& s = ls[li];
+        s.n = n;
+        s.h_in = L.in_a < 0 ? h : ls[L.in_a].h;
+        s.w_in = L.in_a < 0 ? w : ls[L.in_a].w;
+        s.h = Spec::out_dim(L, s.h_in);
+        s.w = Spec::out_dim(L, s.w_in);
+        ANH_REQUIRE(s.h >= 1 && s.w >= 1, "input too small for this net depth");
+        if (L.in_b >= 0) ANH_REQUIRE(ls[L.in_b].h == s.h_in && ls[L.in_b].w == s.w_in, "skip connection size mismatch");
+        const size_t elems = (size_t)n * s.h * s.w * L.cout;
+        if (L.has_bn) {
+            s.raw.reserve(elems * es);
+            if (training) s.dact.reserve(elems * es);
+            bn_need = std::max(bn_need, (size_t)bn_partial_blocks((int64_t)n * s.h * s.w) * 2 * L.cout * sizeof(double));
+        }
+    }
+    const anh_layer_desc& head = spec.layers.back();
+    ANH_REQUIRE(ls.back().h == h && ls.back().w == w, "net output size differs from its input size");
+    if (training) {
+        const size_t P = (size_t)n * h * w;
+        logits.reserve(P * head.cout * 4);
+        dlogits.reserve(P * head.cout * 4);
+        loss_partials.reserve((size_t)loss_partial_blocks((int64_t)P) * (head.cout + 1) * sizeof(double));
+        bn_partials.reserve(bn_need);
+    }
+}
+
+Src Engine::layer_source(int li, const Src& image) const {
+    const anh_layer_desc& L = spec.layers[li];
+    if (L.in_a < 0) return image;
+    Src s;
+    s.dtype = dtype;
+    s.kind = L.in_b >= 0 ? SRC_ACT2 : SRC_ACT;
+    s.a = ls[L.in_a].raw.p; s.a_scale = ls[L.in_a].scale; s.a_shift = ls[L.in_a].shift;
+    if (L.in_b >= 0) { s.b = ls[L.in_b].raw.p; s.b_scale = ls[L.in_b].scale; s.b_shift = ls[L.in_b].shift; }
+    return s;
+}
+
+void Engine::conv_dispatch(const ConvArgs& a, const char* tag, double flops, double bytes) {
+    const bool fast = dtype == DT_BF16 && mfma_conv_supported(a);
+    std::string name = std::string(fast ? "conv_mfma_bf16:" : (dtype == DT_BF16 ? "conv_generic_bf16:" : "conv_generic_f32:")) + tag;
+    const int tok = prof.begin(stream, name.c_str(), flops, bytes);
+    if (fast) launch_conv_mfma(a, stream);
+    else launch_conv_generic(a, stream);
+    prof.end(stream, tok);
+}
+
+void Engine::wgrad_dispatch(WgradArgs& a, const char* tag, double flops, double bytes) {
+    const bool fast = dtype == DT_BF16 && mfma_wgrad_supported(a);
+    const int64_t need = fast ? wgrad_mfma_scratch_floats(a) : wgrad_generic_scratch_floats(a);
+    wgrad_partials.reserve((size_t)need * 4);
+    a.partials = wgrad_partials.as<float>();
+    a.partials_capacity = (int64_t)(wgrad_partials.bytes / 4);
+    std::string name = std::string(fast ? "wgrad_mfma_bf16:" : (dtype == DT_BF16 ? "wgrad_generic_bf16:" : "wgrad_generic_f32:")) + tag;
+    const int tok = prof.begin(stream, name.c_str(), flops, bytes);
+    if (fast) launch_wgrad_mfma(a, stream);
+    else launch_wgrad_generic(a, stream);
+    prof.end(stream, tok);
+}
+
+static const char* layer_tag(const anh_layer_desc& L) {
+    if (L.in_a < 0) return "stem";
+    if (!L.has_bn) return "head";
+    if (L.type == 1) return "cont3x3s2";
+    return L.stride == 2 ? "con3x3s2" : "con3x3s1";
+}
+
+void Engine::run_conv_forward(int li, const Src& image, bool training_pass, float* d_out_nchw) {
+    const anh_layer_desc& L = spec.layers[li];
+    LayerState& s = ls[li];
+    ConvArgs a;
+    a.src = layer_source(li, image);
+    a.n = s.n; a.h_in = s.h_in; a.w_in = s.w_in; a.c_red = L.cin;
+    a.h_out = s.h; a.w_out = s.w; a.c_out = L.cout;
+    a.k = L.k; a.stride = L.stride; a.pad = L.pad; a.gather = L.type;
+    a.w_f32 = w_tm_f32.as<float>() + L.w_off;
+    a.w_bf16 = dtype == DT_BF16 ? (const void*)(w_km_bf16.as<uint16_t>() + L.w_off) : nullptr;
+    a.bias = L.has_bias ? master.as<float>() + L.b_off : nullptr;
+    const int64_t p_out = (int64_t)s.n * s.h * s.w, p_in = (int64_t)s.n * s.h_in * s.w_in;
+    if (L.has_bn) { a.out = s.raw.p; a.out_dtype = dtype; }
+    else if (training_pass) { a.out = logits.p; a.out_dtype = DT_F32; }
+    else { a.out = d_out_nchw; a.out_dtype = DT_F32; a.out_nchw = 1; }
+    const double flops = 2.0 * L.k * L.k * L.cin * L.cout * (double)(L.type == 0 ? p_out : p_in);
+    const double es = (double)elem_size(dtype);
+    const double bytes = (double)p_in * L.cin * (L.in_a < 0 ? 1.0 : es) * (L.in_b >= 0 ? 2 : 1) + (double)p_out * L.cout * (L.has_bn ? es : 4.0) +
+                         (double)spec.filter_count(li) * es;
+    conv_dispatch(a, (std::string("fwd_") + layer_tag(L)).c_str(), flops, bytes);
+    if (L.has_bn && training_pass) {
+        BnFwdArgs b;
+        b.y = s.raw.p; b.dtype = dtype; b.pixels = p_out; b.c = L.cout;
+        b.gamma = master.as<float>() + L.g_off; b.beta = master.as<float>() + L.beta_off;
+        b.mean = s.mean; b.invstd = s.invstd; b.scale = s.scale; b.shift = s.shift; b.var = s.var;
+        b.partials = bn_partials.as<double>(); b.eps = kBnEps;
+        const int tok = prof.begin(stream, "bn_forward_stats", 0, (double)p_out * L.cout * es);
+        launch_bn_forward_stats(b, stream);
+        prof.end(stream, tok);
+    }
+}
+
+void Engine::forward_inference(const Src& image, int n, int h, int w, float* d_out_nchw) {
+    ANH_REQUIRE(!training, "forward_inference on a training net: take a runtime snapshot first");
+    plan_dims(n, h, w);
+    for (size_t li = 0; li < spec.layers.size(); ++li) run_conv_forward((int)li, image, false, d_out_nchw);
+}
+
+void Engine::forward_training(const Src& image, int n, int h, int w) {
+    ANH_REQUIRE(training, "not a training net");
+    plan_dims(n, h, w);
+    for (size_t li = 0; li < spec.layers.size(); ++li) run_conv_forward((int)li, image, true, nullptr);
+    last_image = image; last_n = n; last_h = h; last_w = w;
+    have_forward = true;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// backward + update
+// ---------------------------------------------------------------------------------------------------
+void Engine::backward(const uint16_t* d_labels, const float* d_weights, double loss_scale_n) {
+    ANH_REQUIRE(training && have_forward, "backward without a training forward");
+    const int nl = (int)spec.layers.size();
+    const anh_layer_desc& head = spec.layers.back();
+    const int64_t P = (int64_t)last_n * last_h * last_w;
+    const double es = (double)elem_size(dtype);
+    {
+        LossArgs a;
+        a.logits = logits.as<float>(); a.labels = d_labels; a.weights = d_weights; a.dlogits = dlogits.as<float>();
+        a.pixels = P; a.k = head.cout;
+        a.scale = 1.0 / (loss_scale_n * (double)last_h * (double)last_w);
+        a.partials = loss_partials.as<double>(); a.loss_out = loss_dev;
+        a.loss_out_f32 = grad.as<float>() + spec.n_params;
+        a.dbias = grad.as<float>() + head.b_off;
+        a.error_flag = error_flag;
+        const int tok = prof.begin(stream, "softmax_logloss", 0, (double)P * (head.cout * 8.0 + 6.0));
+        launch_loss(a, stream);
+        prof.end(stream, tok);
+    }
+    for (auto& s : ls) s.dact_written = false;
+    for (int li = nl - 1; li >= 0; --li) {
+        const anh_layer_desc& L = spec.layers[li];
+        LayerState& s = ls[li];
+        const int64_t p_out = (int64_t)s.n * s.h * s.w, p_in = (int64_t)s.n * s.h_in * s.w_in;
+        const void* dy;
+        DType dy_dt;
+        if (L.has_bn) {
+            ANH_REQUIRE(s.dact_written, "internal: layer output has no consumer");
+            BnBwdArgs b;
+            b.da = s.dact.p; b.y = s.raw.p; b.dtype = dtype; b.pixels = p_out; b.c = L.cout;
+            b.gamma = master.as<float>() + L.g_off; b.mean = s.mean; b.invstd = s.invstd; b.scale = s.scale; b.shift = s.shift;
+            b.dgamma = grad.as<float>() + L.g_off; b.dbeta = grad.as<float>() + L.beta_off;
+            b.partials = bn_partials.as<double>(); b.coef = coef.as<float>();
+            const int tok = prof.begin(stream, "bn_relu_backward", 0, (double)p_out * L.cout * es * 5);
+            launch_bn_backward(b, stream);
+            prof.end(stream, tok);
+            dy = s.dact.p; dy_dt = dtype;
+        } else { dy = dlogits.p; dy_dt = DT_F32; }
+
+        const double flops = 2.0 * L.k * L.k * L.cin * L.cout * (double)(L.type == 0 ? p_out : p_in);
+        {   // filter gradient
+            WgradArgs g;
+            g.src = layer_source(li, last_image);
+            g.dy = dy; g.dy_dtype = dy_dt;
+            g.n = s.n; g.h_in = s.h_in; g.w_in = s.w_in; g.c_in = L.cin;
+            g.h_out = s.h; g.w_out = s.w; g.c_out = L.cout;
+            g.k = L.k; g.stride = L.stride; g.pad = L.pad; g.gather = L.type;
+            g.dw = grad.as<float>() + L.w_off;
+            const double bytes = (double)p_in * L.cin * (L.in_a < 0 ? 1.0 : es) * (L.in_b >= 0 ? 2 : 1) + (double)p_out * L.cout * (L.has_bn ? es : 4.0);
+            wgrad_dispatch(g, (std::string("wgrad_") + layer_tag(L)).c_str(), flops, bytes);
+        }
+        if (L.in_a >= 0) {   // data gradient -> d(activation of the producing layers)
+            ConvArgs a;
+            a.src.kind = SRC_RAW; a.src.dtype = dy_dt; a.src.a = dy;
+            a.n = s.n; a.h_in = s.h; a.w_in = s.w; a.c_red = L.cout;
+            a.h_out = s.h_in; a.w_out = s.w_in; a.c_out = L.cin;
+            a.k = L.k; a.stride = L.stride; a.pad = L.pad; a.gather = 1 - L.type;
+            a.w_f32 = w_km_f32.as<float>() + L.w_off;
+            a.w_bf16 = dtype == DT_BF16 ? (const void*)(w_tm_bf16.as<uint16_t>() + L.w_off) : nullptr;
+            a.out = ls[L.in_a].dact.p; a.out_dtype = dtype; a.out_accumulate = ls[L.in_a].dact_written ? 1 : 0;
+            ls[L.in_a].dact_written = true;
+            if (L.in_b >= 0) {
+                a.out2 = ls[L.in_b].dact.p; a.out2_accumulate = ls[L.in_b].dact_written ? 1 : 0;
+                ls[L.in_b].dact_written = true;
+            }
+            const double bytes = (double)p_out * L.cout * (L.has_bn ? es : 4.0) + (double)p_in * L.cin * es * (L.in_b >= 0 ? 2 : 1) * (a.out_accumulate ? 2 : 1);
+            conv_dispatch(a, (std::string("dgrad_") + layer_tag(L)).c_str(), flops, bytes);
+        }
+    }
+}
+
+void Engine::apply_update(double lr, double weight_decay, double momentum_coef, double grad_scale, unsigned long bn_window) {
+    ANH_REQUIRE(training && have_forward, "apply_update without a step");
+    for (size_t li = 0; li < spec.layers.size(); ++li) {
+        const anh_layer_desc& L = spec.layers[li];
+        if (!L.has_bn) continue;
+        LayerState& s = ls[li];
+        const double P = (double)s.n * s.h * s.w;
+        const double af = 1.0 / (s.running_updates + 1.0);
+        if (s.running_updates + 1.0 < (double)bn_window) s.running_updates += 1.0;
+        launch_bn_running_update(s.mean, s.var, running.as<float>() + L.rs_off, running.as<float>() + L.rs_off + L.cout, L.cout, af,
+                                 P > 1 ? P / (P - 1.0) : 1.0, stream);
+    }
+    SgdArgs a;
+    a.segments = segments.as<ParamSegment>(); a.n_segments = (int)segments_host.size();
+    a.n_params = spec.n_params;
+    a.master = master.as<float>(); a.momentum = momentum.as<float>(); a.grad_tm = grad.as<float>();
+    a.w_tm_f32 = w_tm_f32.as<float>(); a.w_km_f32 = w_km_f32.as<float>();
+    a.w_tm_bf16 = w_tm_bf16.p; a.w_km_bf16 = w_km_bf16.p;
+    a.lr = lr; a.weight_decay = weight_decay; a.momentum_coef = momentum_coef; a.grad_scale = grad_scale; a.apply = 1;
+    const int tok = prof.begin(stream, "sgd_momentum_wd", 0, (double)spec.n_params * 28);
+    launch_sgd(a, stream);
+    prof.end(stream, tok);
+}
+
+double Engine::read_loss() {
+    synchronize();
+    float v = 0;
+    HIP_CHECK(hipMemcpy(&v, grad.as<float>() + spec.n_params, sizeof(float), hipMemcpyDeviceToHost));
+    return (double)v;
+}
+
+int Engine::read_error_flag_and_clear() {
+    synchronize();
+    int v = 0;
+    HIP_CHECK(hipMemcpy(&v, error_flag, sizeof(int), hipMemcpyDeviceToHost));
+    if (v) HIP_CHECK(hipMemset(error_flag, 0, sizeof(int)));
+    return v;
+}
+
+void Engine::layer_tensor(int layer, int which, float* out_host, int64_t capacity, int dims[4]) {
+    ANH_REQUIRE(layer >= 0 && layer < (int)ls.size(), "layer index out of range");
+    const anh_layer_desc& L = spec.layers[layer];
+    const LayerState& s = ls[layer];
+    dims[0] = s.n; dims[1] = s.h; dims[2] = s.w; dims[3] = L.cout;
+    const int64_t elems = (int64_t)s.n * s.h * s.w * L.cout;
+    if (!out_host) return;
+    ANH_REQUIRE(elems <= capacity, "buffer too small");
+    synchronize();
+    const void* src;
+    DType dt = dtype;
+    if (!L.has_bn) { src = which == 0 ? logits.p : dlogits.p; dt = DT_F32; ANH_REQUIRE(training, "head taps exist only on a training net"); }
+    else src = which == 0 ? s.raw.p : s.dact.p;
+    ANH_REQUIRE(src != nullptr, "tensor not available");
+    if (dt == DT_F32) HIP_CHECK(hipMemcpy(out_host, src, (size_t)elems * 4, hipMemcpyDeviceToHost));
+    else {
+        std::vector<uint16_t> tmp((size_t)elems);
+        HIP_CHECK(hipMemcpy(tmp.data(), src, (size_t)elems * 2, hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < elems; ++i) { uint32_t u = (uint32_t)tmp[i] << 16; std::memcpy(out_host + i, &u, 4); }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// tiled inference (annonet_infer.cpp:42-214)
+// ---------------------------------------------------------------------------------------------------
+void Engine::infer_device(const uint8_t* d_image, int H, int W, const double* gains_host, const std::vector<anh_tile>& tiles,
+                          uint16_t* d_labels, float* d_blended) {
+    ANH_REQUIRE(H >= 1 && W >= 1, "empty image");
+    const int K = spec.cfg.classes;
+    const int64_t pixels = (int64_t)H * W;
+    launch_fill_zero(d_blended, (size_t)K * pixels * 4, stream);
+    for (const anh_tile& t : tiles) {
+        const TileWindow win = tile_window(t, spec.cfg.levels);
+        Src image;
+        image.kind = SRC_IMAGE;
+        image.img = d_image; image.img_h = H; image.img_w = W; image.img_left = win.left; image.img_top = win.top;
+        tile_out.reserve((size_t)K * win.height * win.width * 4);
+        forward_inference(image, 1, win.height, win.width, tile_out.as<float>());
+        BlendArgs b;
+        b.logits_nchw = tile_out.as<float>(); b.blended = d_blended;
+        b.k = K; b.tile_h = win.height; b.tile_w = win.width; b.tile_left = win.left; b.tile_top = win.top;
+        b.img_h = H; b.img_w = W;
+        b.full[0] = t.full_rect.left; b.full[1] = t.full_rect.top; b.full[2] = t.full_rect.right; b.full[3] = t.full_rect.bottom;
+        b.unique[0] = t.unique_rect.left; b.unique[1] = t.unique_rect.top; b.unique[2] = t.unique_rect.right; b.unique[3] = t.unique_rect.bottom;
+        const int tok = prof.begin(stream, "blend_accumulate", 0, (double)K * win.height * win.width * 12);
+        launch_blend(b, stream);
+        prof.end(stream, tok);
+    }
+    const double* d_gains = nullptr;
+    if (gains_host) {
+        gains_dev.reserve((size_t)K * sizeof(double));
+        HIP_CHECK(hipMemcpyAsync(gains_dev.p, gains_host, (size_t)K * sizeof(double), hipMemcpyHostToDevice, stream));
+        d_gains = gains_dev.as<double>();
+    }
+    if (d_labels) {
+        const int tok = prof.begin(stream, "argmax_gain", 0, (double)pixels * (K * 4.0 + 2.0));
+        launch_argmax(d_blended, K, pixels, d_gains, d_labels, stream);
+        prof.end(stream, tok);
+    }
+}
+
+}  // namespace anh

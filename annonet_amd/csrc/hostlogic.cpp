@@ -1,0 +1,191 @@
+#include "hostlogic.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+
+#include "common.h"
+#include "spec.h"
+
+namespace anh {
+
+// ---------------------------------------------------------------------------------------------------
+// Tiler — stand-in for tiling::get_tiles (tiling/tiling.{h,cpp} absent; contract from annonet_infer.cpp:42-164):
+// full_rects cover the image with >= overlap shared pixels between neighbours, unique_rect is the part of a
+// full_rect no other tile covers, and a single tile has unique == full.  Tiles come out row-major.
+// ---------------------------------------------------------------------------------------------------
+namespace {
+struct Span { long first, last; };
+
+std::vector<Span> cut_axis(long extent, long max_len, long overlap) {
+    std::vector<Span> cuts;
+    if (extent <= 0) return cuts;
+    if (extent <= max_len) { cuts.push_back({0, extent - 1}); return cuts; }
+    ANH_REQUIRE(overlap >= 0, "overlap must not be negative");
+    ANH_REQUIRE(max_len > 2 * overlap, "max tile size must exceed twice the overlap");
+    const long stride_max = max_len - overlap;
+    const long pieces = (extent - overlap + stride_max - 1) / stride_max;
+    const long len = (extent + (pieces - 1) * overlap + pieces - 1) / pieces;
+    for (long i = 0; i < pieces; ++i) {
+        const long first = i * (extent - len) / (pieces - 1);
+        cuts.push_back({first, first + len - 1});
+    }
+    for (long i = 0; i + 2 < pieces; ++i)
+        ANH_REQUIRE(cuts[i + 2].first > cuts[i].last + 1, "max tile size is too small for this overlap");
+    return cuts;
+}
+
+Span exclusive_part(const std::vector<Span>& cuts, size_t i, long extent) {
+    return {i == 0 ? 0 : cuts[i - 1].last + 1, i + 1 == cuts.size() ? extent - 1 : cuts[i + 1].first - 1};
+}
+}  // namespace
+
+std::vector<anh_tile> make_tiles(int width, int height, const anh_tiling_params& p) {
+    ANH_REQUIRE(width >= 0 && height >= 0, "negative image size");
+    ANH_REQUIRE(p.max_tile_width >= 1 && p.max_tile_height >= 1, "max tile size must be positive");
+    const std::vector<Span> cols = cut_axis(width, p.max_tile_width, p.overlap_x);
+    const std::vector<Span> rows = cut_axis(height, p.max_tile_height, p.overlap_y);
+    std::vector<anh_tile> tiles;
+    tiles.reserve(cols.size() * rows.size());
+    for (size_t r = 0; r < rows.size(); ++r) {
+        const Span uy = exclusive_part(rows, r, height);
+        for (size_t c = 0; c < cols.size(); ++c) {
+            const Span ux = exclusive_part(cols, c, width);
+            anh_tile t;
+            t.full_rect = {cols[c].first, rows[r].first, cols[c].last, rows[r].last};
+            t.unique_rect = {ux.first, uy.first, ux.last, uy.last};
+            tiles.push_back(t);
+        }
+    }
+    return tiles;
+}
+
+// annonet_infer.cpp:46-66: centre = tl + size/2 (integer division); side = GetRecommendedInputDimension(full side);
+// left = cx - side/2.
+TileWindow tile_window(const anh_tile& t, int levels) {
+    const long fw = t.full_rect.right - t.full_rect.left + 1, fh = t.full_rect.bottom - t.full_rect.top + 1;
+    const long cx = t.full_rect.left + fw / 2, cy = t.full_rect.top + fh / 2;
+    TileWindow w;
+    w.width = Spec::recommended_input_dim(levels, (int)fw);
+    w.height = Spec::recommended_input_dim(levels, (int)fh);
+    w.left = (int)(cx - w.width / 2);
+    w.top = (int)(cy - w.height / 2);
+    return w;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// set_weights (annonet_train.h:20-83).  Per-crop histogram -> w_l = (avg/count_l)^class_weight, renormalised so that
+// the weights sum to total * (nr*nc/total)^image_weight.  "avg" divides by the histogram's *allocated* length
+// (index*2+16 growth, annonet_train.h:29-34); it cancels in the normalisation but is kept for fidelity.
+// ---------------------------------------------------------------------------------------------------
+void set_weights(const uint16_t* labels, int nr, int nc, double class_weight, double image_weight, anh_wlabel* out) {
+    ANH_REQUIRE(nr >= 0 && nc >= 0, "negative label image size");
+    const size_t n = (size_t)nr * nc;
+    std::vector<size_t> histogram;
+    for (size_t i = 0; i < n; ++i) {
+        const uint16_t l = labels[i];
+        if (l == ANH_LABEL_IGNORE) continue;
+        if (l >= histogram.size()) histogram.resize((size_t)l * 2 + 16);
+        ++histogram[l];
+    }
+    size_t labelled = 0;
+    for (size_t c : histogram) labelled += c;
+    std::vector<double> weight_of(histogram.size(), 0.0);
+    if (labelled > 0) {
+        const double mean_count = labelled / (double)histogram.size();
+        double raw_total = 0.0;
+        for (size_t l = 0; l < histogram.size(); ++l) {
+            if (histogram[l] == 0) continue;
+            weight_of[l] = std::pow(mean_count / histogram[l], class_weight);
+            raw_total += histogram[l] * weight_of[l];
+        }
+        const double wanted_total = labelled * std::pow(nr * nc / (double)labelled, image_weight);
+        for (double& w : weight_of) w *= wanted_total / raw_total;
+    }
+    for (size_t i = 0; i < n; ++i) {
+        out[i].label = labels[i];
+        out[i].weight = labels[i] == ANH_LABEL_IGNORE ? 0.0f : (float)weight_of[labels[i]];
+    }
+}
+
+// random_rect_containing_point (annonet_train.h:85-105)
+anh_rect random_rect_containing_point(uint32_t draw_x, uint32_t draw_y, long px, long py, long w, long h) {
+    ANH_REQUIRE(w >= 1 && h >= 1, "rect size must be positive");
+    const long cx_lo = px - (w - 1) / 2, cx_hi = px + w / 2;
+    const long cy_lo = py - (h - 1) / 2, cy_hi = py + h / 2;
+    const long cx = cx_lo + (long)(draw_x % (uint64_t)(cx_hi - cx_lo + 1));
+    const long cy = cy_lo + (long)(draw_y % (uint64_t)(cy_hi - cy_lo + 1));
+    anh_rect r;
+    r.left = cx - w / 2; r.top = cy - h / 2;  // dlib::centered_rect
+    r.right = r.left + w - 1; r.bottom = r.top + h - 1;
+    ANH_REQUIRE(px >= r.left && px <= r.right && py >= r.top && py <= r.bottom, "rect does not contain the point");
+    return r;
+}
+
+// outpaint (annonet.h:74-120): every pixel outside `inside` takes the value of the nearest pixel of `inside`.
+void outpaint(uint8_t* image, int nr, int nc, int channels, anh_rect in) {
+    in.left = std::max(in.left, 0L); in.top = std::max(in.top, 0L);
+    in.right = std::min<long>(in.right, nc - 1); in.bottom = std::min<long>(in.bottom, nr - 1);
+    if (in.left > in.right || in.top > in.bottom) return;
+    for (long r = 0; r < nr; ++r) {
+        const long sr = std::min(std::max(r, in.top), in.bottom);
+        for (long c = 0; c < nc; ++c) {
+            const long sc = std::min(std::max(c, in.left), in.right);
+            if (sr == r && sc == c) continue;
+            std::memmove(image + ((size_t)r * nc + c) * channels, image + ((size_t)sr * nc + sc) * channels, channels);
+        }
+    }
+}
+
+// dlib count_steps_without_decrease [UPSTREAM-UNVERIFIED]: walk the history from newest to oldest, keep a least-squares
+// line through what has been seen, and remember the longest suffix for which "the loss is going down" is not
+// more likely than probability_of_decrease.
+int64_t count_steps_without_decrease(const double* values, int64_t n, double probability_of_decrease) {
+    double cnt = 0, sx = 0, sy = 0, sxx = 0, sxy = 0, syy = 0;
+    int64_t longest = 0;
+    for (int64_t back = 1; back <= n; ++back) {
+        const double x = cnt, y = values[n - back];
+        cnt += 1; sx += x; sy += y; sxx += x * x; sxy += x * y; syy += y * y;
+        if (cnt <= 2) continue;
+        const double vxx = sxx - sx * sx / cnt, vxy = sxy - sx * sy / cnt, vyy = syy - sy * sy / cnt;
+        const double slope = vxy / vxx;
+        const double resid = std::max(0.0, (vyy - slope * vxy) / (cnt - 2));
+        const double stderr_slope = std::sqrt(resid / vxx);
+        // x runs backwards in time, so a positive slope here is a decreasing loss
+        const double p_decreasing = stderr_slope == 0 ? (slope > 0 ? 1.0 : 0.0)
+                                                      : 1.0 - 0.5 * std::erfc(slope / stderr_slope / std::sqrt(2.0));
+        if (p_decreasing < probability_of_decrease) longest = back;
+    }
+    return longest;
+}
+
+// dnn_trainer's schedule [UPSTREAM-UNVERIFIED]: every `threshold/200`-ish steps (budget of 200 per step) test the
+// history; if the loss has not decreased over `threshold` steps, multiply the rate by `shrink` and forget the
+// oldest `dump_amount` values.
+void LrSchedule::record(double loss) {
+    if (shrink != 1.0 && check_budget > threshold) {
+        check_budget = 0;
+        std::vector<double> h(history.begin(), history.end());
+        steps_without_progress = (unsigned long)count_steps_without_decrease(h.data(), (int64_t)h.size(), 0.51);
+        if (steps_without_progress >= threshold) {
+            // second look without the largest 10% of the values (robust variant)
+            std::vector<double> sorted = h;
+            std::sort(sorted.begin(), sorted.end());
+            const double cap = sorted.empty() ? 0 : sorted[(size_t)((sorted.size() - 1) * 0.9)];
+            std::vector<double> trimmed;
+            for (double v : h) if (v <= cap) trimmed.push_back(v);
+            steps_without_progress = (unsigned long)count_steps_without_decrease(trimmed.data(), (int64_t)trimmed.size(), 0.51);
+            if (steps_without_progress >= threshold * 9 / 10) {
+                lr *= shrink;
+                for (unsigned long i = 0; i < dump_amount && !history.empty(); ++i) history.pop_front();
+                steps_without_progress = 0;
+            }
+        }
+    }
+    check_budget += 200;
+    history.push_back(loss);
+    while (history.size() > (size_t)threshold * 2 + 1) history.pop_front();
+}
+
+}  // namespace anh

@@ -1,0 +1,146 @@
+// kernels.h — launch interface of the HIP kernels (gfx950).  Layouts: activations NHWC (channels innermost),
+// storage type T = float (ANH_FP32) or __bf16 (ANH_BF16); all arithmetic accumulates in fp32.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace anh {
+
+enum DType { DT_F32 = 0, DT_BF16 = 1 };
+
+// How a kernel reads its input activations.  Post-activation tensors are never materialised: a consumer
+// re-applies the producer's folded batch-norm (scale, shift) and the relu while loading the raw conv output.
+enum SrcKind {
+    SRC_RAW = 0,    // value = a[i]
+    SRC_ACT = 1,    // value = relu(a[i]*scale_a[c] + shift_a[c])
+    SRC_ACT2 = 2,   // value = relu(a[i]*scale_a[c]+shift_a[c]) + relu(b[i]*scale_b[c]+shift_b[c])   (skip add)
+    SRC_IMAGE = 3   // value = u8 image / 256, read through a clamp-to-edge window (annonet_infer.cpp:68-75)
+};
+
+struct Src {
+    int kind = SRC_RAW;
+    int dtype = DT_F32;
+    const void* a = nullptr; const float* a_scale = nullptr; const float* a_shift = nullptr;
+    const void* b = nullptr; const float* b_scale = nullptr; const float* b_shift = nullptr;
+    // SRC_IMAGE: sample n lives at img + n*img_sample_stride; the net input window starts at (img_left, img_top)
+    const uint8_t* img = nullptr;
+    int img_h = 0, img_w = 0, img_left = 0, img_top = 0;
+    int64_t img_sample_stride = 0;
+};
+
+// out[n,oy,ox,co] = sum_{ky,kx,cr} src(n, iy, ix, cr) * w[(ky*k+kx)][cr][co]   (+ bias[co])
+//   gather = 0 ("con"):        iy = oy*stride + ky - pad
+//   gather = 1 ("transposed"): ty = oy + pad - ky, valid iff ty % stride == 0, iy = ty/stride
+// Forward con / backward-data cont use gather 0; forward cont / backward-data con use gather 1.
+struct ConvArgs {
+    Src src;
+    int n = 0, h_in = 0, w_in = 0, c_red = 0;
+    int h_out = 0, w_out = 0, c_out = 0;
+    int k = 0, stride = 1, pad = 0, gather = 0;
+    const float* w_f32 = nullptr;     // [tap][c_red][c_out] fp32
+    const void* w_bf16 = nullptr;     // [tap][c_out][c_red] bf16 (MFMA B operand, k contiguous)
+    const float* bias = nullptr;
+    void* out = nullptr; int out_dtype = DT_F32; int out_accumulate = 0;
+    void* out2 = nullptr; int out2_accumulate = 0;  // optional second destination (skip-add gradient)
+    int out_nchw = 0;                               // fp32 NCHW destination (boundary layout)
+    double* stat_partials = nullptr;                // fused bn statistics (MFMA path), else nullptr
+};
+
+// dw[tap][ci][co] = sum_pixels src(n, iy, ix, ci) * dy[n,oy,ox,co]; same gather convention as ConvArgs.
+struct WgradArgs {
+    Src src;
+    const void* dy = nullptr; int dy_dtype = DT_F32;
+    int n = 0, h_in = 0, w_in = 0, c_in = 0;
+    int h_out = 0, w_out = 0, c_out = 0;
+    int k = 0, stride = 1, pad = 0, gather = 0;
+    float* dw = nullptr;        // [tap][c_in][c_out] fp32
+    float* partials = nullptr;  // scratch, >= splits * k*k*c_in*c_out floats
+    int64_t partials_capacity = 0;
+};
+
+void launch_conv_generic(const ConvArgs& a, hipStream_t s);
+void launch_wgrad_generic(const WgradArgs& a, hipStream_t s);
+int64_t wgrad_generic_scratch_floats(const WgradArgs& a);
+
+// batch-norm forward statistics over y[P][C]: partial sums -> mean/var -> folded (scale, shift); optional running update
+struct BnFwdArgs {
+    const void* y = nullptr; int dtype = DT_F32;
+    int64_t pixels = 0; int c = 0;
+    const float* gamma = nullptr; const float* beta = nullptr;
+    float* mean = nullptr; float* invstd = nullptr; float* scale = nullptr; float* shift = nullptr;
+    double* var = nullptr;            // biased batch variance (kept for the running update)
+    double* partials = nullptr;       // >= bn_partial_blocks(pixels) * 2 * c doubles
+    float eps = 1e-4f;
+};
+int bn_partial_blocks(int64_t pixels);
+void launch_bn_forward_stats(const BnFwdArgs& a, hipStream_t s);
+
+// running_mean/var update (dlib bn_: averaging factor 1/(updates+1) up to the window; unbiased variance)
+void launch_bn_running_update(const float* mean, const double* var, float* running_mean, float* running_var,
+                              int c, double averaging_factor, double unbias, hipStream_t s);
+
+// batch-norm + relu backward.  da: gradient w.r.t. the post-activation output; y: raw conv output.
+//   reduce:  dgamma = sum dz*xhat, dbeta = sum dz, with dz = da * (y*scale+shift > 0)
+//   apply:   dy = gamma*invstd*(dz - dbeta/P - xhat*dgamma/P), written over da
+struct BnBwdArgs {
+    void* da = nullptr; const void* y = nullptr; int dtype = DT_F32;
+    int64_t pixels = 0; int c = 0;
+    const float* gamma = nullptr; const float* mean = nullptr; const float* invstd = nullptr;
+    const float* scale = nullptr; const float* shift = nullptr;
+    float* dgamma = nullptr; float* dbeta = nullptr;  // destinations in the gradient blob
+    double* partials = nullptr;
+    float* coef = nullptr;  // scratch 3*c floats
+};
+void launch_bn_backward(const BnBwdArgs& a, hipStream_t s);
+
+// loss_multiclass_log_per_pixel_weighted on fp32 NHWC logits [P][K]; writes dlogits in place of nothing (separate buffer),
+// the summed loss (double) and the bias gradient.
+struct LossArgs {
+    const float* logits = nullptr; const uint16_t* labels = nullptr; const float* weights = nullptr;
+    float* dlogits = nullptr;
+    int64_t pixels = 0; int k = 0;
+    double scale = 0;  // 1/(N*nr*nc)
+    double* partials = nullptr;  // >= loss_partial_blocks(pixels) * (1+k) doubles
+    double* loss_out = nullptr;  // device scalar
+    float* loss_out_f32 = nullptr;  // copy in the gradient bucket's trailing slot
+    float* dbias = nullptr;
+    int* error_flag = nullptr;   // set to 1 when a label is >= k and not the ignore label
+};
+int loss_partial_blocks(int64_t pixels);
+void launch_loss(const LossArgs& a, hipStream_t s);
+
+// SGD with momentum and weight decay over the canonical parameter blob; rewrites the compute-layout copies.
+struct ParamSegment {
+    int64_t start, count;  // canonical range
+    int kind;              // 0 filter (weight decay on), 1 bias / gamma / beta (weight decay off)
+    int type, k, cin, cout;
+};
+struct SgdArgs {
+    const ParamSegment* segments = nullptr; int n_segments = 0;  // device table
+    int64_t n_params = 0;
+    float* master = nullptr; float* momentum = nullptr;
+    const float* grad_tm = nullptr;   // filters tap-major [t][ci][co]; other segments canonical
+    float* w_tm_f32 = nullptr; float* w_km_f32 = nullptr;   // [t][ci][co] / [t][co][ci]
+    void* w_tm_bf16 = nullptr; void* w_km_bf16 = nullptr;
+    double lr = 0, weight_decay = 0, momentum_coef = 0, grad_scale = 1;
+    int apply = 1;  // 0: only refresh the compute-layout copies from master (after set_params)
+};
+void launch_sgd(const SgdArgs& a, hipStream_t s);
+// canonical <-> tap-major conversion of a whole blob (get_grads, tests)
+void launch_tm_to_canonical(const ParamSegment* segments, int n_segments, int64_t n_params, const float* tm, float* canonical, hipStream_t s);
+
+// inference glue (annonet_infer.cpp:116-214)
+struct BlendArgs {
+    const float* logits_nchw = nullptr;  // [K][th][tw] of one tile
+    float* blended = nullptr;            // [K][H][W]
+    int k = 0, tile_h = 0, tile_w = 0, tile_left = 0, tile_top = 0;
+    int img_h = 0, img_w = 0;
+    long full[4] = {0, 0, 0, 0}, unique[4] = {0, 0, 0, 0};  // l,t,r,b
+};
+void launch_blend(const BlendArgs& a, hipStream_t s);
+void launch_argmax(const float* blended, int k, int64_t pixels, const double* gains_or_null, uint16_t* labels, hipStream_t s);
+
+void launch_fill_zero(void* p, size_t bytes, hipStream_t s);
+
+}  // namespace anh

@@ -1,0 +1,737 @@
+// kernels_generic.hip — shape-agnostic HIP kernels for gfx950.
+//
+// These carry (a) the fp32 parity mode, where every convolution output is ONE k-ordered fmaf chain
+// (taps row-major, reduction channels innermost) so that inference is bit-exact against the oracle, and
+// (b) every layer shape the MFMA kernels (kernels_mfma.hip) do not cover: the 3-channel stem, the K-channel
+// head, widths that are not multiples of 32.  Wavefronts are 64 lanes: one lane = one output pixel, one
+// wave = 64 consecutive pixels x 8 output channels, so weight addresses are wave-uniform (scalar loads) and
+// activation loads are 16/32-byte vectors per lane.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace anh {
+namespace {
+
+typedef __bf16 bf16;
+
+template <typename T> __device__ __forceinline__ float to_f(T v);
+template <> __device__ __forceinline__ float to_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f<bf16>(bf16 v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f(float v);
+template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16 from_f<bf16>(float v) { return (bf16)v; }
+
+__device__ __forceinline__ float relu_affine(float y, float s, float t) {
+    const float z = fmaf(y, s, t);
+    return z > 0.f ? z : 0.f;
+}
+
+template <typename T> __device__ __forceinline__ void load8(const T* p, float v[8]);
+template <> __device__ __forceinline__ void load8<float>(const float* p, float v[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+template <> __device__ __forceinline__ void load8<bf16>(const bf16* p, float v[8]) {
+    const uint4 r = *reinterpret_cast<const uint4*>(p);
+    const unsigned w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[2 * i] = __uint_as_float(w[i] << 16);
+        v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+}
+template <typename T> __device__ __forceinline__ void store8(T* p, const float v[8]);
+template <> __device__ __forceinline__ void store8<float>(float* p, const float v[8]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+template <> __device__ __forceinline__ void store8<bf16>(bf16* p, const float v[8]) {
+    bf16 t[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = (bf16)v[i];
+    *reinterpret_cast<uint4*>(p) = *reinterpret_cast<const uint4*>(t);
+}
+
+// ---- reading one input value / eight consecutive channels through the producer's bn+relu ----
+template <typename T, int KIND>
+__device__ __forceinline__ float fetch1(const Src& s, int n, int y, int x, int h, int w, int c_total, int c) {
+    if (KIND == SRC_IMAGE) {
+        const int sy = min(max(s.img_top + y, 0), s.img_h - 1);
+        const int sx = min(max(s.img_left + x, 0), s.img_w - 1);
+        const uint8_t v = s.img[(size_t)n * s.img_sample_stride + ((size_t)sy * s.img_w + sx) * c_total + c];
+        return (float)v * (1.0f / 256.0f);  // dlib input<>::to_tensor
+    }
+    const size_t i = (((size_t)n * h + y) * w + x) * c_total + c;
+    const float a = to_f<T>(reinterpret_cast<const T*>(s.a)[i]);
+    if (KIND == SRC_RAW) return a;
+    float v = relu_affine(a, s.a_scale[c], s.a_shift[c]);
+    if (KIND == SRC_ACT2) v += relu_affine(to_f<T>(reinterpret_cast<const T*>(s.b)[i]), s.b_scale[c], s.b_shift[c]);
+    return v;
+}
+
+template <typename T, int KIND>
+__device__ __forceinline__ void fetch8(const Src& s, size_t pixel, int c_total, int c8, float v[8]) {
+    const size_t i = pixel * c_total + c8;
+    load8<T>(reinterpret_cast<const T*>(s.a) + i, v);
+    if (KIND == SRC_RAW) return;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = relu_affine(v[j], s.a_scale[c8 + j], s.a_shift[c8 + j]);
+    if (KIND == SRC_ACT2) {
+        float u[8];
+        load8<T>(reinterpret_cast<const T*>(s.b) + i, u);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += relu_affine(u[j], s.b_scale[c8 + j], s.b_shift[c8 + j]);
+    }
+}
+
+__device__ __forceinline__ bool tap_source(int o, int kk, int stride, int pad, int gather, int limit, int& src) {
+    if (gather == 0) { src = o * stride + kk - pad; }
+    else {
+        const int t = o + pad - kk;
+        if (t < 0 || (t % stride) != 0) { src = 0; return false; }
+        src = t / stride;
+    }
+    return src >= 0 && src < limit;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// conv_generic: block = 64 pixels x (blockDim.y groups of 8 output channels)
+// ---------------------------------------------------------------------------------------------------
+template <typename TIN, typename TOUT, int KIND>
+__global__ __launch_bounds__(256) void conv_generic_kernel(ConvArgs a) {
+    const int64_t total = (int64_t)a.n * a.h_out * a.w_out;
+    const int64_t p_raw = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const int co0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.y * blockDim.y + threadIdx.y) * 8);
+    if (co0 >= a.c_out) return;
+    const bool live = p_raw < total;
+    const int64_t p = live ? p_raw : total - 1;
+    const int plane = a.h_out * a.w_out;
+    const int n = (int)(p / plane);
+    const int rem = (int)(p - (int64_t)n * plane);
+    const int oy = rem / a.w_out, ox = rem - oy * a.w_out;
+
+    float acc[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) acc[o] = 0.f;
+    const bool vec_in = KIND != SRC_IMAGE && (a.c_red % 8) == 0;
+    const bool vec_w = (a.c_out % 8) == 0;
+
+    for (int ky = 0; ky < a.k; ++ky) {
+        int iy;
+        const bool vy = tap_source(oy, ky, a.stride, a.pad, a.gather, a.h_in, iy);
+        for (int kx = 0; kx < a.k; ++kx) {
+            int ix;
+            const bool valid = tap_source(ox, kx, a.stride, a.pad, a.gather, a.w_in, ix) && vy;
+            if (!__any(valid)) continue;  // adding fmaf(0,w,acc) is the identity, so skipping is exact
+            const float* wt = a.w_f32 + (size_t)(ky * a.k + kx) * a.c_red * a.c_out + co0;
+            const size_t pixel = valid ? ((size_t)n * a.h_in + iy) * a.w_in + ix : 0;
+            if (vec_in) {
+                for (int c8 = 0; c8 < a.c_red; c8 += 8) {
+                    float v[8];
+                    if (valid) fetch8<TIN, KIND>(a.src, pixel, a.c_red, c8, v);
+                    else {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] = 0.f;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float* wr = wt + (size_t)(c8 + j) * a.c_out;
+                        if (vec_w) {
+                            const float4 w0 = *reinterpret_cast<const float4*>(wr), w1 = *reinterpret_cast<const float4*>(wr + 4);
+                            acc[0] = fmaf(v[j], w0.x, acc[0]); acc[1] = fmaf(v[j], w0.y, acc[1]);
+                            acc[2] = fmaf(v[j], w0.z, acc[2]); acc[3] = fmaf(v[j], w0.w, acc[3]);
+                            acc[4] = fmaf(v[j], w1.x, acc[4]); acc[5] = fmaf(v[j], w1.y, acc[5]);
+                            acc[6] = fmaf(v[j], w1.z, acc[6]); acc[7] = fmaf(v[j], w1.w, acc[7]);
+                        } else {
+#pragma unroll
+                            for (int o = 0; o < 8; ++o)
+                                if (co0 + o < a.c_out) acc[o] = fmaf(v[j], wr[o], acc[o]);
+                        }
+                    }
+                }
+            } else {
+                for (int c = 0; c < a.c_red; ++c) {
+                    const float v = valid ? fetch1<TIN, KIND>(a.src, n, iy, ix, a.h_in, a.w_in, a.c_red, c) : 0.f;
+                    const float* wr = wt + (size_t)c * a.c_out;
+                    if (vec_w) {
+                        const float4 w0 = *reinterpret_cast<const float4*>(wr), w1 = *reinterpret_cast<const float4*>(wr + 4);
+                        acc[0] = fmaf(v, w0.x, acc[0]); acc[1] = fmaf(v, w0.y, acc[1]);
+                        acc[2] = fmaf(v, w0.z, acc[2]); acc[3] = fmaf(v, w0.w, acc[3]);
+                        acc[4] = fmaf(v, w1.x, acc[4]); acc[5] = fmaf(v, w1.y, acc[5]);
+                        acc[6] = fmaf(v, w1.z, acc[6]); acc[7] = fmaf(v, w1.w, acc[7]);
+                    } else {
+#pragma unroll
+                        for (int o = 0; o < 8; ++o)
+                            if (co0 + o < a.c_out) acc[o] = fmaf(v, wr[o], acc[o]);
+                    }
+                }
+            }
+        }
+    }
+    if (!live) return;
+    if (a.bias) {
+#pragma unroll
+        for (int o = 0; o < 8; ++o)
+            if (co0 + o < a.c_out) acc[o] = acc[o] + a.bias[co0 + o];
+    }
+    if (a.out_nchw) {
+        float* out = reinterpret_cast<float*>(a.out);
+#pragma unroll
+        for (int o = 0; o < 8; ++o)
+            if (co0 + o < a.c_out) out[(((size_t)n * a.c_out + co0 + o) * a.h_out + oy) * a.w_out + ox] = acc[o];
+        return;
+    }
+    const size_t base = (size_t)p * a.c_out + co0;
+#pragma unroll
+    for (int dst = 0; dst < 2; ++dst) {
+        TOUT* out = reinterpret_cast<TOUT*>(dst == 0 ? a.out : a.out2);
+        const int accumulate = dst == 0 ? a.out_accumulate : a.out2_accumulate;
+        if (!out) continue;
+        if (vec_w) {
+            float r[8];
+            if (accumulate) {
+                load8<TOUT>(out + base, r);
+#pragma unroll
+                for (int o = 0; o < 8; ++o) r[o] += acc[o];
+            } else {
+#pragma unroll
+                for (int o = 0; o < 8; ++o) r[o] = acc[o];
+            }
+            store8<TOUT>(out + base, r);
+        } else {
+#pragma unroll
+            for (int o = 0; o < 8; ++o)
+                if (co0 + o < a.c_out) {
+                    const float r = accumulate ? to_f<TOUT>(out[base + o]) + acc[o] : acc[o];
+                    out[base + o] = from_f<TOUT>(r);
+                }
+        }
+    }
+}
+
+template <typename TIN, typename TOUT>
+void conv_generic_dispatch(const ConvArgs& a, dim3 grid, dim3 block, hipStream_t s) {
+    switch (a.src.kind) {
+        case SRC_RAW: hipLaunchKernelGGL((conv_generic_kernel<TIN, TOUT, SRC_RAW>), grid, block, 0, s, a); break;
+        case SRC_ACT: hipLaunchKernelGGL((conv_generic_kernel<TIN, TOUT, SRC_ACT>), grid, block, 0, s, a); break;
+        case SRC_ACT2: hipLaunchKernelGGL((conv_generic_kernel<TIN, TOUT, SRC_ACT2>), grid, block, 0, s, a); break;
+        default: hipLaunchKernelGGL((conv_generic_kernel<TIN, TOUT, SRC_IMAGE>), grid, block, 0, s, a); break;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// wgrad_generic: grid = (pixel split, tap, 32x32 (ci,co) tile); 256 threads, 2x2 outputs each; pixel chunks of 32
+// staged in LDS; per-split partials, reduced in a fixed order (deterministic).
+// ---------------------------------------------------------------------------------------------------
+template <typename TIN, typename TDY, int KIND>
+__global__ __launch_bounds__(256) void wgrad_generic_kernel(WgradArgs a, int64_t pix_per_split, int n_co_tiles) {
+    __shared__ float xs[32][33];
+    __shared__ float ds[32][33];
+    const int tid = threadIdx.x;
+    const int tap = blockIdx.y, ky = tap / a.k, kx = tap - ky * a.k;
+    const int ci0 = (blockIdx.z / n_co_tiles) * 32, co0 = (blockIdx.z % n_co_tiles) * 32;
+    const int64_t total = (int64_t)a.n * a.h_out * a.w_out;
+    const int64_t p_begin = (int64_t)blockIdx.x * pix_per_split;
+    const int64_t p_end = min(total, p_begin + pix_per_split);
+    const int plane = a.h_out * a.w_out;
+    const int tci = (tid >> 4) * 2, tco = (tid & 15) * 2;
+    float acc00 = 0.f, acc01 = 0.f, acc10 = 0.f, acc11 = 0.f;
+    const TDY* dy = reinterpret_cast<const TDY*>(a.dy);
+
+    for (int64_t p0 = p_begin; p0 < p_end; p0 += 32) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int e = tid + 256 * r;
+            const int px = e >> 5, ch = e & 31;
+            const int64_t p = p0 + px;
+            float xv = 0.f, dv = 0.f;
+            if (p < p_end) {
+                const int n = (int)(p / plane);
+                const int rem = (int)(p - (int64_t)n * plane);
+                const int oy = rem / a.w_out, ox = rem - oy * a.w_out;
+                int iy, ix;
+                const bool vy = tap_source(oy, ky, a.stride, a.pad, a.gather, a.h_in, iy);
+                const bool valid = tap_source(ox, kx, a.stride, a.pad, a.gather, a.w_in, ix) && vy;
+                if (valid && ci0 + ch < a.c_in) xv = fetch1<TIN, KIND>(a.src, n, iy, ix, a.h_in, a.w_in, a.c_in, ci0 + ch);
+                if (co0 + ch < a.c_out) dv = to_f<TDY>(dy[(size_t)p * a.c_out + co0 + ch]);
+            }
+            xs[px][ch] = xv;
+            ds[px][ch] = dv;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int px = 0; px < 32; ++px) {
+            const float x0 = xs[px][tci], x1 = xs[px][tci + 1];
+            const float d0 = ds[px][tco], d1 = ds[px][tco + 1];
+            acc00 = fmaf(x0, d0, acc00); acc01 = fmaf(x0, d1, acc01);
+            acc10 = fmaf(x1, d0, acc10); acc11 = fmaf(x1, d1, acc11);
+        }
+        __syncthreads();
+    }
+    const size_t nw = (size_t)a.k * a.k * a.c_in * a.c_out;
+    float* out = a.partials + (size_t)blockIdx.x * nw + (size_t)tap * a.c_in * a.c_out;
+    const int ci = ci0 + tci, co = co0 + tco;
+    if (ci < a.c_in && co < a.c_out) out[(size_t)ci * a.c_out + co] = acc00;
+    if (ci < a.c_in && co + 1 < a.c_out) out[(size_t)ci * a.c_out + co + 1] = acc01;
+    if (ci + 1 < a.c_in && co < a.c_out) out[(size_t)(ci + 1) * a.c_out + co] = acc10;
+    if (ci + 1 < a.c_in && co + 1 < a.c_out) out[(size_t)(ci + 1) * a.c_out + co + 1] = acc11;
+}
+
+__global__ void reduce_partials_kernel(const float* partials, int splits, int64_t nw, float* out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nw) return;
+    double s = 0.0;
+    for (int k = 0; k < splits; ++k) s += (double)partials[(size_t)k * nw + i];
+    out[i] = (float)s;
+}
+
+void wgrad_plan(const WgradArgs& a, int& splits, int64_t& pix_per_split, int& n_ci_tiles, int& n_co_tiles) {
+    const int64_t total = (int64_t)a.n * a.h_out * a.w_out;
+    n_ci_tiles = (a.c_in + 31) / 32;
+    n_co_tiles = (a.c_out + 31) / 32;
+    const int64_t per_split_blocks = (int64_t)a.k * a.k * n_ci_tiles * n_co_tiles;
+    int64_t want = (2048 + per_split_blocks - 1) / per_split_blocks;
+    const int64_t max_by_pixels = std::max<int64_t>(1, total / 512);
+    want = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(want, 512), max_by_pixels));
+    pix_per_split = ((total + want - 1) / want + 31) / 32 * 32;
+    splits = (int)((total + pix_per_split - 1) / pix_per_split);
+}
+
+template <typename TIN, typename TDY>
+void wgrad_generic_dispatch(const WgradArgs& a, dim3 grid, int64_t pps, int nco, hipStream_t s) {
+    switch (a.src.kind) {
+        case SRC_RAW: hipLaunchKernelGGL((wgrad_generic_kernel<TIN, TDY, SRC_RAW>), grid, dim3(256), 0, s, a, pps, nco); break;
+        case SRC_ACT: hipLaunchKernelGGL((wgrad_generic_kernel<TIN, TDY, SRC_ACT>), grid, dim3(256), 0, s, a, pps, nco); break;
+        case SRC_ACT2: hipLaunchKernelGGL((wgrad_generic_kernel<TIN, TDY, SRC_ACT2>), grid, dim3(256), 0, s, a, pps, nco); break;
+        default: hipLaunchKernelGGL((wgrad_generic_kernel<TIN, TDY, SRC_IMAGE>), grid, dim3(256), 0, s, a, pps, nco); break;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// batch norm
+// ---------------------------------------------------------------------------------------------------
+constexpr int kBnPixelsPerBlock = 1024;
+
+// block (cx, 256/cx): thread (c, r) walks pixels r, r+rows, ... of this block's slab for channels c, c+cx, ...
+template <typename T>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const T* y, int64_t pixels, int c, double* partials) {
+    extern __shared__ float sh[];  // [rows][2*c]
+    const int cx = blockDim.x, rows = blockDim.y;
+    const int64_t p0 = (int64_t)blockIdx.x * kBnPixelsPerBlock;
+    const int64_t p1 = min(pixels, p0 + kBnPixelsPerBlock);
+    for (int ch = threadIdx.x; ch < c; ch += cx) {
+        float s = 0.f, q = 0.f;
+        for (int64_t p = p0 + threadIdx.y; p < p1; p += rows) {
+            const float v = to_f<T>(y[(size_t)p * c + ch]);
+            s += v; q = fmaf(v, v, q);
+        }
+        sh[(threadIdx.y * c + ch) * 2] = s;
+        sh[(threadIdx.y * c + ch) * 2 + 1] = q;
+    }
+    __syncthreads();
+    const int tid = threadIdx.y * cx + threadIdx.x;
+    for (int ch = tid; ch < c; ch += cx * rows) {
+        double s = 0, q = 0;
+        for (int r = 0; r < rows; ++r) { s += sh[(r * c + ch) * 2]; q += sh[(r * c + ch) * 2 + 1]; }
+        partials[((size_t)blockIdx.x * c + ch) * 2] = s;
+        partials[((size_t)blockIdx.x * c + ch) * 2 + 1] = q;
+    }
+}
+
+__global__ void bn_finalize_kernel(const double* partials, int blocks, int64_t pixels, int c, const float* gamma, const float* beta,
+                                   float eps, float* mean, float* invstd, float* scale, float* shift, double* var_out) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    double s = 0, q = 0;
+    for (int b = 0; b < blocks; ++b) { s += partials[((size_t)b * c + ch) * 2]; q += partials[((size_t)b * c + ch) * 2 + 1]; }
+    const double m = s / (double)pixels;
+    double var = q / (double)pixels - m * m;
+    if (var < 0) var = 0;
+    const float mf = (float)m;
+    const float is = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = gamma[ch] * is;
+    mean[ch] = mf; invstd[ch] = is; scale[ch] = sc; shift[ch] = fmaf(-mf, sc, beta[ch]);
+    var_out[ch] = var;
+}
+
+__global__ void bn_running_kernel(const float* mean, const double* var, float* rmean, float* rvar, int c, double af, double unbias) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    rmean[ch] = (float)((1.0 - af) * (double)rmean[ch] + af * (double)mean[ch]);
+    rvar[ch] = (float)((1.0 - af) * (double)rvar[ch] + af * unbias * var[ch]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* da, const T* y, int64_t pixels, int c, const float* mean, const float* invstd,
+                                                            const float* scale, const float* shift, double* partials) {
+    extern __shared__ float sh[];
+    const int cx = blockDim.x, rows = blockDim.y;
+    const int64_t p0 = (int64_t)blockIdx.x * kBnPixelsPerBlock;
+    const int64_t p1 = min(pixels, p0 + kBnPixelsPerBlock);
+    for (int ch = threadIdx.x; ch < c; ch += cx) {
+        const float m = mean[ch], is = invstd[ch], sc = scale[ch], sf = shift[ch];
+        float sg = 0.f, sb = 0.f;
+        for (int64_t p = p0 + threadIdx.y; p < p1; p += rows) {
+            const size_t i = (size_t)p * c + ch;
+            const float yv = to_f<T>(y[i]);
+            const float dz = fmaf(yv, sc, sf) > 0.f ? to_f<T>(da[i]) : 0.f;
+            sg = fmaf(dz, (yv - m) * is, sg);
+            sb += dz;
+        }
+        sh[(threadIdx.y * c + ch) * 2] = sg;
+        sh[(threadIdx.y * c + ch) * 2 + 1] = sb;
+    }
+    __syncthreads();
+    const int tid = threadIdx.y * cx + threadIdx.x;
+    for (int ch = tid; ch < c; ch += cx * rows) {
+        double g = 0, b = 0;
+        for (int r = 0; r < rows; ++r) { g += sh[(r * c + ch) * 2]; b += sh[(r * c + ch) * 2 + 1]; }
+        partials[((size_t)blockIdx.x * c + ch) * 2] = g;
+        partials[((size_t)blockIdx.x * c + ch) * 2 + 1] = b;
+    }
+}
+
+__global__ void bn_bwd_finalize_kernel(const double* partials, int blocks, int64_t pixels, int c, const float* gamma, const float* invstd,
+                                       float* dgamma, float* dbeta, float* coef) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    double g = 0, b = 0;
+    for (int k = 0; k < blocks; ++k) { g += partials[((size_t)k * c + ch) * 2]; b += partials[((size_t)k * c + ch) * 2 + 1]; }
+    dgamma[ch] = (float)g; dbeta[ch] = (float)b;
+    coef[ch] = gamma[ch] * invstd[ch];
+    coef[c + ch] = (float)(b / (double)pixels);
+    coef[2 * c + ch] = (float)(g / (double)pixels);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(T* da, const T* y, int64_t total, int c, const float* mean, const float* invstd,
+                                                           const float* scale, const float* shift, const float* coef) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int ch = (int)(i % c);
+        const float yv = to_f<T>(y[i]);
+        const float dz = fmaf(yv, scale[ch], shift[ch]) > 0.f ? to_f<T>(da[i]) : 0.f;
+        const float xhat = (yv - mean[ch]) * invstd[ch];
+        da[i] = from_f<T>(coef[ch] * (dz - coef[c + ch] - xhat * coef[2 * c + ch]));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// loss_multiclass_log_per_pixel_weighted
+// ---------------------------------------------------------------------------------------------------
+constexpr int kLossPixelsPerBlock = 2048;
+
+template <int KMAX>
+__global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
+    __shared__ double red[256];
+    const int64_t p0 = (int64_t)blockIdx.x * kLossPixelsPerBlock;
+    const int64_t p1 = min(a.pixels, p0 + kLossPixelsPerBlock);
+    const int K = a.k;
+    double loss = 0.0;
+    float dbias[KMAX], z[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) dbias[k] = 0.f;
+    for (int64_t p = p0 + threadIdx.x; p < p1; p += 256) {
+        const uint16_t y = a.labels[p];
+        float* g = a.dlogits + (size_t)p * K;
+        if (y == ANH_LABEL_IGNORE || y >= K) {
+            if (y != ANH_LABEL_IGNORE && a.error_flag) *a.error_flag = 1;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) if (k < K) g[k] = 0.f;
+            continue;
+        }
+        const float* zp = a.logits + (size_t)p * K;
+        float m = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) if (k < K) { z[k] = zp[k]; m = fmaxf(m, z[k]); }
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) if (k < K) { z[k] = expf(z[k] - m); sum += z[k]; }
+        const float sw = (float)a.scale * a.weights[p];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) if (k < K) {
+            const float pk = z[k] / sum;
+            float gk;
+            if (k == y) { loss += (double)sw * (double)(-logf(fmaxf(pk, 1e-10f))); gk = sw * (pk - 1.f); }
+            else gk = sw * pk;
+            g[k] = gk;
+            dbias[k] += gk;
+        }
+    }
+    for (int slot = 0; slot <= K; ++slot) {
+        double mine = loss;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) if (slot == k + 1) mine = (double)dbias[k];
+        red[threadIdx.x] = mine;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) a.partials[(size_t)blockIdx.x * (K + 1) + slot] = red[0];
+        __syncthreads();
+    }
+}
+
+__global__ void loss_finalize_kernel(const double* partials, int blocks, int k, double* loss_out, float* loss_out_f32, float* dbias) {
+    const int slot = threadIdx.x;
+    if (slot > k) return;
+    double s = 0;
+    for (int b = 0; b < blocks; ++b) s += partials[(size_t)b * (k + 1) + slot];
+    if (slot == 0) { *loss_out = s; if (loss_out_f32) *loss_out_f32 = (float)s; }
+    else dbias[slot - 1] = (float)s;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// SGD + layout refresh
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int find_segment(const ParamSegment* seg, int n, int64_t i) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (seg[mid].start <= i) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+// canonical index within a filter segment -> (tap-major, k-major) indices
+__device__ __forceinline__ void filter_indices(const ParamSegment& sg, int64_t local, int64_t& tm, int64_t& km) {
+    const int kk = sg.k * sg.k;
+    const int t = (int)(local % kk);
+    const int64_t r = local / kk;
+    int ci, co;
+    if (sg.type == 0) { ci = (int)(r % sg.cin); co = (int)(r / sg.cin); }   // [co][ci][t]
+    else { co = (int)(r % sg.cout); ci = (int)(r / sg.cout); }              // [ci][co][t]
+    tm = ((int64_t)t * sg.cin + ci) * sg.cout + co;
+    km = ((int64_t)t * sg.cout + co) * sg.cin + ci;
+}
+
+__global__ __launch_bounds__(256) void sgd_kernel(SgdArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n_params) return;
+    const ParamSegment sg = a.segments[find_segment(a.segments, a.n_segments, i)];
+    const int64_t local = i - sg.start;
+    int64_t tm = local, km = local;
+    if (sg.kind == 0) filter_indices(sg, local, tm, km);
+    float w = a.master[i];
+    if (a.apply) {
+        const double g = (double)a.grad_tm[sg.start + tm] * a.grad_scale;
+        const double wd = sg.kind == 0 ? a.weight_decay : 0.0;
+        const float v = (float)(a.momentum_coef * (double)a.momentum[i] - wd * a.lr * (double)w - a.lr * g);
+        a.momentum[i] = v;
+        w += v;
+        a.master[i] = w;
+    }
+    a.w_tm_f32[sg.start + tm] = w;
+    a.w_km_f32[sg.start + km] = w;
+    if (a.w_tm_bf16) reinterpret_cast<bf16*>(a.w_tm_bf16)[sg.start + tm] = (bf16)w;
+    if (a.w_km_bf16) reinterpret_cast<bf16*>(a.w_km_bf16)[sg.start + km] = (bf16)w;
+}
+
+__global__ void tm_to_canonical_kernel(const ParamSegment* segments, int n_segments, int64_t n_params, const float* tm_blob, float* canon) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_params) return;
+    const ParamSegment sg = segments[find_segment(segments, n_segments, i)];
+    const int64_t local = i - sg.start;
+    int64_t tm = local, km = local;
+    if (sg.kind == 0) filter_indices(sg, local, tm, km);
+    canon[i] = tm_blob[sg.start + tm];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// inference glue
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double ramp(long long coordinate, long long first_possible, long long first_in, long long last_in, long long last_possible) {
+    // get_t (annonet_infer.cpp:102-114)
+    if (coordinate < first_in) return (double)(coordinate - first_possible) / (double)(first_in - first_possible);
+    if (coordinate > last_in) return (double)(last_possible - coordinate) / (double)(last_possible - last_in);
+    return 1.0;
+}
+
+// one thread per (x of the tile, y of the tile); loops over classes.  annonet_infer.cpp:116-164
+__global__ __launch_bounds__(256) void blend_kernel(BlendArgs a) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= a.tile_w) return;
+    const long long bx = (long long)a.tile_left + x, by = (long long)a.tile_top + y;
+    if (by < a.full[1] || by > a.full[3] || by < 0 || by >= a.img_h) return;
+    if (bx < a.full[0] || bx > a.full[2] || bx < 0 || bx >= a.img_w) return;
+    const bool inside_unique = bx >= a.unique[0] && bx <= a.unique[2] && by >= a.unique[1] && by <= a.unique[3];
+    double t = 1.0;
+    if (!inside_unique) {
+        const double th = ramp(bx, a.full[0], a.unique[0], a.unique[2], a.full[2]);
+        const double tv = ramp(by, a.full[1], a.unique[1], a.unique[3], a.full[3]);
+        t = __dmul_rn(th, tv);
+    }
+    for (int k = 0; k < a.k; ++k) {
+        const float in = a.logits_nchw[((size_t)k * a.tile_h + y) * a.tile_w + x];
+        float* out = a.blended + ((size_t)k * a.img_h + by) * a.img_w + bx;
+        if (inside_unique) *out = in;
+        else *out = (float)__dadd_rn((double)*out, __dmul_rn(t, (double)in));  // float += double * float
+    }
+}
+
+// find_label (annonet_infer.cpp:170-185): strict '>' from -inf, start label 65535, gain added in double
+__global__ __launch_bounds__(256) void argmax_kernel(const float* blended, int k, int64_t pixels, const double* gains, uint16_t* labels) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < pixels; p += stride) {
+        uint16_t label = ANH_LABEL_IGNORE;
+        float best = -INFINITY;
+        for (int c = 0; c < k; ++c) {
+            const double gain = gains ? gains[c] : 0.0;
+            const float value = (float)__dadd_rn((double)blended[(size_t)c * pixels + p], gain);
+            if (value > best) { label = (uint16_t)c; best = value; }
+        }
+        labels[p] = label;
+    }
+}
+
+}  // namespace
+
+// ===================================================================================================
+// launchers
+// ===================================================================================================
+void launch_conv_generic(const ConvArgs& a, hipStream_t s) {
+    const int64_t total = (int64_t)a.n * a.h_out * a.w_out;
+    if (total == 0) return;
+    const int groups = (a.c_out + 7) / 8;
+    const int gy = std::min(groups, 4);
+    dim3 block(64, gy), grid((unsigned)((total + 63) / 64), (groups + gy - 1) / gy);
+    const bool in_bf16 = a.src.kind != SRC_IMAGE && a.src.dtype == DT_BF16;
+    const bool out_bf16 = !a.out_nchw && a.out_dtype == DT_BF16;
+    if (in_bf16) {
+        if (out_bf16) conv_generic_dispatch<bf16, bf16>(a, grid, block, s);
+        else conv_generic_dispatch<bf16, float>(a, grid, block, s);
+    } else {
+        if (out_bf16) conv_generic_dispatch<float, bf16>(a, grid, block, s);
+        else conv_generic_dispatch<float, float>(a, grid, block, s);
+    }
+    HIP_CHECK(hipGetLastError());
+}
+
+int64_t wgrad_generic_scratch_floats(const WgradArgs& a) {
+    int splits, nci, nco; int64_t pps;
+    wgrad_plan(a, splits, pps, nci, nco);
+    return (int64_t)splits * a.k * a.k * a.c_in * a.c_out;
+}
+
+void launch_wgrad_generic(const WgradArgs& a, hipStream_t s) {
+    int splits, nci, nco; int64_t pps;
+    wgrad_plan(a, splits, pps, nci, nco);
+    const int64_t nw = (int64_t)a.k * a.k * a.c_in * a.c_out;
+    ANH_REQUIRE((int64_t)splits * nw <= a.partials_capacity, "wgrad scratch too small");
+    dim3 grid(splits, a.k * a.k, nci * nco);
+    const bool in_bf16 = a.src.kind != SRC_IMAGE && a.src.dtype == DT_BF16;
+    const bool dy_bf16 = a.dy_dtype == DT_BF16;
+    if (in_bf16) {
+        if (dy_bf16) wgrad_generic_dispatch<bf16, bf16>(a, grid, pps, nco, s);
+        else wgrad_generic_dispatch<bf16, float>(a, grid, pps, nco, s);
+    } else {
+        if (dy_bf16) wgrad_generic_dispatch<float, bf16>(a, grid, pps, nco, s);
+        else wgrad_generic_dispatch<float, float>(a, grid, pps, nco, s);
+    }
+    HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s, a.partials, splits, nw, a.dw);
+    HIP_CHECK(hipGetLastError());
+}
+
+int bn_partial_blocks(int64_t pixels) { return (int)((pixels + kBnPixelsPerBlock - 1) / kBnPixelsPerBlock); }
+
+static dim3 bn_block(int c) {
+    int cx = 1;
+    while (cx < c && cx < 64) cx <<= 1;
+    return dim3(cx, 256 / cx);
+}
+
+void launch_bn_forward_stats(const BnFwdArgs& a, hipStream_t s) {
+    const int blocks = bn_partial_blocks(a.pixels);
+    const dim3 block = bn_block(a.c);
+    const size_t shmem = (size_t)block.y * a.c * 2 * sizeof(float);
+    if (a.dtype == DT_BF16)
+        hipLaunchKernelGGL(bn_stats_kernel<bf16>, dim3(blocks), block, shmem, s, reinterpret_cast<const bf16*>(a.y), a.pixels, a.c, a.partials);
+    else
+        hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(blocks), block, shmem, s, reinterpret_cast<const float*>(a.y), a.pixels, a.c, a.partials);
+    HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((a.c + 63) / 64), dim3(64), 0, s, a.partials, blocks, a.pixels, a.c, a.gamma, a.beta, a.eps,
+                       a.mean, a.invstd, a.scale, a.shift, a.var);
+    HIP_CHECK(hipGetLastError());
+}
+
+void launch_bn_running_update(const float* mean, const double* var, float* running_mean, float* running_var, int c,
+                              double averaging_factor, double unbias, hipStream_t s) {
+    hipLaunchKernelGGL(bn_running_kernel, dim3((c + 63) / 64), dim3(64), 0, s, mean, var, running_mean, running_var, c, averaging_factor, unbias);
+    HIP_CHECK(hipGetLastError());
+}
+
+void launch_bn_backward(const BnBwdArgs& a, hipStream_t s) {
+    const int blocks = bn_partial_blocks(a.pixels);
+    const dim3 block = bn_block(a.c);
+    const size_t shmem = (size_t)block.y * a.c * 2 * sizeof(float);
+    const int64_t total = a.pixels * a.c;
+    const int apply_blocks = (int)std::min<int64_t>((total + 255) / 256, 256 * 16);
+    if (a.dtype == DT_BF16) {
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16>, dim3(blocks), block, shmem, s, reinterpret_cast<const bf16*>(a.da),
+                           reinterpret_cast<const bf16*>(a.y), a.pixels, a.c, a.mean, a.invstd, a.scale, a.shift, a.partials);
+    } else {
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(blocks), block, shmem, s, reinterpret_cast<const float*>(a.da),
+                           reinterpret_cast<const float*>(a.y), a.pixels, a.c, a.mean, a.invstd, a.scale, a.shift, a.partials);
+    }
+    HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((a.c + 63) / 64), dim3(64), 0, s, a.partials, blocks, a.pixels, a.c, a.gamma, a.invstd,
+                       a.dgamma, a.dbeta, a.coef);
+    HIP_CHECK(hipGetLastError());
+    if (a.dtype == DT_BF16) {
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16>, dim3(apply_blocks), dim3(256), 0, s, reinterpret_cast<bf16*>(a.da),
+                           reinterpret_cast<const bf16*>(a.y), total, a.c, a.mean, a.invstd, a.scale, a.shift, a.coef);
+    } else {
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(apply_blocks), dim3(256), 0, s, reinterpret_cast<float*>(a.da),
+                           reinterpret_cast<const float*>(a.y), total, a.c, a.mean, a.invstd, a.scale, a.shift, a.coef);
+    }
+    HIP_CHECK(hipGetLastError());
+}
+
+int loss_partial_blocks(int64_t pixels) { return (int)((pixels + kLossPixelsPerBlock - 1) / kLossPixelsPerBlock); }
+
+void launch_loss(const LossArgs& a, hipStream_t s) {
+    ANH_REQUIRE(a.k >= 1 && a.k <= 64, "class count out of range for the loss kernel");
+    const int blocks = loss_partial_blocks(a.pixels);
+    if (a.k <= 4) hipLaunchKernelGGL(loss_kernel<4>, dim3(blocks), dim3(256), 0, s, a);
+    else if (a.k <= 8) hipLaunchKernelGGL(loss_kernel<8>, dim3(blocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(loss_kernel<64>, dim3(blocks), dim3(256), 0, s, a);
+    HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(128), 0, s, a.partials, blocks, a.k, a.loss_out, a.loss_out_f32, a.dbias);
+    HIP_CHECK(hipGetLastError());
+}
+
+void launch_sgd(const SgdArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)((a.n_params + 255) / 256)), dim3(256), 0, s, a);
+    HIP_CHECK(hipGetLastError());
+}
+
+void launch_tm_to_canonical(const ParamSegment* segments, int n_segments, int64_t n_params, const float* tm, float* canonical, hipStream_t s) {
+    hipLaunchKernelGGL(tm_to_canonical_kernel, dim3((unsigned)((n_params + 255) / 256)), dim3(256), 0, s, segments, n_segments, n_params, tm, canonical);
+    HIP_CHECK(hipGetLastError());
+}
+
+void launch_blend(const BlendArgs& a, hipStream_t s) {
+    if (a.tile_w <= 0 || a.tile_h <= 0) return;
+    hipLaunchKernelGGL(blend_kernel, dim3((a.tile_w + 255) / 256, a.tile_h), dim3(256), 0, s, a);
+    HIP_CHECK(hipGetLastError());
+}
+
+void launch_argmax(const float* blended, int k, int64_t pixels, const double* gains_or_null, uint16_t* labels, hipStream_t s) {
+    if (pixels == 0) return;
+    const int blocks = (int)std::min<int64_t>((pixels + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(argmax_kernel, dim3(blocks), dim3(256), 0, s, blended, k, pixels, gains_or_null, labels);
+    HIP_CHECK(hipGetLastError());
+}
+
+void launch_fill_zero(void* p, size_t bytes, hipStream_t s) {
+    if (bytes) HIP_CHECK(hipMemsetAsync(p, 0, bytes, s));
+}
+
+}  // namespace anh

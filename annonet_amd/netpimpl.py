@@ -1,0 +1,364 @@
+"""Host-side mirror of the reference's NetPimpl interface (dlib-dnn-pimpl-wrapper/NetPimpl.h, known from its call
+sites: annonet_infer.cpp:49-100, annonet_train_main.cpp:376-410,558-609, annonet_infer_main.cpp:347-351) plus
+annonet_infer() (annonet_infer.h:34-42), set_weights() and tiling::get_tiles, over the C ABI.
+
+Method names follow the C++ ones so that tests read like the reference's own host code.  numpy arrays stand in for
+dlib::matrix (row-major, u8 HWC images, u16 label images).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import ANH_BF16, ANH_FP32, LABEL_IGNORE, AnnonetHipError, NetConfig, check
+
+label_to_ignore = LABEL_IGNORE
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def net_config(levels=2, in_channels=3, classes=3, width_scaler=1.0, min_filters=1, precision=ANH_BF16):
+    return NetConfig(levels, in_channels, classes, width_scaler, min_filters, precision)
+
+
+def net_layers(cfg):
+    L = _lib.lib()
+    n = L.anh_net_layer_count(C.byref(cfg))
+    if n < 0:
+        check(1)
+    out = []
+    for i in range(n):
+        d = _lib.LayerDesc()
+        check(L.anh_net_layer(C.byref(cfg), i, C.byref(d)))
+        out.append(d)
+    return out
+
+
+class tiling:
+    """tiling::parameters / tiling::get_tiles (annonet_infer.cpp:42, annonet_infer_main.cpp:423-427)."""
+
+    class parameters:
+        def __init__(self, max_tile_width=1024, max_tile_height=1024, overlap_x=0, overlap_y=0):
+            self.max_tile_width, self.max_tile_height = max_tile_width, max_tile_height
+            self.overlap_x, self.overlap_y = overlap_x, overlap_y
+
+        def _c(self):
+            return _lib.TilingParams(self.max_tile_width, self.max_tile_height, self.overlap_x, self.overlap_y)
+
+    @staticmethod
+    def get_tiles(width, height, params):
+        L = _lib.lib()
+        arr = C.POINTER(_lib.Tile)()
+        n = C.c_size_t(0)
+        p = params._c()
+        check(L.anh_get_tiles(width, height, C.byref(p), C.byref(arr), C.byref(n)))
+        try:
+            return [(arr[i].full_rect.tuple(), arr[i].unique_rect.tuple()) for i in range(n.value)]
+        finally:
+            L.anh_free(arr)
+
+
+def set_weights(unweighted_label_image, class_weight, image_weight):
+    """set_weights() (annonet_train.h:20-83) -> (labels u16, weights f32) = NetPimpl::training_label_type."""
+    lab = np.ascontiguousarray(unweighted_label_image, dtype=np.uint16)
+    out = np.zeros(lab.shape, dtype=np.dtype([("label", np.uint16), ("weight", np.float32)], align=True))
+    assert out.itemsize == C.sizeof(_lib.WLabel)
+    check(_lib.lib().anh_set_weights(_ptr(lab), lab.shape[0], lab.shape[1], class_weight, image_weight, _ptr(out)))
+    return out
+
+
+def random_rect_containing_point(draw_x, draw_y, px, py, width, height):
+    r = _lib.Rect()
+    check(_lib.lib().anh_random_rect_containing_point(draw_x, draw_y, px, py, width, height, C.byref(r)))
+    return r.tuple()
+
+
+def outpaint(img, inside):
+    img = np.ascontiguousarray(img, dtype=np.uint8).copy()
+    ch = 1 if img.ndim == 2 else img.shape[2]
+    r = _lib.Rect(*inside)
+    check(_lib.lib().anh_outpaint(_ptr(img), img.shape[0], img.shape[1], ch, C.byref(r)))
+    return img
+
+
+def count_steps_without_decrease(values, probability_of_decrease=0.51):
+    v = np.ascontiguousarray(values, dtype=np.float64)
+    return _lib.lib().anh_count_steps_without_decrease(_ptr(v), v.size, probability_of_decrease)
+
+
+class _Profiled:
+    _is_trainer = 0
+
+    def profile_enable(self, on=True):
+        check(self.L.anh_profile_enable(self.h, self._is_trainer, int(on)))
+
+    def profile_reset(self):
+        check(self.L.anh_profile_reset(self.h, self._is_trainer))
+
+    def profile(self):
+        n = self.L.anh_profile_count(self.h, self._is_trainer)
+        if n < 0:
+            check(1)
+        out = []
+        for i in range(n):
+            name = C.create_string_buffer(128)
+            ms, cnt, fl, by = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
+            check(self.L.anh_profile_entry(self.h, self._is_trainer, i, name, 128, C.byref(ms), C.byref(cnt), C.byref(fl), C.byref(by)))
+            out.append({"name": name.value.decode(), "total_ms": ms.value, "launches": cnt.value, "flops": fl.value, "bytes": by.value})
+        return out
+
+
+class RuntimeNet(_Profiled):
+    """NetPimpl::RuntimeNet."""
+
+    def __init__(self, cfg=None, _handle=None):
+        self.L = _lib.lib()
+        self.h = C.c_void_p()
+        if _handle is not None:
+            self.h = _handle
+        else:
+            cfg = cfg or net_config()
+            check(self.L.anh_runtime_create(C.byref(cfg), C.byref(self.h)))
+        c = NetConfig()
+        check(self.L.anh_runtime_config(self.h, C.byref(c)))
+        self.cfg = c
+        self.n_params = self.L.anh_net_param_count(C.byref(c))
+        self.n_running = self.L.anh_net_running_count(C.byref(c))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.anh_runtime_destroy(self.h)
+            self.h = None
+
+    @staticmethod
+    def GetRecommendedInputDimension(levels, n):
+        return _lib.lib().anh_recommended_input_dim(levels, n)
+
+    def set_params(self, params, running):
+        p = np.ascontiguousarray(params, dtype=np.float32)
+        r = np.ascontiguousarray(running, dtype=np.float32)
+        check(self.L.anh_runtime_set_params(self.h, _ptr(p), p.size, _ptr(r), r.size))
+
+    def get_params(self):
+        p = np.empty(self.n_params, np.float32)
+        r = np.empty(self.n_running, np.float32)
+        check(self.L.anh_runtime_get_params(self.h, _ptr(p), p.size, _ptr(r), r.size))
+        return p, r
+
+    def Serialize(self):
+        blob, n = C.c_void_p(), C.c_size_t()
+        check(self.L.anh_runtime_serialize(self.h, C.byref(blob), C.byref(n)))
+        try:
+            return C.string_at(blob, n.value)
+        finally:
+            self.L.anh_free(blob)
+
+    @classmethod
+    def Deserialize(cls, data, precision=ANH_BF16):
+        L = _lib.lib()
+        h = C.c_void_p()
+        buf = C.create_string_buffer(data, len(data))
+        check(L.anh_runtime_deserialize(buf, len(data), precision, C.byref(h)))
+        return cls(_handle=h)
+
+    def Forward(self, input_tile):
+        """u8 [H,W,C] (or [N,H,W,C]) -> fp32 [K,H,W] (or [N,K,H,W]); the returned array is a copy."""
+        img = np.ascontiguousarray(input_tile, dtype=np.uint8)
+        single = img.ndim != 4
+        if img.ndim == 2:
+            img = img[None, :, :, None]
+        elif img.ndim == 3:
+            img = img[None]
+        n, h, w, c = img.shape
+        if c != self.cfg.in_channels:
+            raise AnnonetHipError(1, "channel count does not match the net input")
+        out = C.POINTER(C.c_float)()
+        k, nr, nc = C.c_int(), C.c_int(), C.c_int()
+        check(self.L.anh_runtime_forward(self.h, _ptr(img), n, h, w, C.byref(out), C.byref(k), C.byref(nr), C.byref(nc)))
+        arr = np.ctypeslib.as_array(out, shape=(n, k.value, nr.value, nc.value)).copy()
+        return arr[0] if single else arr
+
+    def synchronize(self):
+        check(self.L.anh_runtime_synchronize(self.h))
+
+    def set_stream(self, stream_ptr):
+        check(self.L.anh_runtime_set_stream(self.h, stream_ptr))
+
+
+def annonet_infer(net, input_image, gains=None, detection_levels=None, tiling_parameters=None, want_blended=False):
+    """annonet_infer() (annonet_infer.h:34-42): returns the u16 label image (and the blended class planes)."""
+    img = np.ascontiguousarray(input_image, dtype=np.uint8)
+    if img.ndim == 2:
+        img = img[:, :, None]
+    H, W, c = img.shape
+    if c != net.cfg.in_channels:
+        raise AnnonetHipError(1, "channel count does not match the net input")
+    K = net.cfg.classes
+    res = np.empty((H, W), np.uint16)
+    bl = np.empty((K, H, W), np.float32) if want_blended else None
+    g = np.ascontiguousarray(gains, dtype=np.float64) if gains is not None else None
+    d = np.ascontiguousarray(detection_levels, dtype=np.float64) if detection_levels is not None else None
+    if g is not None and g.size != K or d is not None and d.size != K:
+        raise AnnonetHipError(1, "gains / detection levels need one value per class")
+    tp = tiling_parameters._c() if tiling_parameters is not None else None
+    check(net.L.anh_infer(net.h, _ptr(img), H, W, _ptr(g), _ptr(d), C.byref(tp) if tp is not None else None, _ptr(res), _ptr(bl)))
+    return (res, bl) if want_blended else res
+
+
+class TrainingNet(_Profiled):
+    """NetPimpl::TrainingNet (annonet_train_main.cpp:396-410)."""
+    _is_trainer = 1
+
+    def __init__(self, levels=2, in_channels=3, precision=ANH_BF16, seed=0):
+        self.L = _lib.lib()
+        self.h = C.c_void_p()
+        check(self.L.anh_trainer_create(C.byref(self.h)))
+        check(self.L.anh_trainer_set_levels(self.h, levels))
+        check(self.L.anh_trainer_set_input_channels(self.h, in_channels))
+        check(self.L.anh_trainer_set_precision(self.h, precision))
+        check(self.L.anh_trainer_set_seed(self.h, seed))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.anh_trainer_destroy(self.h)
+            self.h = None
+
+    @property
+    def cfg(self):
+        c = NetConfig()
+        check(self.L.anh_trainer_config(self.h, C.byref(c)))
+        return c
+
+    @property
+    def n_params(self):
+        c = self.cfg
+        return self.L.anh_net_param_count(C.byref(c))
+
+    @property
+    def n_running(self):
+        c = self.cfg
+        return self.L.anh_net_running_count(C.byref(c))
+
+    def GetRequiredInputDimension(self):
+        c = self.cfg
+        return self.L.anh_required_input_dim(C.byref(c))
+
+    def Initialize(self):
+        check(self.L.anh_trainer_initialize(self.h))
+
+    def SetNetWidth(self, scaler, min_filter_count):
+        check(self.L.anh_trainer_set_net_width(self.h, scaler, min_filter_count))
+
+    def SetClassCount(self, n):
+        check(self.L.anh_trainer_set_class_count(self.h, n))
+
+    def SetLearningRate(self, lr):
+        check(self.L.anh_trainer_set_learning_rate(self.h, lr))
+
+    def SetLearningRateShrinkFactor(self, f):
+        check(self.L.anh_trainer_set_learning_rate_shrink_factor(self.h, f))
+
+    def SetIterationsWithoutProgressThreshold(self, n):
+        check(self.L.anh_trainer_set_iterations_without_progress_threshold(self.h, n))
+
+    def SetPreviousLossValuesDumpAmount(self, n):
+        check(self.L.anh_trainer_set_previous_loss_values_dump_amount(self.h, n))
+
+    def SetAllBatchNormalizationRunningStatsWindowSizes(self, n):
+        check(self.L.anh_trainer_set_all_bn_running_stats_window_sizes(self.h, n))
+
+    def SetSynchronizationFile(self, path, seconds):
+        check(self.L.anh_trainer_set_synchronization_file(self.h, path.encode(), float(seconds)))
+
+    def BeVerbose(self):
+        check(self.L.anh_trainer_be_verbose(self.h))
+
+    def set_sgd(self, weight_decay=0.0005, momentum=0.9):
+        check(self.L.anh_trainer_set_sgd(self.h, weight_decay, momentum))
+
+    def GetLearningRate(self):
+        return self.L.anh_trainer_get_learning_rate(self.h)
+
+    def get_last_loss(self):
+        return self.L.anh_trainer_get_last_loss(self.h)
+
+    def step_count(self):
+        return self.L.anh_trainer_get_step_count(self.h)
+
+    def StartTraining(self, samples, labels):
+        """samples: list of u8 [H,W,C]; labels: list of structured (label, weight) arrays from set_weights()."""
+        n = len(samples)
+        if n == 0 or n != len(labels):
+            raise AnnonetHipError(1, "samples and labels must be non-empty and of equal length")
+        imgs = [np.ascontiguousarray(s, dtype=np.uint8) for s in samples]
+        labs = [np.ascontiguousarray(l) for l in labels]
+        h, w = imgs[0].shape[:2]
+        for im, lb in zip(imgs, labs):
+            if im.shape[:2] != (h, w) or lb.shape != (h, w) or lb.itemsize != C.sizeof(_lib.WLabel):
+                raise AnnonetHipError(1, "all samples and label images of a mini-batch must share one size")
+        ip = (C.c_void_p * n)(*[im.ctypes.data for im in imgs])
+        lp = (C.c_void_p * n)(*[lb.ctypes.data for lb in labs])
+        check(self.L.anh_trainer_step(self.h, ip, lp, n, h, w))
+
+    # ---- device-resident, data-parallel-friendly form ----
+    def forward_backward_device(self, d_images, d_labels, d_weights, n, h, w, loss_scale_n):
+        check(self.L.anh_trainer_forward_backward_device(self.h, d_images, d_labels, d_weights, n, h, w, float(loss_scale_n)))
+
+    def apply_update(self, grad_scale=1.0):
+        check(self.L.anh_trainer_apply_update(self.h, float(grad_scale)))
+
+    def grad_buffer(self):
+        p, n = C.c_void_p(), C.c_int64()
+        check(self.L.anh_trainer_grad_buffer(self.h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def get_params(self):
+        p = np.empty(self.n_params, np.float32)
+        r = np.empty(self.n_running, np.float32)
+        check(self.L.anh_trainer_get_params(self.h, _ptr(p), p.size, _ptr(r), r.size))
+        return p, r
+
+    def set_params(self, params, running):
+        p = np.ascontiguousarray(params, dtype=np.float32)
+        r = np.ascontiguousarray(running, dtype=np.float32)
+        check(self.L.anh_trainer_set_params(self.h, _ptr(p), p.size, _ptr(r), r.size))
+
+    def get_grads(self):
+        g = np.empty(self.n_params, np.float32)
+        check(self.L.anh_trainer_get_grads(self.h, _ptr(g), g.size))
+        return g
+
+    def get_momentum(self):
+        m = np.empty(self.n_params, np.float32)
+        check(self.L.anh_trainer_get_momentum(self.h, _ptr(m), m.size))
+        return m
+
+    def set_momentum(self, m):
+        m = np.ascontiguousarray(m, dtype=np.float32)
+        check(self.L.anh_trainer_set_momentum(self.h, _ptr(m), m.size))
+
+    def GetRuntimeNet(self, precision=None):
+        h = C.c_void_p()
+        check(self.L.anh_trainer_snapshot_runtime(self.h, self.cfg.precision if precision is None else precision, C.byref(h)))
+        return RuntimeNet(_handle=h)
+
+    def save_state(self, path):
+        check(self.L.anh_trainer_save_state(self.h, path.encode()))
+
+    def load_state(self, path):
+        check(self.L.anh_trainer_load_state(self.h, path.encode()))
+
+    def synchronize(self):
+        check(self.L.anh_trainer_synchronize(self.h))
+
+    def set_stream(self, stream_ptr):
+        check(self.L.anh_trainer_set_stream(self.h, stream_ptr))
+
+    def layer_tensor(self, layer, which=0):
+        dims = (C.c_int * 4)()
+        check(self.L.anh_trainer_layer_tensor(self.h, layer, which, None, 0, dims))
+        out = np.empty(tuple(dims), np.float32)
+        check(self.L.anh_trainer_layer_tensor(self.h, layer, which, _ptr(out), out.size, dims))
+        return out

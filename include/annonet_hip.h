@@ -1,0 +1,192 @@
+/*
+ * annonet_hip.h — C ABI of libannonet_hip.so, the MI355X (gfx950) implementation of annonet's hot path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++ or torch types.
+ * The C++ shims include/NetPimpl.h and include/tiling/tiling.h wrap it back into the class surface
+ * annonet's host code uses (dlib-dnn-pimpl-wrapper/NetPimpl.h and tiling/tiling.h, both absent from the
+ * reference snapshot and therefore known only from their call sites, cited per function below).
+ * All file:line citations are relative to the reference tree.
+ *
+ * Conventions
+ *   - every function returns anh_status (0 = ok) unless stated; on failure anh_last_error() (thread-local)
+ *     holds the message.  Nothing aborts: device out-of-memory is ANH_ERR_OOM, so a host that throws on
+ *     failure exits with a positive code (find_max_mini-batch_size.cmd:49-53 relies on that).
+ *   - images are u8, row-major HWC, channel order R,G,B (dlib::matrix<rgb_pixel>) or one channel.
+ *   - network outputs are fp32 NCHW (annonet_infer.cpp:26-30).
+ *   - "host" entry points take host pointers and copy; "_device" entry points take pointers that are
+ *     already resident in this GPU's HBM and enqueue on the handle's stream without synchronising.
+ *   - one thread drives a handle at a time (annonet_train_main.cpp:583-614, annonet_infer_main.cpp:446-494).
+ */
+#ifndef ANNONET_HIP_H
+#define ANNONET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    ANH_OK = 0,
+    ANH_ERR_INVALID = 1,  /* bad argument / precondition (DLIB_CASSERT analogue, annonet_infer.cpp:90-94) */
+    ANH_ERR_OOM = 2,      /* device or host allocation failed */
+    ANH_ERR_DEVICE = 3,   /* HIP runtime error, no usable GPU */
+    ANH_ERR_IO = 4,       /* malformed blob / file error */
+    ANH_ERR_INTERNAL = 5
+} anh_status;
+
+typedef enum {
+    ANH_FP32 = 0, /* parity mode: fp32 storage, fp32 k-ordered fmaf chains (bit-exact inference vs the oracle) */
+    ANH_BF16 = 1  /* throughput mode: bf16 storage + bf16 MFMA, fp32 accumulate, fp32 master weights */
+} anh_precision;
+
+#define ANH_LABEL_IGNORE 65535 /* dlib::loss_multiclass_log_per_pixel_::label_to_ignore (annonet.cpp:25) */
+
+/* Build-time knobs of the reference made run-time: DLIB_DNN_PIMPL_WRAPPER_LEVEL_COUNT (appveyor.yml:7-20),
+ * DLIB_DNN_PIMPL_WRAPPER_GRAYSCALE_INPUT (annonet_train_main.cpp:93-100), SetNetWidth (annonet_train_main.cpp:402),
+ * SetClassCount (:405). */
+typedef struct {
+    int levels;          /* 0..3 down/up-sampling levels */
+    int in_channels;     /* 3 = RGB, 1 = grayscale */
+    int classes;         /* K */
+    double width_scaler; /* --net-width-scaler */
+    int min_filters;     /* --net-width-min-filter-count */
+    int precision;       /* anh_precision */
+} anh_net_config;
+
+/* One layer of the net (the stand-in for NetStructure.h). Offsets index the canonical
+ * parameter blob: con filters [cout][cin][ky][kx], cont filters [cin][cout][ky][kx], bias[cout],
+ * gamma[cout], beta[cout]; running-stats blob: mean[cout], var[cout] per bn layer. */
+typedef struct {
+    int type; /* 0 = con, 1 = cont */
+    int k, stride, pad, cin, cout;
+    int in_a, in_b; /* producing layer; -1 = image; in_b = -2: no skip input */
+    int has_bn, has_bias;
+    int64_t w_off, b_off, g_off, beta_off, rs_off;
+} anh_layer_desc;
+
+typedef struct { uint16_t label; float weight; } anh_wlabel; /* dlib weighted_label (annonet_train.h:80) */
+typedef struct { long left, top, right, bottom; } anh_rect;   /* dlib::rectangle, inclusive */
+typedef struct { anh_rect full_rect, unique_rect; } anh_tile; /* tiling::dlib_tile (annonet_infer.cpp:46-47,118,138) */
+typedef struct { int max_tile_width, max_tile_height, overlap_x, overlap_y; } anh_tiling_params; /* tiling::parameters (annonet_infer_main.cpp:423-427) */
+
+typedef struct anh_runtime anh_runtime; /* NetPimpl::RuntimeNet */
+typedef struct anh_trainer anh_trainer; /* NetPimpl::TrainingNet */
+
+const char* anh_last_error(void);
+void anh_free(void* p); /* releases buffers this library returned (serialize, get_tiles) */
+
+/* dlib::cuda::set_device (annonet_train_main.cpp:392-394): device used by handles created afterwards on this thread */
+int anh_set_device(int device);
+int anh_device_count(void); /* number of visible GPUs; 0 when none (never fails) */
+
+/* ---- static dimension maths ---- */
+/* TrainingNet::GetRequiredInputDimension() (annonet_train_main.cpp:376,441; annonet_infer_main.cpp:421): receptive-field side */
+int anh_required_input_dim(const anh_net_config* cfg);
+/* RuntimeNet::GetRecommendedInputDimension(int) (annonet_infer.cpp:49-50; annonet_train_main.cpp:382): smallest valid side >= n */
+int anh_recommended_input_dim(int levels, int n);
+
+/* ---- net description ---- */
+int anh_net_layer_count(const anh_net_config* cfg);
+int anh_net_layer(const anh_net_config* cfg, int index, anh_layer_desc* out);
+int64_t anh_net_param_count(const anh_net_config* cfg);
+int64_t anh_net_running_count(const anh_net_config* cfg);
+
+/* ---- RuntimeNet ---- */
+int anh_runtime_create(const anh_net_config* cfg, anh_runtime** out); /* default-constructed RuntimeNet (annonet_infer_main.cpp:347) */
+void anh_runtime_destroy(anh_runtime* h);
+int anh_runtime_config(const anh_runtime* h, anh_net_config* out);
+int anh_runtime_set_params(anh_runtime* h, const float* params, int64_t n_params, const float* running, int64_t n_running);
+int anh_runtime_get_params(const anh_runtime* h, float* params, int64_t n_params, float* running, int64_t n_running);
+/* RuntimeNet::Serialize / Deserialize (annonet_train_main.cpp:558-561; annonet_infer_main.cpp:347-351): opaque blob */
+int anh_runtime_serialize(const anh_runtime* h, void** blob, size_t* size);
+int anh_runtime_deserialize(const void* blob, size_t size, int precision, anh_runtime** out);
+/* RuntimeNet::Forward(const input_type&) (annonet_infer.cpp:77): returns a library-owned fp32 NCHW tensor,
+ * valid until the next call on this handle; k = classes, nr x nc = input tile size (annonet_infer.cpp:80-100). */
+int anh_runtime_forward(anh_runtime* h, const uint8_t* image_hwc, int n, int height, int width,
+                        const float** out_nchw, int* k, int* nr, int* nc);
+int anh_runtime_forward_device(anh_runtime* h, const uint8_t* d_image_hwc, int n, int height, int width, float* d_out_nchw);
+/* annonet_infer() (annonet_infer.h:34-42, annonet_infer.cpp:32-240) in one call: tile, clamp-pad, forward, blend,
+ * argmax(+gain), optional detection-level blob filter.  gains / detection_levels: K doubles or NULL.
+ * tiling: NULL = one tile (tiling::parameters() default argument, annonet_infer.h:41).
+ * blended_out (optional, host): K planes H*W fp32 = annonet_infer_temp::blended_output (annonet_infer.h:31). */
+int anh_infer(anh_runtime* h, const uint8_t* image_hwc, int height, int width,
+              const double* gains, const double* detection_levels, const anh_tiling_params* tiling,
+              uint16_t* result_labels, float* blended_out);
+/* same with the image and the label map resident in HBM; explicit tile list (e.g. one rank's shard) when tiles != NULL */
+int anh_infer_device(anh_runtime* h, const uint8_t* d_image_hwc, int height, int width,
+                     const double* gains, const anh_tiling_params* tiling,
+                     const anh_tile* tiles, size_t n_tiles, uint16_t* d_result_labels, float* d_blended);
+int anh_runtime_set_stream(anh_runtime* h, void* hip_stream); /* NULL = the handle's own stream */
+int anh_runtime_synchronize(anh_runtime* h);
+
+/* ---- TrainingNet (annonet_train_main.cpp:396-410) ---- */
+int anh_trainer_create(anh_trainer** out);                                      /* TrainingNet ctor */
+void anh_trainer_destroy(anh_trainer* h);
+int anh_trainer_set_net_width(anh_trainer* h, double scaler, int min_filters); /* SetNetWidth */
+int anh_trainer_set_class_count(anh_trainer* h, size_t classes);               /* SetClassCount */
+int anh_trainer_set_levels(anh_trainer* h, int levels);                        /* LEVEL_COUNT */
+int anh_trainer_set_input_channels(anh_trainer* h, int channels);              /* GRAYSCALE_INPUT */
+int anh_trainer_set_precision(anh_trainer* h, int precision);
+int anh_trainer_set_seed(anh_trainer* h, uint64_t seed);
+int anh_trainer_initialize(anh_trainer* h);                                    /* Initialize(): builds the net, random init */
+int anh_trainer_set_learning_rate(anh_trainer* h, double lr);                  /* SetLearningRate */
+int anh_trainer_set_learning_rate_shrink_factor(anh_trainer* h, double f);     /* SetLearningRateShrinkFactor */
+int anh_trainer_set_iterations_without_progress_threshold(anh_trainer* h, unsigned long n);
+int anh_trainer_set_previous_loss_values_dump_amount(anh_trainer* h, unsigned long n);
+int anh_trainer_set_all_bn_running_stats_window_sizes(anh_trainer* h, unsigned long n);
+int anh_trainer_set_synchronization_file(anh_trainer* h, const char* path, double seconds); /* SetSynchronizationFile */
+int anh_trainer_be_verbose(anh_trainer* h);                                    /* BeVerbose */
+int anh_trainer_set_sgd(anh_trainer* h, double weight_decay, double momentum); /* dlib sgd defaults 0.0005 / 0.9 */
+double anh_trainer_get_learning_rate(const anh_trainer* h);                    /* GetLearningRate (annonet_train_main.cpp:570) */
+double anh_trainer_get_last_loss(anh_trainer* h);                              /* synchronises */
+unsigned long anh_trainer_get_step_count(const anh_trainer* h);
+int anh_trainer_config(const anh_trainer* h, anh_net_config* out);
+/* StartTraining(samples, labels) (annonet_train_main.cpp:609): one optimiser step; inputs are consumed (copied to
+ * HBM) before this returns (annonet_train_main.cpp:585-586). images[i]: height*width*channels u8; labels[i]: height*width. */
+int anh_trainer_step(anh_trainer* h, const uint8_t* const* images, const anh_wlabel* const* labels, int n, int height, int width);
+/* the same step on inputs resident in HBM, split so that data-parallel ranks can all-reduce the gradient
+ * bucket in between: forward_backward -> (RCCL all-reduce of grad_buffer) -> apply_update.
+ * loss_scale_n: the N of the loss scale 1/(N*nr*nc), i.e. the GLOBAL batch. */
+int anh_trainer_forward_backward_device(anh_trainer* h, const uint8_t* d_images, const uint16_t* d_labels, const float* d_weights,
+                                        int n, int height, int width, double loss_scale_n);
+int anh_trainer_apply_update(anh_trainer* h, double grad_scale);
+int anh_trainer_grad_buffer(anh_trainer* h, void** d_ptr, int64_t* count); /* flat fp32 gradients (+1 trailing slot: loss) */
+int anh_trainer_get_params(anh_trainer* h, float* params, int64_t n_params, float* running, int64_t n_running);
+int anh_trainer_set_params(anh_trainer* h, const float* params, int64_t n_params, const float* running, int64_t n_running);
+int anh_trainer_get_grads(anh_trainer* h, float* grads_canonical, int64_t n_params);
+int anh_trainer_get_momentum(anh_trainer* h, float* momentum, int64_t n_params);
+int anh_trainer_set_momentum(anh_trainer* h, const float* momentum, int64_t n_params);
+/* GetRuntimeNet() (annonet_train_main.cpp:558): independent by-value snapshot; quiesces the device first */
+int anh_trainer_snapshot_runtime(anh_trainer* h, int precision, anh_runtime** out);
+int anh_trainer_save_state(anh_trainer* h, const char* path); /* trainer synchronization file */
+int anh_trainer_load_state(anh_trainer* h, const char* path);
+int anh_trainer_set_stream(anh_trainer* h, void* hip_stream);
+int anh_trainer_synchronize(anh_trainer* h);
+/* debugging / parity taps: raw conv output (which=0) or gradient w.r.t. the layer's activation (which=1), as fp32 NHWC */
+int anh_trainer_layer_tensor(anh_trainer* h, int layer, int which, float* out, int64_t capacity, int dims4[4]);
+
+/* ---- per-kernel timing (HIP events on the handle's stream), for bench.py's roofline line ---- */
+int anh_profile_enable(void* handle, int is_trainer, int enable);
+int anh_profile_reset(void* handle, int is_trainer);
+int anh_profile_count(void* handle, int is_trainer);
+int anh_profile_entry(void* handle, int is_trainer, int index, char* name, size_t name_cap,
+                      double* total_ms, int64_t* launches, double* flops, double* bytes);
+
+/* ---- host logic ---- */
+/* tiling::get_tiles(width, height, params) (annonet_infer.cpp:42): *tiles is malloc'd, release with anh_free */
+int anh_get_tiles(int width, int height, const anh_tiling_params* params, anh_tile** tiles, size_t* count);
+/* set_weights() (annonet_train.h:20-83) */
+int anh_set_weights(const uint16_t* labels, int nr, int nc, double class_weight, double image_weight, anh_wlabel* out);
+/* random_rect_containing_point() (annonet_train.h:85-105); the two 32-bit draws of dlib::rand are passed in */
+int anh_random_rect_containing_point(uint32_t draw_x, uint32_t draw_y, long px, long py, long width, long height, anh_rect* out);
+/* outpaint() (annonet.h:74-120), in place on a u8 image with `channels` interleaved channels */
+int anh_outpaint(uint8_t* image, int nr, int nc, int channels, const anh_rect* inside);
+/* dlib count_steps_without_decrease, used by the learning-rate schedule */
+int64_t anh_count_steps_without_decrease(const double* values, int64_t n, double probability_of_decrease);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ANNONET_HIP_H */
