@@ -118,6 +118,7 @@ _SIGNATURES = {
     "anh_trainer_synchronize": (C.c_int, [_P]),
     "anh_trainer_layer_tensor": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int64, C.POINTER(C.c_int)]),
     "anh_profile_enable": (C.c_int, [_P, C.c_int, C.c_int]),
+    "anh_profile_set_filter": (C.c_int, [_P, C.c_int, C.c_char_p]),
     "anh_profile_reset": (C.c_int, [_P, C.c_int]),
     "anh_profile_count": (C.c_int, [_P, C.c_int]),
     "anh_profile_entry": (C.c_int, [_P, C.c_int, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
@@ -136,6 +137,13 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (no CPU fallback exists)")
+        # torch wheels bundle their own libamdhip64 (same soname as /opt/rocm's).  Whichever copy is loaded first
+        # serves the whole process; a second copy cannot open the GPU.  Loading torch first keeps ONE HIP runtime, so
+        # device pointers and streams are interchangeable between torch (plumbing) and this library.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError here = the library does not export a declared symbol

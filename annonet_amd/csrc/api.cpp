@@ -596,6 +596,9 @@ static Engine* engine_of(void* handle, int is_trainer) {
 int anh_profile_enable(void* handle, int is_trainer, int enable) {
     return guarded([&] { Engine* e = engine_of(handle, is_trainer); e->synchronize(); e->prof.enabled = enable != 0; });
 }
+int anh_profile_set_filter(void* handle, int is_trainer, const char* substring) {
+    return guarded([&] { Engine* e = engine_of(handle, is_trainer); e->synchronize(); e->prof.filter = substring ? substring : ""; });
+}
 int anh_profile_reset(void* handle, int is_trainer) {
     return guarded([&] { Engine* e = engine_of(handle, is_trainer); e->synchronize(); e->prof.reset(); });
 }

@@ -19,6 +19,7 @@ class Profiler {
   public:
     struct Entry { std::string name; double total_ms = 0; int64_t launches = 0; double flops = 0, bytes = 0; };
     bool enabled = false;
+    std::string filter;  // when non-empty only kernels whose name contains it are timed
     ~Profiler();
     int begin(hipStream_t s, const char* name, double flops, double bytes);  // returns a token (or -1 when disabled)
     void end(hipStream_t s, int token);

@@ -35,6 +35,7 @@ hipEvent_t Profiler::get_event() {
 }
 int Profiler::begin(hipStream_t s, const char* name, double flops, double bytes) {
     if (!enabled) return -1;
+    if (!filter.empty() && std::string(name).find(filter) == std::string::npos) return -1;
     int idx = -1;
     for (size_t i = 0; i < entries.size(); ++i) if (entries[i].name == name) { idx = (int)i; break; }
     if (idx < 0) { entries.push_back(Entry{name}); idx = (int)entries.size() - 1; }

@@ -25,6 +25,11 @@ template <typename T> __device__ __forceinline__ T from_f(float v);
 template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16 from_f<bf16>(float v) { return (bf16)v; }
 
+// In ANH_BF16 mode a conv consumes bf16 operands (the MFMA A fragment), so the value produced by the bn+relu(+skip)
+// prologue is rounded to bf16 here too: the generic and the MFMA kernels then see identical inputs.
+template <typename T> __device__ __forceinline__ float operand_round(float v) { return v; }
+template <> __device__ __forceinline__ float operand_round<bf16>(float v) { return (float)(bf16)v; }
+
 __device__ __forceinline__ float relu_affine(float y, float s, float t) {
     const float z = fmaf(y, s, t);
     return z > 0.f ? z : 0.f;
@@ -70,7 +75,7 @@ __device__ __forceinline__ float fetch1(const Src& s, int n, int y, int x, int h
     if (KIND == SRC_RAW) return a;
     float v = relu_affine(a, s.a_scale[c], s.a_shift[c]);
     if (KIND == SRC_ACT2) v += relu_affine(to_f<T>(reinterpret_cast<const T*>(s.b)[i]), s.b_scale[c], s.b_shift[c]);
-    return v;
+    return operand_round<T>(v);
 }
 
 template <typename T, int KIND>
@@ -86,6 +91,8 @@ __device__ __forceinline__ void fetch8(const Src& s, size_t pixel, int c_total, 
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] += relu_affine(u[j], s.b_scale[c8 + j], s.b_shift[c8 + j]);
     }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = operand_round<T>(v[j]);
 }
 
 __device__ __forceinline__ bool tap_source(int o, int kk, int stride, int pad, int gather, int limit, int& src) {
@@ -526,8 +533,11 @@ __global__ __launch_bounds__(256) void sgd_kernel(SgdArgs a) {
         w += v;
         a.master[i] = w;
     }
-    a.w_tm_f32[sg.start + tm] = w;
-    a.w_km_f32[sg.start + km] = w;
+    // bf16 mode: the fp32 compute copies of the FILTERS carry the bf16-rounded value, so every kernel multiplies by
+    // the same weights as the MFMA path; bias / gamma / beta stay fp32
+    const float wq = (a.w_tm_bf16 && sg.kind == 0) ? (float)(bf16)w : w;
+    a.w_tm_f32[sg.start + tm] = wq;
+    a.w_km_f32[sg.start + km] = wq;
     if (a.w_tm_bf16) reinterpret_cast<bf16*>(a.w_tm_bf16)[sg.start + tm] = (bf16)w;
     if (a.w_km_bf16) reinterpret_cast<bf16*>(a.w_km_bf16)[sg.start + km] = (bf16)w;
 }

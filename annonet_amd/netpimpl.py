@@ -94,6 +94,9 @@ class _Profiled:
     def profile_enable(self, on=True):
         check(self.L.anh_profile_enable(self.h, self._is_trainer, int(on)))
 
+    def profile_set_filter(self, substring=""):
+        check(self.L.anh_profile_set_filter(self.h, self._is_trainer, (substring or "").encode()))
+
     def profile_reset(self):
         check(self.L.anh_profile_reset(self.h, self._is_trainer))
 

@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""bench.py — BASELINE.json's metric on its config: 227x227 RGB tiles/s, training step (forward + loss + backward +
+SGD update), batch 32 per GPU, bf16, random-init net (levels 2, width 1.0, K=3), synthetic tiles.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One process per GPU; for N > 1 the only exchange step of the path is the all-reduce (RCCL) of the flat gradient
+bucket.  Inputs are resident in HBM before the timed region.  Prints ONE JSON line on rank 0, with
+  roofline     — the dominant kernel class: algorithmic flops (or bytes) per launch / its mean launch time, measured
+                 with HIP events on the compute stream inside the timed region;
+  cpu_baseline — the oracle (a CPU port of the path, see oracle/) timed on this host on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+TILE = 227
+BATCH = 32
+LEVELS, WIDTH, CLASSES = 2, 1.0, 3
+# peaks from /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec), bf16 MFMA ~2.5 PFLOP/s dense (spec)
+PEAK_HBM_GBS = 8000.0
+PEAK_BF16_TFLOPS = 2500.0
+RIDGE = PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
+
+
+def synthetic_batch(rank):
+    import annonet_amd as aa
+    rng_img = np.random.default_rng(1000 * rank + 0)
+    rng_lab = np.random.default_rng(1000 * rank + 1)
+    img = rng_img.integers(0, 256, (BATCH, TILE, TILE, 3), dtype=np.uint8)
+    lab = rng_lab.integers(0, CLASSES, (BATCH, TILE, TILE)).astype(np.uint16)
+    lab[rng_lab.random((BATCH, TILE, TILE)) < 0.05] = 65535
+    w = np.stack([aa.set_weights(lab[i], 0.5, 0.5)["weight"] for i in range(BATCH)])  # annonet_train_main.cpp:292-293 defaults
+    return img, lab, w
+
+
+def cpu_baseline(sample_tiles=4):
+    """The oracle's training step on `sample_tiles` tiles of the same workload, all host cores (OpenMP)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import random_params
+    from oracle.oracle import OracleNet
+    o = OracleNet(LEVELS, 3, CLASSES, WIDTH, 1)
+    p, r = random_params(o, 2)
+    o.params[:], o.running[:] = p, r
+    img, lab, w = synthetic_batch(0)
+    img, lab, w = img[:sample_tiles], lab[:sample_tiles], w[:sample_tiles]
+    o.train_step(img[:1], lab[:1], w[:1])  # warm-up (page-in, OpenMP pool)
+    t0 = time.perf_counter()
+    o.train_step(img, lab, w)
+    dt = time.perf_counter() - t0
+    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    return {"value": sample_tiles / dt, "unit": "tiles/s", "cores": cores, "kind": "port",
+            "sample": f"1 training step on {sample_tiles} tiles of {TILE}x{TILE}x3 (same net, fp32 CPU oracle, {dt:.2f} s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import annonet_amd as aa
+    from annonet_amd import dist as aad
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    aa._lib.check(aa.lib().anh_set_device(local_rank))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    prec = aa.ANH_BF16 if args.precision == "bf16" else aa.ANH_FP32
+    t = aa.TrainingNet(LEVELS, 3, prec, seed=2)
+    t.SetNetWidth(WIDTH, 1)
+    t.SetClassCount(CLASSES)
+    t.Initialize()
+    t.SetLearningRate(0.1)
+    stream = torch.cuda.current_stream()
+    t.set_stream(stream.cuda_stream)
+    bucket = aad.grad_bucket_tensor(t)
+
+    img, lab, w = synthetic_batch(rank)
+    dev = torch.device("cuda", local_rank)
+    d_img = torch.from_numpy(img).to(dev)
+    d_lab = torch.from_numpy(lab.view(np.int16)).to(dev)
+    d_w = torch.from_numpy(w).to(dev)
+
+    def step():
+        aad.data_parallel_step(t, bucket, d_img.data_ptr(), d_lab.data_ptr(), d_w.data_ptr(), BATCH, TILE, TILE, world)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # untimed: warm-up, then a short all-kernel profile to find the dominant kernel class
+    for _ in range(max(args.warmup, 1)):
+        step()
+    t.synchronize()
+    t.profile_enable(True)
+    for _ in range(2):
+        step()
+    t.synchronize()
+    prof_all = t.profile()
+    t.profile_reset()
+    dominant = max(prof_all, key=lambda e: e["total_ms"])["name"] if prof_all else ""
+    t.profile_set_filter(dominant)
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        elapsed = float(el.item())
+    t.synchronize()
+    dom = [e for e in t.profile() if e["name"] == dominant]
+    loss = t.get_last_loss()
+    t.profile_enable(False)
+
+    if rank == 0:
+        roof = None
+        if dom and dom[0]["launches"]:
+            e = dom[0]
+            avg_s = e["total_ms"] / 1e3 / e["launches"]
+            flops, byts = e["flops"] / e["launches"], e["bytes"] / e["launches"]
+            ai = flops / byts if byts else 0.0
+            if flops > 0 and ai >= RIDGE * 0.25:  # dense contraction: quote against the MFMA peak
+                roof = {"bound": "mfma", "achieved": flops / avg_s / 1e12, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s"}
+            else:
+                roof = {"bound": "hbm", "achieved": byts / avg_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s"}
+            roof["frac"] = roof["achieved"] / roof["peak"]
+            roof["traffic"] = None
+            roof["kernel"] = dominant
+            roof["avg_launch_us"] = avg_s * 1e6
+            roof["launches"] = e["launches"]
+            roof["arithmetic_intensity"] = ai
+        total_ms = sum(e["total_ms"] for e in prof_all) or 1.0
+        breakdown = sorted(((e["name"], round(100 * e["total_ms"] / total_ms, 1)) for e in prof_all), key=lambda x: -x[1])[:8]
+        out = {
+            "metric": "227x227 RGB tiles/sec fwd+bwd @ batch 32", "value": BATCH * world * args.steps / elapsed, "unit": "tiles/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": f"training step (fwd+loss+bwd+SGD), batch {BATCH}x3x{TILE}x{TILE} per GPU, encoder-decoder levels={LEVELS} width={WIDTH} K={CLASSES}, random init",
+                       "global_batch": BATCH * world, "parallelism": f"dp{world}"},
+            "roofline": roof,
+            "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline(),
+            "kernel_time_share_pct": breakdown,
+            "final_loss": loss,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

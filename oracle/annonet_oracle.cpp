@@ -46,6 +46,19 @@ constexpr float kBnEps = 1e-4f;      // dlib DEFAULT_BATCH_NORM_EPS [UPSTREAM-UN
 
 thread_local std::string g_err;
 
+// bf16 emulation (round-to-nearest-even, as v_cvt_pk_bf16_f32): used to restate the ANH_BF16 storage points
+//  so that the throughput mode can be held to a tight bar too.
+inline float bf16r(float v) {
+    uint32_t u;
+    std::memcpy(&u, &v, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return v;  // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    u &= 0xffff0000u;
+    std::memcpy(&v, &u, 4);
+    return v;
+}
+inline void round_tensor(std::vector<float>& d) { for (float& v : d) v = bf16r(v); }
+
 // ------------------------------------------------------------------------------------------
 // Net specification.  Stands in for dlib-dnn-pimpl-wrapper/NetStructure.h [ABSENT]
 // (annonet_train.h:16, annonet_train_cuda.vcxproj:247).  DESIGN.md §2 states the same list.
@@ -287,6 +300,7 @@ struct Net {
     // hyper-parameters (annonet_train_main.cpp:396-410)
     double lr = 0.1, weight_decay = 0.0005, mom = 0.9;
     unsigned long bn_window = 100;
+    bool emulate_bf16 = false;  // round weights, conv inputs, stored conv outputs and stored gradients to bf16
     // scratch
     std::vector<Tensor> raw, act, dact;
     Tensor image;
@@ -317,10 +331,19 @@ void affine_from_running(const Net& net, const Layer& L, std::vector<float>& sca
 
 void gather_input(const Net& net, const Layer& L, const std::vector<Tensor>& act, Tensor& x) {
     const Tensor& a = L.in_a < 0 ? net.image : act[L.in_a];
-    if (L.in_b == -2) { x = a; return; }
-    const Tensor& b = act[L.in_b];
-    x.resize(a.n, a.h, a.w, a.c);
-    for (size_t i = 0; i < x.d.size(); ++i) x.d[i] = a.d[i] + b.d[i];
+    if (L.in_b == -2) x = a;
+    else {
+        const Tensor& b = act[L.in_b];
+        x.resize(a.n, a.h, a.w, a.c);
+        for (size_t i = 0; i < x.d.size(); ++i) x.d[i] = a.d[i] + b.d[i];
+    }
+    if (net.emulate_bf16) round_tensor(x.d);  // the MFMA A operand is bf16
+}
+
+std::vector<float> layer_weights(const Net& net, const Layer& L) {
+    std::vector<float> wt = to_tap_major(L, net.params.data() + L.w_off);
+    if (net.emulate_bf16) round_tensor(wt);
+    return wt;
 }
 
 // forward; training=false uses running stats, training=true uses batch stats and records
@@ -336,9 +359,10 @@ void forward(Net& net, bool training, std::vector<BnBatch>* bn_out) {
     for (int li = 0; li < nl; ++li) {
         const Layer& L = s.layers[li];
         gather_input(net, L, net.act, x);
-        std::vector<float> wt = to_tap_major(L, net.params.data() + L.w_off);
+        std::vector<float> wt = layer_weights(net, L);
         conv_forward(L, wt, x, net.raw[li]);
         Tensor& y = net.raw[li];
+        if (net.emulate_bf16 && L.has_bn) round_tensor(y.d);  // raw conv outputs are stored as bf16; logits stay fp32
         Tensor& a = net.act[li];
         a.resize(y.n, y.h, y.w, y.c);
         const size_t P = y.pixels();
@@ -462,6 +486,7 @@ void train_step(Net& net, const uint8_t* images, const uint16_t* labels, const f
                     const float xhat = (y.d[i] - bb.mean[c]) * bb.invstd[c];
                     dy.d[i] = (float)((double)g[c] * bb.invstd[c] * ((double)dz - db[c] * invP - (double)xhat * dg[c] * invP));
                 }
+            if (net.emulate_bf16) round_tensor(dy.d);
         } else {
             dy.d = da.d;
             if (L.has_bias) {
@@ -474,12 +499,13 @@ void train_step(Net& net, const uint8_t* images, const uint16_t* labels, const f
         conv_backward_filter(L, x, dy, dw);
         from_tap_major_add(L, dw.data(), net.grads.data() + L.w_off);
         if (L.in_a >= 0) {
-            std::vector<float> wt = to_tap_major(L, net.params.data() + L.w_off);
+            std::vector<float> wt = layer_weights(net, L);
             Tensor dx; dx.resize(x.n, x.h, x.w, x.c);
             conv_backward_data(L, wt, dy, dx);
+            const bool r = net.emulate_bf16;
             Tensor& ta = net.dact[L.in_a];
-            for (size_t i = 0; i < dx.d.size(); ++i) ta.d[i] += dx.d[i];
-            if (L.in_b >= 0) { Tensor& tb = net.dact[L.in_b]; for (size_t i = 0; i < dx.d.size(); ++i) tb.d[i] += dx.d[i]; }
+            for (size_t i = 0; i < dx.d.size(); ++i) { ta.d[i] += dx.d[i]; if (r) ta.d[i] = bf16r(ta.d[i]); }
+            if (L.in_b >= 0) { Tensor& tb = net.dact[L.in_b]; for (size_t i = 0; i < dx.d.size(); ++i) { tb.d[i] += dx.d[i]; if (r) tb.d[i] = bf16r(tb.d[i]); } }
         }
     }
     if (!apply_update) return;
@@ -628,6 +654,7 @@ double* orc_net_running_updates(void* h) { return ((Net*)h)->running_count.data(
 void orc_net_set_hyper(void* h, double lr, double wd, double mom, unsigned long bn_window) {
     Net* n = (Net*)h; n->lr = lr; n->weight_decay = wd; n->mom = mom; n->bn_window = bn_window;
 }
+void orc_net_set_bf16_emulation(void* h, int on) { ((Net*)h)->emulate_bf16 = on != 0; }
 int orc_required_input_dim(void* h) { return required_dim(((Net*)h)->spec); }
 int orc_recommended_input_dim(int levels, int n) { return recommended_dim(levels, n); }
 

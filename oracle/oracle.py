@@ -51,6 +51,7 @@ def lib():
         L.orc_net_running_updates.restype = C.POINTER(C.c_double)
         L.orc_net_running_updates.argtypes = [C.c_void_p]
         L.orc_net_set_hyper.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_ulong]
+        L.orc_net_set_bf16_emulation.argtypes = [C.c_void_p, C.c_int]
         L.orc_required_input_dim.argtypes = [C.c_void_p]
         L.orc_recommended_input_dim.argtypes = [C.c_int, C.c_int]
         L.orc_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
@@ -128,6 +129,10 @@ class OracleNet:
 
     def set_hyper(self, lr=0.1, wd=0.0005, mom=0.9, bn_window=100):
         self.L.orc_net_set_hyper(self.h, lr, wd, mom, bn_window)
+
+    def set_bf16_emulation(self, on=True):
+        """Round weights, conv inputs, stored conv outputs and stored gradients to bf16 (the ANH_BF16 storage points)."""
+        self.L.orc_net_set_bf16_emulation(self.h, int(on))
 
     def required_input_dim(self):
         return self.L.orc_required_input_dim(self.h)

@@ -203,41 +203,68 @@ def test_loss_scale_uses_global_batch_and_grad_bucket_layout():
 
 
 # ------------------------------------------------------------------------------------------------------------------
-# bf16 throughput mode
+# bf16 throughput mode.  Two bars: (a) against the oracle restating the bf16 storage points (weights, conv inputs,
+# stored conv outputs, stored gradients rounded to bf16; fp32 accumulation) — tight; (b) against the plain fp32
+# oracle — the documented precision loss of the mode.
 # ------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("levels,scaler,minf", [(2, 1.0, 1), (2, 0.25, 4), (1, 1.0, 1), (3, 0.5, 1)])
-def test_bf16_forward_within_tolerance(levels, scaler, minf):
+BF16_CASES = [(2, 1.0, 1), (2, 0.25, 4), (1, 1.0, 1), (3, 0.5, 1), (2, 0.1, 5)]
+
+
+@pytest.mark.parametrize("levels,scaler,minf", BF16_CASES)
+def test_bf16_forward(levels, scaler, minf):
     o, net = pair(levels, 3, 3, scaler, minf, aa.ANH_BF16)
     rng = np.random.default_rng(1)
     d = o.recommended_input_dim(45)
     img = rng.integers(0, 256, (2, d, d + (1 << levels), 3), dtype=np.uint8)
-    want = o.forward(img)
     got = net.Forward(img)
-    span = want.max() - want.min()
+    # (a) bf16-restating oracle: only fp32 accumulation order and rare rounding-boundary flips differ
+    o.set_bf16_emulation(True)
+    emu = o.forward(img)
+    span = emu.max() - emu.min()
+    assert np.abs(got - emu).max() <= 4e-3 * span, (np.abs(got - emu).max(), span)
+    assert np.abs(got - emu).mean() <= 2e-4 * span
+    mism = got.argmax(1) != emu.argmax(1)
+    srt = np.sort(emu, axis=1)
+    assert (srt[:, -1] - srt[:, -2])[mism].max(initial=0) <= 8e-3 * span
+    assert mism.mean() <= 2e-3
+    # (b) plain fp32 oracle
+    o.set_bf16_emulation(False)
+    want = o.forward(img)
     tol = 0.03 * span
-    assert np.abs(got - want).max() <= tol, (np.abs(got - want).max(), span)
-    lw, lg = want.argmax(1), got.argmax(1)
-    mism = lw != lg
-    assert mism.mean() <= 0.03
+    assert np.abs(got - want).max() <= tol
+    mism = got.argmax(1) != want.argmax(1)
     srt = np.sort(want, axis=1)
-    margin = srt[:, -1] - srt[:, -2]
-    assert (margin[mism] <= 2 * tol).all()  # only near-ties may flip
+    assert mism.mean() <= 0.03 and ((srt[:, -1] - srt[:, -2])[mism] <= 2 * tol).all()  # only near-ties may flip
 
 
-@pytest.mark.parametrize("levels,scaler,minf", [(2, 1.0, 1), (1, 0.25, 4)])
-def test_bf16_training_step_within_tolerance(levels, scaler, minf):
+@pytest.mark.parametrize("levels,scaler,minf", [(2, 1.0, 1), (1, 0.25, 4), (3, 0.5, 1), (2, 0.1, 5)])
+def test_bf16_training_step(levels, scaler, minf):
     o, t = trainer_pair(levels, 3, 3, scaler, minf, aa.ANH_BF16)
     rng = np.random.default_rng(2)
     d = o.recommended_input_dim(35)
     img, lab, w, wl = make_batch(rng, 4, d, 3, 3)
+    p0, r0, m0 = o.params.copy(), o.running.copy(), o.momentum.copy()
+    fp32_loss = o.train_step(img, lab, w, apply_update=False)
+    o.set_bf16_emulation(True)
     want_loss = o.train_step(img, lab, w)
     t.StartTraining(list(img), wl)
-    assert abs(t.get_last_loss() - want_loss) <= 0.03 * max(1.0, abs(want_loss))
+    got_loss = t.get_last_loss()
+    assert abs(got_loss - want_loss) <= 2e-3 * max(1.0, abs(want_loss))
+    assert abs(got_loss - fp32_loss) <= 0.03 * max(1.0, abs(fp32_loss))
+    # Whole-net gradients can only be held to a loose bar in bf16: two correct implementations decorrelate at the level
+    # of one bf16 ulp (summation order moves dbeta by ~0.3%, which shifts every dy and re-rolls every rounding), and that
+    # compounds through each bn backward.  Kernel-exact checks with identical inputs live in test_gpu_ops.py.
     g, gw = t.get_grads(), o.grads
-    for L in o.layers:
+    for li, L in enumerate(o.layers):
         nw = L.k * L.k * L.cin * L.cout
         a, b = g[L.w_off:L.w_off + nw], gw[L.w_off:L.w_off + nw]
-        rel = np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-12)
-        assert rel < 0.08, (L.cin, L.cout, L.k, rel)
+        rel = np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-20)
+        cos = float(a @ b) / max(np.linalg.norm(a) * np.linalg.norm(b), 1e-30)
+        assert rel < 0.15 and cos > 0.985, (li, L.cin, L.cout, L.k, rel, cos)
+        if L.has_bn:
+            want = o.layer_output(li, 0)
+            got = t.layer_tensor(li, 0)
+            assert np.abs(got - want).max() <= 1e-2 * np.abs(want).max(), li  # forward: at most one bf16 ulp
     p, r = t.get_params()
     assert np.isfinite(p).all() and np.isfinite(r).all()
+    np.testing.assert_allclose(r, o.running, rtol=2e-2, atol=1e-3)
