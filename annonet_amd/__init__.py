@@ -6,4 +6,5 @@ is the thin host-side mirror used by tests and bench.py.  There is no CPU fallba
 """
 from ._lib import ANH_BF16, ANH_FP32, LABEL_IGNORE, AnnonetHipError, build, lib  # noqa: F401
 from .netpimpl import (RuntimeNet, TrainingNet, annonet_infer, count_steps_without_decrease, net_config, net_layers,  # noqa: F401
-                       outpaint, random_rect_containing_point, set_weights, tiling)
+                       op_conv_backward_data, op_conv_backward_filter, op_conv_forward, outpaint,
+                       random_rect_containing_point, set_weights, tiling)

@@ -43,6 +43,14 @@ class Tile(C.Structure):
     _fields_ = [("full_rect", Rect), ("unique_rect", Rect)]
 
 
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("type", "k", "stride", "pad", "cin", "cout")]
+
+
+class OpInput(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p)]
+
+
 class TilingParams(C.Structure):
     _fields_ = [("max_tile_width", C.c_int), ("max_tile_height", C.c_int), ("overlap_x", C.c_int), ("overlap_y", C.c_int)]
 
@@ -56,7 +64,7 @@ def build(force=False):
 
 
 _P = C.c_void_p
-_SIGNATURES = {
+_SIGNATURES = {  # ConvDesc / OpInput are defined above
     # name: (restype, argtypes)
     "anh_last_error": (C.c_char_p, []),
     "anh_free": (None, [_P]),
@@ -122,6 +130,9 @@ _SIGNATURES = {
     "anh_profile_reset": (C.c_int, [_P, C.c_int]),
     "anh_profile_count": (C.c_int, [_P, C.c_int]),
     "anh_profile_entry": (C.c_int, [_P, C.c_int, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "anh_op_conv_forward": (C.c_int, [C.c_int, C.POINTER(ConvDesc), C.c_int, C.c_int, C.c_int, C.POINTER(OpInput), C.POINTER(OpInput), _P, _P, _P, C.POINTER(C.c_int)]),
+    "anh_op_conv_backward_data": (C.c_int, [C.c_int, C.POINTER(ConvDesc), C.c_int, C.c_int, C.c_int, _P, _P, _P, C.POINTER(C.c_int)]),
+    "anh_op_conv_backward_filter": (C.c_int, [C.c_int, C.POINTER(ConvDesc), C.c_int, C.c_int, C.c_int, C.POINTER(OpInput), C.POINTER(OpInput), _P, _P, C.POINTER(C.c_int)]),
     "anh_get_tiles": (C.c_int, [C.c_int, C.c_int, C.POINTER(TilingParams), C.POINTER(C.POINTER(Tile)), C.POINTER(C.c_size_t)]),
     "anh_set_weights": (C.c_int, [_P, C.c_int, C.c_int, C.c_double, C.c_double, _P]),
     "anh_random_rect_containing_point": (C.c_int, [C.c_uint32, C.c_uint32, C.c_long, C.c_long, C.c_long, C.c_long, C.POINTER(Rect)]),

@@ -40,6 +40,8 @@ struct BlobHeader {
 };
 }  // namespace
 
+namespace anh { void set_last_error(const std::string& message) { g_error = message; } }
+
 struct anh_runtime {
     std::unique_ptr<Engine> eng;
 };

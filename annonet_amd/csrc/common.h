@@ -17,6 +17,8 @@ struct Error : std::runtime_error {
     Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
 };
 
+void set_last_error(const std::string& message);  // api.cpp: thread-local text behind anh_last_error()
+
 [[noreturn]] inline void fail(int code, const std::string& msg) { throw Error(code, msg); }
 
 #define ANH_REQUIRE(cond, msg) \

@@ -8,13 +8,6 @@
 
 namespace anh {
 
-// kernels_mfma.hip
-bool mfma_conv_supported(const ConvArgs& a);
-void launch_conv_mfma(const ConvArgs& a, hipStream_t s);
-bool mfma_wgrad_supported(const WgradArgs& a);
-void launch_wgrad_mfma(const WgradArgs& a, hipStream_t s);
-int64_t wgrad_mfma_scratch_floats(const WgradArgs& a);
-
 namespace {
 constexpr float kBnEps = 1e-4f;  // dlib DEFAULT_BATCH_NORM_EPS [UPSTREAM-UNVERIFIED]
 inline size_t elem_size(DType d) { return d == DT_BF16 ? 2 : 4; }
@@ -278,7 +271,7 @@ Src Engine::layer_source(int li, const Src& image) const {
 }
 
 void Engine::conv_dispatch(const ConvArgs& a, const char* tag, double flops, double bytes) {
-    const bool fast = dtype == DT_BF16 && mfma_conv_supported(a);
+    const bool fast = conv_takes_mfma(a, dtype);
     std::string name = std::string(fast ? "conv_mfma_bf16:" : (dtype == DT_BF16 ? "conv_generic_bf16:" : "conv_generic_f32:")) + tag;
     const int tok = prof.begin(stream, name.c_str(), flops, bytes);
     if (fast) launch_conv_mfma(a, stream);
@@ -287,7 +280,7 @@ void Engine::conv_dispatch(const ConvArgs& a, const char* tag, double flops, dou
 }
 
 void Engine::wgrad_dispatch(WgradArgs& a, const char* tag, double flops, double bytes) {
-    const bool fast = dtype == DT_BF16 && mfma_wgrad_supported(a);
+    const bool fast = wgrad_takes_mfma(a, dtype);
     const int64_t need = fast ? wgrad_mfma_scratch_floats(a) : wgrad_generic_scratch_floats(a);
     wgrad_partials.reserve((size_t)need * 4);
     a.partials = wgrad_partials.as<float>();

@@ -143,4 +143,15 @@ void launch_argmax(const float* blended, int k, int64_t pixels, const double* ga
 
 void launch_fill_zero(void* p, size_t bytes, hipStream_t s);
 
+// kernels_mfma.hip: bf16 MFMA implicit-GEMM kernels; *_supported() says whether a shape is covered
+bool mfma_conv_supported(const ConvArgs& a);
+void launch_conv_mfma(const ConvArgs& a, hipStream_t s);
+bool mfma_wgrad_supported(const WgradArgs& a);
+void launch_wgrad_mfma(const WgradArgs& a, hipStream_t s);
+int64_t wgrad_mfma_scratch_floats(const WgradArgs& a);
+
+// kernel choice shared by the engine and the single-op entry points: MFMA when the mode is bf16 and the shape is covered
+inline bool conv_takes_mfma(const ConvArgs& a, DType mode) { return mode == DT_BF16 && mfma_conv_supported(a); }
+inline bool wgrad_takes_mfma(const WgradArgs& a, DType mode) { return mode == DT_BF16 && mfma_wgrad_supported(a); }
+
 }  // namespace anh

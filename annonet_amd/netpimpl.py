@@ -365,3 +365,62 @@ class TrainingNet(_Profiled):
         out = np.empty(tuple(dims), np.float32)
         check(self.L.anh_trainer_layer_tensor(self.h, layer, which, _ptr(out), out.size, dims))
         return out
+
+
+# ---- single-layer ops (include/annonet_hip.h "single-layer ops"): kernel-level parity tests and micro-benchmarks ----
+def _op_input(x, scale, shift, keep):
+    if x is None:
+        return None
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    s = None if scale is None else np.ascontiguousarray(scale, dtype=np.float32)
+    t = None if shift is None else np.ascontiguousarray(shift, dtype=np.float32)
+    keep.extend([x, s, t])
+    return _lib.OpInput(x.ctypes.data, s.ctypes.data if s is not None else None, t.ctypes.data if t is not None else None)
+
+
+def _out_dim(desc, n):
+    type_, k, stride, pad = desc[:4]
+    if stride <= 0:
+        return 0  # the library rejects the descriptor
+    return (n + 2 * pad - k) // stride + 1 if type_ == 0 else stride * (n - 1) + k - 2 * pad
+
+
+def op_conv_forward(precision, desc, xa, sa=None, ta=None, xb=None, sb=None, tb=None, filters=None, bias=None):
+    """desc = (type, k, stride, pad, cin, cout).  Returns (y [N,Ho,Wo,Cout] fp32, used_mfma)."""
+    keep = []
+    a = _op_input(xa, sa, ta, keep)
+    b = _op_input(xb, sb, tb, keep)
+    n, h, w, _ = keep[0].shape
+    d = _lib.ConvDesc(*desc)
+    f = np.ascontiguousarray(filters, dtype=np.float32)
+    bi = None if bias is None else np.ascontiguousarray(bias, dtype=np.float32)
+    y = np.empty((n, _out_dim(desc, h), _out_dim(desc, w), desc[5]), np.float32)
+    used = C.c_int(0)
+    check(_lib.lib().anh_op_conv_forward(precision, C.byref(d), n, h, w, C.byref(a), C.byref(b) if b is not None else None,
+                                         _ptr(f), _ptr(bi), _ptr(y), C.byref(used)))
+    return y, bool(used.value)
+
+
+def op_conv_backward_data(precision, desc, dy, filters, in_hw):
+    d = _lib.ConvDesc(*desc)
+    g = np.ascontiguousarray(dy, dtype=np.float32)
+    f = np.ascontiguousarray(filters, dtype=np.float32)
+    n = g.shape[0]
+    dx = np.empty((n, in_hw[0], in_hw[1], desc[4]), np.float32)
+    used = C.c_int(0)
+    check(_lib.lib().anh_op_conv_backward_data(precision, C.byref(d), n, in_hw[0], in_hw[1], _ptr(g), _ptr(f), _ptr(dx), C.byref(used)))
+    return dx, bool(used.value)
+
+
+def op_conv_backward_filter(precision, desc, xa, sa=None, ta=None, xb=None, sb=None, tb=None, dy=None):
+    keep = []
+    a = _op_input(xa, sa, ta, keep)
+    b = _op_input(xb, sb, tb, keep)
+    n, h, w, _ = keep[0].shape
+    d = _lib.ConvDesc(*desc)
+    g = np.ascontiguousarray(dy, dtype=np.float32)
+    dw = np.empty(desc[1] * desc[1] * desc[4] * desc[5], np.float32)
+    used = C.c_int(0)
+    check(_lib.lib().anh_op_conv_backward_filter(precision, C.byref(d), n, h, w, C.byref(a), C.byref(b) if b is not None else None,
+                                                 _ptr(g), _ptr(dw), C.byref(used)))
+    return dw, bool(used.value)

@@ -175,6 +175,20 @@ int anh_profile_count(void* handle, int is_trainer);
 int anh_profile_entry(void* handle, int is_trainer, int index, char* name, size_t name_cap,
                       double* total_ms, int64_t* launches, double* flops, double* bytes);
 
+/* ---- single-layer ops on host tensors (kernel-level parity tests and micro-benchmarks) ----
+ * The same kernels the net runs, on caller-provided data.  Tensors are fp32 NHWC on the host; in ANH_BF16 they are
+ * rounded to bf16 on upload and the result is rounded to bf16 storage before it comes back (filter gradients stay fp32).
+ * An input is a producer's raw conv output plus its folded batch-norm: value = relu(x*scale+shift); scale == NULL means
+ * "use x as it is".  A second input, when given, is added (skip connection). */
+typedef struct { int type, k, stride, pad, cin, cout; } anh_conv_desc; /* type 0 = con, 1 = cont */
+typedef struct { const float* x; const float* scale; const float* shift; } anh_op_input;
+int anh_op_conv_forward(int precision, const anh_conv_desc* d, int n, int h_in, int w_in, const anh_op_input* a, const anh_op_input* b,
+                        const float* filters_canonical, const float* bias, float* y_nhwc, int* used_mfma);
+int anh_op_conv_backward_data(int precision, const anh_conv_desc* d, int n, int h_in, int w_in, const float* dy_nhwc,
+                              const float* filters_canonical, float* dx_nhwc, int* used_mfma);
+int anh_op_conv_backward_filter(int precision, const anh_conv_desc* d, int n, int h_in, int w_in, const anh_op_input* a, const anh_op_input* b,
+                                const float* dy_nhwc, float* dw_canonical, int* used_mfma);
+
 /* ---- host logic ---- */
 /* tiling::get_tiles(width, height, params) (annonet_infer.cpp:42): *tiles is malloc'd, release with anh_free */
 int anh_get_tiles(int width, int height, const anh_tiling_params* params, anh_tile** tiles, size_t* count);

@@ -905,6 +905,84 @@ int orc_infer(void* h, const uint8_t* image, int H, int W, const double* gains, 
     ORC_CATCH
 }
 
+
+// ---- single-layer ops on caller tensors (kernel-level parity tests).  Inputs are a producer's raw output plus its
+// folded bn (scale/shift; NULL = use the tensor as it is, no relu), optionally a second (skip) input that is added.
+// bf16 != 0 restates the ANH_BF16 storage points: operands and filters rounded to bf16, result rounded (not dw). ----
+static void op_input(const float* xa, const float* sa, const float* ta, const float* xb, const float* sb, const float* tb,
+                     int n, int h, int w, int c, bool bf16, Tensor& x) {
+    x.resize(n, h, w, c);
+    const size_t P = x.pixels();
+    for (size_t p = 0; p < P; ++p)
+        for (int ch = 0; ch < c; ++ch) {
+            const size_t i = p * c + ch;
+            float v = xa[i];
+            if (sa) { const float z = fmaf(v, sa[ch], ta[ch]); v = z > 0.f ? z : 0.f; }
+            if (xb) {
+                float u = xb[i];
+                if (sb) { const float z = fmaf(u, sb[ch], tb[ch]); u = z > 0.f ? z : 0.f; }
+                v += u;
+            }
+            x.d[i] = bf16 ? bf16r(v) : v;
+        }
+}
+static Layer op_layer(int type, int k, int stride, int pad, int cin, int cout) {
+    Layer L{};
+    L.type = type; L.k = k; L.stride = stride; L.pad = pad; L.cin = cin; L.cout = cout;
+    return L;
+}
+
+int orc_op_conv_forward(int type, int k, int stride, int pad, int cin, int cout, int n, int h, int w,
+                        const float* xa, const float* sa, const float* ta, const float* xb, const float* sb, const float* tb,
+                        const float* filters, const float* bias, int bf16, float* y_out) {
+    ORC_TRY
+    const Layer L = op_layer(type, k, stride, pad, cin, cout);
+    Tensor x, y;
+    op_input(xa, sa, ta, xb, sb, tb, n, h, w, cin, bf16 != 0, x);
+    std::vector<float> wt = to_tap_major(L, filters);
+    if (bf16) round_tensor(wt);
+    conv_forward(L, wt, x, y);
+    for (size_t i = 0; i < y.d.size(); ++i) {
+        float v = y.d[i];
+        if (bias) v = v + bias[i % cout];
+        y_out[i] = (bf16 && !bias) ? bf16r(v) : v;  // biased (head) outputs stay fp32
+    }
+    return 0;
+    ORC_CATCH
+}
+
+int orc_op_conv_backward_data(int type, int k, int stride, int pad, int cin, int cout, int n, int h_in, int w_in,
+                              const float* dy, const float* filters, int bf16, float* dx_out) {
+    ORC_TRY
+    const Layer L = op_layer(type, k, stride, pad, cin, cout);
+    Tensor g, dx;
+    g.resize(n, out_dim(L, h_in), out_dim(L, w_in), cout);
+    for (size_t i = 0; i < g.d.size(); ++i) g.d[i] = bf16 ? bf16r(dy[i]) : dy[i];
+    dx.resize(n, h_in, w_in, cin);
+    std::vector<float> wt = to_tap_major(L, filters);
+    if (bf16) round_tensor(wt);
+    conv_backward_data(L, wt, g, dx);
+    for (size_t i = 0; i < dx.d.size(); ++i) dx_out[i] = bf16 ? bf16r(dx.d[i]) : dx.d[i];
+    return 0;
+    ORC_CATCH
+}
+
+int orc_op_conv_backward_filter(int type, int k, int stride, int pad, int cin, int cout, int n, int h_in, int w_in,
+                                const float* xa, const float* sa, const float* ta, const float* xb, const float* sb, const float* tb,
+                                const float* dy, int bf16, float* dw_canonical) {
+    ORC_TRY
+    const Layer L = op_layer(type, k, stride, pad, cin, cout);
+    Tensor x, g;
+    op_input(xa, sa, ta, xb, sb, tb, n, h_in, w_in, cin, bf16 != 0, x);
+    g.resize(n, out_dim(L, h_in), out_dim(L, w_in), cout);
+    for (size_t i = 0; i < g.d.size(); ++i) g.d[i] = bf16 ? bf16r(dy[i]) : dy[i];
+    std::vector<double> dw;
+    conv_backward_filter(L, x, g, dw);
+    from_tap_major_add(L, dw.data(), dw_canonical);
+    return 0;
+    ORC_CATCH
+}
+
 // ---- learning-rate schedule helper: dlib count_steps_without_decrease [UPSTREAM-UNVERIFIED] ----
 // Walks the loss history backwards, fits a line to the values seen so far and returns the
 // largest suffix length for which P(slope < 0 in forward time) < probability_of_decrease.

@@ -67,6 +67,10 @@ def lib():
         L.orc_get_tiles.argtypes = [C.c_long] * 6 + [C.POINTER(Tile), C.c_int64]
         L.orc_infer.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                 C.c_long, C.c_long, C.c_long, C.c_long, C.POINTER(Tile), C.c_int64, C.c_void_p, C.c_void_p]
+        P = C.c_void_p
+        L.orc_op_conv_forward.argtypes = [C.c_int] * 9 + [P] * 8 + [C.c_int, P]
+        L.orc_op_conv_backward_data.argtypes = [C.c_int] * 9 + [P, P, C.c_int, P]
+        L.orc_op_conv_backward_filter.argtypes = [C.c_int] * 9 + [P] * 7 + [C.c_int, P]
         L.orc_count_steps_without_decrease.restype = C.c_int64
         L.orc_count_steps_without_decrease.argtypes = [C.c_void_p, C.c_int64, C.c_double]
         _LIB = L
@@ -226,3 +230,45 @@ def get_tiles(width, height, max_w, max_h, ov_x, ov_y):
 def count_steps_without_decrease(values, probability_of_decrease=0.51):
     v = np.ascontiguousarray(values, dtype=np.float64)
     return lib().orc_count_steps_without_decrease(_p(v), v.size, probability_of_decrease)
+
+
+def _f32(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _out_dim(desc, n):
+    type_, k, stride, pad = desc[:4]
+    return (n + 2 * pad - k) // stride + 1 if type_ == 0 else stride * (n - 1) + k - 2 * pad
+
+
+def op_conv_forward(desc, xa, sa=None, ta=None, xb=None, sb=None, tb=None, filters=None, bias=None, bf16=False):
+    """desc = (type, k, stride, pad, cin, cout); xa [N,H,W,Cin] fp32 (raw producer output); returns y [N,Ho,Wo,Cout]."""
+    xa, sa, ta, xb, sb, tb, filters, bias = map(_f32, (xa, sa, ta, xb, sb, tb, filters, bias))
+    n, h, w, _ = xa.shape
+    y = np.empty((n, _out_dim(desc, h), _out_dim(desc, w), desc[5]), np.float32)
+    _check(lib().orc_op_conv_forward(*desc, n, h, w, _p(xa), _p(sa), _p(ta), _p(xb), _p(sb), _p(tb), _p(filters), _p(bias), int(bf16), _p(y)))
+    return y
+
+
+def op_conv_backward_data(desc, dy, filters, in_hw, bf16=False):
+    dy, filters = _f32(dy), _f32(filters)
+    n = dy.shape[0]
+    dx = np.empty((n, in_hw[0], in_hw[1], desc[4]), np.float32)
+    _check(lib().orc_op_conv_backward_data(*desc, n, in_hw[0], in_hw[1], _p(dy), _p(filters), int(bf16), _p(dx)))
+    return dx
+
+
+def op_conv_backward_filter(desc, xa, sa=None, ta=None, xb=None, sb=None, tb=None, dy=None, bf16=False):
+    xa, sa, ta, xb, sb, tb, dy = map(_f32, (xa, sa, ta, xb, sb, tb, dy))
+    n, h, w, _ = xa.shape
+    dw = np.empty(desc[1] * desc[1] * desc[4] * desc[5], np.float32)
+    _check(lib().orc_op_conv_backward_filter(*desc, n, h, w, _p(xa), _p(sa), _p(ta), _p(xb), _p(sb), _p(tb), _p(dy), int(bf16), _p(dw)))
+    return dw
+
+
+def bf16_round(a):
+    """Round-to-nearest-even to bf16, returned as fp32 (numpy)."""
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    u = a.view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32).reshape(a.shape)

@@ -1,0 +1,113 @@
+"""Kernel-level parity: one conv / cont op at a time, identical inputs on both sides (anh_op_* vs the oracle's orc_op_*).
+
+  fp32 mode           forward and backward-data are the oracle's k-ordered fmaf chains: BIT-EXACT.
+                      backward-filter sums over pixels in a different order: rtol 2e-4.
+  bf16 mode, generic  same chains on bf16-rounded operands: forward / backward-data BIT-EXACT after rounding.
+  bf16 mode, MFMA     fp32 accumulation in MFMA order: |diff| <= one bf16 ulp of the value (rounding-boundary flips),
+                      on at most 2% of the elements; backward-filter rtol 2e-3 against double accumulation.
+Shapes cover every layer kind of the net (stem 5x5 on 3 channels, 3x3 s1, 3x3 s2, transposed 3x3 s2, 1x1 head), odd
+sizes, ragged tile edges, and the prologue kinds (raw / bn+relu / bn+relu with skip add).
+"""
+import numpy as np
+import pytest
+
+import annonet_amd as aa
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+#           type k  s  p  cin cout   n  h   w
+SHAPES = [
+    ((0, 5, 1, 2, 3, 32), 2, 19, 23),     # stem
+    ((0, 3, 1, 1, 32, 32), 2, 21, 37),    # dec0 / enc
+    ((0, 3, 1, 1, 64, 64), 1, 18, 33),
+    ((0, 3, 1, 1, 128, 128), 1, 9, 35),
+    ((0, 3, 2, 0, 32, 64), 2, 23, 31),    # down
+    ((0, 3, 2, 0, 64, 128), 1, 15, 19),
+    ((1, 3, 2, 0, 128, 64), 1, 7, 9),     # up (transposed)
+    ((1, 3, 2, 0, 64, 32), 2, 11, 15),
+    ((0, 1, 1, 0, 32, 3), 2, 17, 13),     # head
+    ((0, 3, 1, 1, 8, 16), 1, 12, 10),     # narrow nets (width scaler < 1)
+    ((0, 3, 1, 1, 40, 24), 1, 10, 13),    # widths that are not multiples of 32
+]
+
+
+def make_inputs(desc, n, h, w, seed, prologue, bf16):
+    rng = np.random.default_rng(seed)
+    cin, cout = desc[4], desc[5]
+    rnd = orc.bf16_round if bf16 else (lambda a: a.astype(np.float32))
+    xa = rnd(rng.normal(0, 1, (n, h, w, cin)).astype(np.float32))
+    kw = {}
+    if prologue >= 1:
+        kw.update(sa=rng.uniform(0.5, 1.5, cin).astype(np.float32), ta=rng.uniform(-0.3, 0.3, cin).astype(np.float32))
+    if prologue == 2:
+        kw.update(xb=rnd(rng.normal(0, 1, (n, h, w, cin)).astype(np.float32)),
+                  sb=rng.uniform(0.5, 1.5, cin).astype(np.float32), tb=rng.uniform(-0.3, 0.3, cin).astype(np.float32))
+    k = desc[1]
+    lim = np.sqrt(6.0 / (k * k * (cin + cout)))
+    filters = rng.uniform(-lim, lim, k * k * cin * cout).astype(np.float32)
+    return xa, kw, filters, rng
+
+
+def assert_bf16_close(got, want, what):
+    ulp = np.abs(want) * 2.0 ** -7 + 1e-30
+    diff = np.abs(got - want)
+    assert (diff <= ulp * 1.001 + 1e-6 * np.abs(want).max()).all(), (what, float((diff / ulp).max()))
+    assert (diff > 0).mean() <= 0.02, (what, float((diff > 0).mean()))
+
+
+@pytest.mark.parametrize("precision", [aa.ANH_FP32, aa.ANH_BF16])
+@pytest.mark.parametrize("prologue", [0, 1, 2])
+@pytest.mark.parametrize("desc,n,h,w", SHAPES)
+def test_conv_forward(desc, n, h, w, prologue, precision):
+    bf16 = precision == aa.ANH_BF16
+    xa, kw, filters, rng = make_inputs(desc, n, h, w, 1, prologue, bf16)
+    bias = rng.uniform(-0.1, 0.1, desc[5]).astype(np.float32) if desc[1] == 1 else None
+    want = orc.op_conv_forward(desc, xa, filters=filters, bias=bias, bf16=bf16, **kw)
+    got, mfma = aa.op_conv_forward(precision, desc, xa, filters=filters, bias=bias, **kw)
+    assert got.shape == want.shape
+    if not mfma:
+        np.testing.assert_array_equal(got, want)
+    else:
+        assert_bf16_close(got, want, ("fwd", desc))
+
+
+@pytest.mark.parametrize("precision", [aa.ANH_FP32, aa.ANH_BF16])
+@pytest.mark.parametrize("desc,n,h,w", SHAPES)
+def test_conv_backward_data(desc, n, h, w, precision):
+    bf16 = precision == aa.ANH_BF16
+    _, _, filters, rng = make_inputs(desc, n, h, w, 2, 0, bf16)
+    ho, wo = aa.netpimpl._out_dim(desc, h), aa.netpimpl._out_dim(desc, w)
+    dy = rng.normal(0, 1e-3, (n, ho, wo, desc[5])).astype(np.float32)
+    if bf16:
+        dy = orc.bf16_round(dy)
+    want = orc.op_conv_backward_data(desc, dy, filters, (h, w), bf16=bf16)
+    got, mfma = aa.op_conv_backward_data(precision, desc, dy, filters, (h, w))
+    if not mfma:
+        np.testing.assert_array_equal(got, want)
+    else:
+        assert_bf16_close(got, want, ("dgrad", desc))
+
+
+@pytest.mark.parametrize("precision", [aa.ANH_FP32, aa.ANH_BF16])
+@pytest.mark.parametrize("prologue", [0, 2])
+@pytest.mark.parametrize("desc,n,h,w", SHAPES)
+def test_conv_backward_filter(desc, n, h, w, prologue, precision):
+    bf16 = precision == aa.ANH_BF16
+    xa, kw, _, rng = make_inputs(desc, n, h, w, 3, prologue, bf16)
+    ho, wo = aa.netpimpl._out_dim(desc, h), aa.netpimpl._out_dim(desc, w)
+    dy = rng.normal(0, 1e-3, (n, ho, wo, desc[5])).astype(np.float32)
+    if bf16:
+        dy = orc.bf16_round(dy)
+    want = orc.op_conv_backward_filter(desc, xa, dy=dy, bf16=bf16, **kw)
+    got, mfma = aa.op_conv_backward_filter(precision, desc, xa, dy=dy, **kw)
+    tol = 2e-3 if mfma else 2e-4
+    np.testing.assert_allclose(got, want, rtol=tol, atol=tol * np.abs(want).max())
+
+
+def test_ops_reject_bad_arguments():
+    x = np.zeros((1, 4, 4, 8), np.float32)
+    with pytest.raises(aa.AnnonetHipError):
+        aa.op_conv_forward(aa.ANH_FP32, (0, 3, 0, 1, 8, 8), x, filters=np.zeros(9 * 64, np.float32))  # stride 0
+    with pytest.raises(aa.AnnonetHipError):
+        aa.op_conv_forward(aa.ANH_FP32, (0, 3, 2, 0, 8, 8), x[:, :2, :2], filters=np.zeros(9 * 64, np.float32))  # too small
