@@ -1,15 +1,419 @@
-// kernels_mfma.hip — bf16 MFMA implicit-GEMM kernels for the dense 3x3 convolutions (gfx950).
+// kernels_mfma.hip — bf16 MFMA implicit-GEMM kernels for the dense 3x3 convolutions (gfx950 / CDNA4).
+//
+// conv3x3s1_mfma: 3x3, stride 1, pad 1 — the forward of enc/dec layers and (with the taps flipped) their
+// backward-data.  One workgroup = 4 waves = an 8x32 tile of output pixels x all output channels.
+//   * The (8+2)x(32+2) input patch of a 32-channel slab is read from HBM ONCE (16 B per lane, the producer's
+//     bn+relu(+skip add) applied in registers), rounded to bf16 and laid down in LDS as 64-byte pixel records;
+//     all 9 taps then read it from LDS — no im2col expansion ever reaches memory.
+//   * The 16-byte chunk index inside a record is XOR-ed with (record>>2)&3: the 16 lanes of a ds_read_b128
+//     group hit 16 distinct 16-byte slots of the 256-byte bank row (conflict-free for every tap offset).
+//   * Weights ([tap][c_out][c_red] bf16, k contiguous) are staged the same way, 9 or 3 taps at a time.
+//   * MFMA 32x32x16 bf16, A = weights (rows = output channel), B = pixels (cols = pixel): the accumulator puts a
+//     pixel on the lane and 4 consecutive channels in 4 registers, so the epilogue packs to bf16, swaps halves with
+//     v_permlane32_swap and stores 16 B per lane straight to NHWC — no LDS transpose.
+//   * fp32 accumulate; 2 workgroups per CU (<= 59 KB LDS, <= 256 VGPR) overlap one tile's staging with the other's MFMAs.
 #include <hip/hip_runtime.h>
 
 #include "common.h"
 #include "kernels.h"
 
 namespace anh {
+namespace {
 
-bool mfma_conv_supported(const ConvArgs&) { return false; }
-void launch_conv_mfma(const ConvArgs&, hipStream_t) { fail(ANH_ERR_INTERNAL, "conv_mfma: unsupported shape"); }
-bool mfma_wgrad_supported(const WgradArgs&) { return false; }
-void launch_wgrad_mfma(const WgradArgs&, hipStream_t) { fail(ANH_ERR_INTERNAL, "wgrad_mfma: unsupported shape"); }
-int64_t wgrad_mfma_scratch_floats(const WgradArgs&) { return 0; }
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int TH = 8, TW = 32;            // output tile (rows x cols); one wave = 2 rows = 2 MFMA pixel groups
+constexpr int PH = TH + 2, PW = TW + 2;   // input patch
+constexpr int PATCH_PIX = PH * PW;        // 340 pixel records of 64 B
+constexpr int X_BYTES = PATCH_PIX * 64;   // 21,760
+
+__device__ __forceinline__ unsigned pack2(float lo, float hi) {
+    bf16x2 t;
+    t[0] = (bf16)lo; t[1] = (bf16)hi;
+    return __builtin_bit_cast(unsigned, t);
+}
+__device__ __forceinline__ float lo_f(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float hi_f(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+
+__device__ __forceinline__ float relu_affine(float y, float s, float t) {
+    const float z = fmaf(y, s, t);
+    return z > 0.f ? z : 0.f;
+}
+
+// 8 bf16 (one 16-byte chunk) through the producer's bn+relu
+__device__ __forceinline__ void affine8(const uint4& raw, const float* sc, const float* sh, float v[8]) {
+    const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[2 * i] = relu_affine(lo_f(w[i]), sc[2 * i], sh[2 * i]);
+        v[2 * i + 1] = relu_affine(hi_f(w[i]), sc[2 * i + 1], sh[2 * i + 1]);
+    }
+}
+
+template <int NT, int KIND, int TAPS>
+__global__ __launch_bounds__(256, 2) void conv3x3s1_mfma_kernel(ConvArgs a, int tiles_x, int tiles_y, int flip) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* lds_x = smem;
+    char* lds_w = smem + X_BYTES;
+    constexpr int C_OUT = NT * 32;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, col = lane & 31;
+    const int tile = blockIdx.x;
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+    const int x0 = tx * TW, y0 = ty * TH;
+    const int H = a.h_out, W = a.w_out;  // stride 1, pad 1: input and output planes have the same size
+    const int c_red = a.c_red;
+    const bf16* xa = reinterpret_cast<const bf16*>(a.src.a);
+    const bf16* xb = reinterpret_cast<const bf16*>(a.src.b);
+    const bf16* wsrc = reinterpret_cast<const bf16*>(a.w_bf16);
+
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[g][nt][r] = 0.f;
+
+    const int c16 = tid & 3;  // this thread always stages the same 16-byte chunk (8 channels) of a record
+
+    for (int cc = 0; cc < c_red; cc += 32) {
+        float sa[8], ta[8], sb[8], tb[8];
+        if (KIND != SRC_RAW) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { sa[j] = a.src.a_scale[cc + c16 * 8 + j]; ta[j] = a.src.a_shift[cc + c16 * 8 + j]; }
+            if (KIND == SRC_ACT2) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { sb[j] = a.src.b_scale[cc + c16 * 8 + j]; tb[j] = a.src.b_shift[cc + c16 * 8 + j]; }
+            }
+        }
+        __syncthreads();  // every wave is done reading the previous slab's patch and weights
+        // ---- stage the input patch of this 32-channel slab ----
+        for (int item = tid; item < PATCH_PIX * 4; item += 256) {
+            const int px = item >> 2;
+            const int py = px / PW, pxx = px - py * PW;
+            const int iy = y0 - 1 + py, ix = x0 - 1 + pxx;
+            uint4 packed = make_uint4(0u, 0u, 0u, 0u);
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+                const size_t off = (((size_t)n * H + iy) * W + ix) * c_red + cc + c16 * 8;
+                const uint4 raw = *reinterpret_cast<const uint4*>(xa + off);
+                if (KIND == SRC_RAW) packed = raw;
+                else {
+                    float v[8];
+                    affine8(raw, sa, ta, v);
+                    if (KIND == SRC_ACT2) {
+                        float u[8];
+                        affine8(*reinterpret_cast<const uint4*>(xb + off), sb, tb, u);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] += u[j];
+                    }
+                    packed = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
+                }
+            }
+            *reinterpret_cast<uint4*>(lds_x + px * 64 + ((c16 ^ ((px >> 2) & 3)) << 4)) = packed;
+        }
+        for (int t0 = 0; t0 < 9; t0 += TAPS) {
+            if (t0 > 0) __syncthreads();  // the previous tap group's weight reads are done
+            // ---- stage the weights of taps [t0, t0+TAPS) for this slab ----
+            for (int item = tid; item < TAPS * C_OUT * 4; item += 256) {
+                const int rec = item >> 2;
+                const int tl = rec / C_OUT, co = rec - tl * C_OUT;
+                const bf16* src = wsrc + ((size_t)(t0 + tl) * C_OUT + co) * c_red + cc + c16 * 8;
+                *reinterpret_cast<uint4*>(lds_w + rec * 64 + ((c16 ^ ((co >> 2) & 3)) << 4)) = *reinterpret_cast<const uint4*>(src);
+            }
+            __syncthreads();
+            // ---- MFMA over the staged taps ----
+#pragma unroll
+            for (int tl = 0; tl < TAPS; ++tl) {
+                const int tap = t0 + tl;
+                const int ky = tap / 3, kx = tap - ky * 3;
+                const int pky = flip ? 2 - ky : ky, pkx = flip ? 2 - kx : kx;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int chunk = (ks << 1) | half;
+                    bf16x8 xf[2];
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        const int pidx = (wave * 2 + g + pky) * PW + col + pkx;
+                        xf[g] = *reinterpret_cast<const bf16x8*>(lds_x + pidx * 64 + ((chunk ^ ((pidx >> 2) & 3)) << 4));
+                    }
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const int co = nt * 32 + col;
+                        const bf16x8 wf = *reinterpret_cast<const bf16x8*>(lds_w + (tl * C_OUT + co) * 64 + ((chunk ^ ((co >> 2) & 3)) << 4));
+#pragma unroll
+                        for (int g = 0; g < 2; ++g) acc[g][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf[g], acc[g][nt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: lane = pixel (col) x half; registers 4q..4q+3 = channels 8q+4*half+0..3 of the 32-channel tile ----
+    bf16* out = reinterpret_cast<bf16*>(a.out);
+    bf16* out2 = reinterpret_cast<bf16*>(a.out2);
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int oy = y0 + wave * 2 + g, ox = x0 + col;
+        const bool valid = oy < H && ox < W;
+        const size_t pix = ((size_t)n * H + (valid ? oy : 0)) * W + (valid ? ox : 0);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const f32x16& v = acc[g][nt];
+                unsigned a0 = pack2(v[8 * s + 0], v[8 * s + 1]), a1 = pack2(v[8 * s + 2], v[8 * s + 3]);
+                unsigned b0 = pack2(v[8 * s + 4], v[8 * s + 5]), b1 = pack2(v[8 * s + 6], v[8 * s + 7]);
+                // lanes 32-63 of a* swap with lanes 0-31 of b*: afterwards every lane holds 8 consecutive channels
+                auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+                auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+                uint4 q = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+                if (!valid) continue;
+                const size_t o = pix * C_OUT + nt * 32 + 16 * s + 8 * half;
+                if (a.out_accumulate) {
+                    const uint4 old = *reinterpret_cast<const uint4*>(out + o);
+                    const uint4 sum = make_uint4(pack2(lo_f(old.x) + lo_f(q.x), hi_f(old.x) + hi_f(q.x)), pack2(lo_f(old.y) + lo_f(q.y), hi_f(old.y) + hi_f(q.y)),
+                                                 pack2(lo_f(old.z) + lo_f(q.z), hi_f(old.z) + hi_f(q.z)), pack2(lo_f(old.w) + lo_f(q.w), hi_f(old.w) + hi_f(q.w)));
+                    *reinterpret_cast<uint4*>(out + o) = sum;
+                } else *reinterpret_cast<uint4*>(out + o) = q;
+                if (out2) {
+                    if (a.out2_accumulate) {
+                        const uint4 old = *reinterpret_cast<const uint4*>(out2 + o);
+                        const uint4 sum = make_uint4(pack2(lo_f(old.x) + lo_f(q.x), hi_f(old.x) + hi_f(q.x)), pack2(lo_f(old.y) + lo_f(q.y), hi_f(old.y) + hi_f(q.y)),
+                                                     pack2(lo_f(old.z) + lo_f(q.z), hi_f(old.z) + hi_f(q.z)), pack2(lo_f(old.w) + lo_f(q.w), hi_f(old.w) + hi_f(q.w)));
+                        *reinterpret_cast<uint4*>(out2 + o) = sum;
+                    } else *reinterpret_cast<uint4*>(out2 + o) = q;
+                }
+            }
+        }
+    }
+}
+
+template <int NT, int TAPS>
+void launch_s1(const ConvArgs& a, hipStream_t s) {
+    const int tiles_x = (a.w_out + TW - 1) / TW, tiles_y = (a.h_out + TH - 1) / TH;
+    const dim3 grid((unsigned)(tiles_x * tiles_y * a.n)), block(256);
+    const size_t lds = X_BYTES + (size_t)TAPS * NT * 32 * 64;
+    const int flip = a.gather;  // backward-data of a stride-1 conv = the same conv with the taps mirrored
+    switch (a.src.kind) {
+        case SRC_RAW: hipLaunchKernelGGL((conv3x3s1_mfma_kernel<NT, SRC_RAW, TAPS>), grid, block, lds, s, a, tiles_x, tiles_y, flip); break;
+        case SRC_ACT: hipLaunchKernelGGL((conv3x3s1_mfma_kernel<NT, SRC_ACT, TAPS>), grid, block, lds, s, a, tiles_x, tiles_y, flip); break;
+        default: hipLaunchKernelGGL((conv3x3s1_mfma_kernel<NT, SRC_ACT2, TAPS>), grid, block, lds, s, a, tiles_x, tiles_y, flip); break;
+    }
+    HIP_CHECK(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// wgrad3x3s1_mfma: filter gradient of a 3x3 stride-1 conv.  dw[tap][ci][co] = sum over pixels x[p + tap][ci] * dy[p][co].
+// The reduction runs over PIXELS, which NHWC keeps strided — so both MFMA operands are fetched with the transposing
+// LDS read ds_read_b64_tr_b16 (4 pixels x 16 channels per 16-lane group, delivered channel-major): the tile is staged
+// exactly as in the forward kernel (64-byte pixel records, XOR-swizzled chunks) and never transposed in memory.
+// One workgroup = (32-channel input slab) x (all output channels) x a strided set of 8x32 pixel tiles; the 9*NTC
+// 32x32 output tiles are dealt round-robin to the 4 waves and stay in accumulators across all of the workgroup's
+// pixel tiles; each workgroup then writes ONE partial, and a fixed-order reduction sums them (deterministic).
+// ---------------------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+constexpr int G_BYTES_PER_NT = TH * TW * 64;  // 16,384: dy tile of one 32-channel group
+
+__device__ __forceinline__ bf16x8 tr_read8(const char* base, int pix_first, int lane) {
+    // this lane's share of a 16(k = pixel) x 32(channel) operand: pixels pix_first + 8*half + {0..7}, channel = lane & 31
+    const int i16 = lane & 15, q = i16 >> 2, p = i16 & 3, cg = (lane >> 4) & 1, half = lane >> 5;
+    s16x4 r[2];
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        const int pix = pix_first + 8 * half + 4 * rr + q;
+        const char* addr = base + pix * 64 + ((((cg << 1) | (p >> 1)) ^ ((pix >> 2) & 3)) << 4) + ((p & 1) << 3);
+        r[rr] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(addr));
+    }
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    s16x8 v = {r[0][0], r[0][1], r[0][2], r[0][3], r[1][0], r[1][1], r[1][2], r[1][3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int NTC, int KIND>
+__global__ __launch_bounds__(256, (NTC == 4 ? 1 : 2)) void wgrad3x3s1_mfma_kernel(WgradArgs a, int tiles_x, int tiles_y, int total_tiles, int splits) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* lds_x = smem;
+    char* lds_g = smem + X_BYTES;
+    constexpr int C_OUT = NTC * 32;
+    constexpr int TPW = (9 * NTC + 3) / 4;  // output tiles per wave
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int slab = blockIdx.y, split = blockIdx.x;
+    const int H = a.h_out, W = a.w_out, c_in = a.c_in;
+    const int cc = slab * 32;
+    const bf16* xa = reinterpret_cast<const bf16*>(a.src.a);
+    const bf16* xb = reinterpret_cast<const bf16*>(a.src.b);
+    const bf16* dy = reinterpret_cast<const bf16*>(a.dy);
+    const int c16 = tid & 3;
+    const int nt_mine = wave % NTC;
+
+    float sa[8], ta[8], sb[8], tb[8];
+    if (KIND != SRC_RAW) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { sa[j] = a.src.a_scale[cc + c16 * 8 + j]; ta[j] = a.src.a_shift[cc + c16 * 8 + j]; }
+        if (KIND == SRC_ACT2) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { sb[j] = a.src.b_scale[cc + c16 * 8 + j]; tb[j] = a.src.b_shift[cc + c16 * 8 + j]; }
+        }
+    }
+
+    f32x16 acc[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    for (int tile = split; tile < total_tiles; tile += splits) {
+        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+        const int x0 = tx * TW, y0 = ty * TH;
+        __syncthreads();
+        // ---- x patch of this channel slab (same staging as the forward kernel) ----
+        for (int item = tid; item < PATCH_PIX * 4; item += 256) {
+            const int px = item >> 2;
+            const int py = px / PW, pxx = px - py * PW;
+            const int iy = y0 - 1 + py, ix = x0 - 1 + pxx;
+            uint4 packed = make_uint4(0u, 0u, 0u, 0u);
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+                const size_t off = (((size_t)n * H + iy) * W + ix) * c_in + cc + c16 * 8;
+                const uint4 raw = *reinterpret_cast<const uint4*>(xa + off);
+                if (KIND == SRC_RAW) packed = raw;
+                else {
+                    float v[8];
+                    affine8(raw, sa, ta, v);
+                    if (KIND == SRC_ACT2) {
+                        float u[8];
+                        affine8(*reinterpret_cast<const uint4*>(xb + off), sb, tb, u);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] += u[j];
+                    }
+                    packed = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
+                }
+            }
+            *reinterpret_cast<uint4*>(lds_x + px * 64 + ((c16 ^ ((px >> 2) & 3)) << 4)) = packed;
+        }
+        // ---- dy tile: [nt][pixel][32 channels]; pixels outside the image contribute zeros ----
+        for (int item = tid; item < TH * TW * NTC * 4; item += 256) {
+            const int rec = item >> 2;          // nt * 256 + pixel
+            const int nt = rec / (TH * TW), pt = rec - nt * (TH * TW);
+            const int oy = y0 + pt / TW, ox = x0 + (pt % TW);
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (oy < H && ox < W) v = *reinterpret_cast<const uint4*>(dy + (((size_t)n * H + oy) * W + ox) * C_OUT + nt * 32 + c16 * 8);
+            *reinterpret_cast<uint4*>(lds_g + rec * 64 + ((c16 ^ ((pt >> 2) & 3)) << 4)) = v;
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int ks = 0; ks < 16; ++ks) {
+            const int row = ks >> 1, xh = (ks & 1) << 4;
+            const bf16x8 gf = tr_read8(lds_g + nt_mine * G_BYTES_PER_NT, row * TW + xh, lane);
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) {
+                const int j = wave + 4 * i;
+                if (j < 9 * NTC) {
+                    const int tap = j / NTC;
+                    const int ky = tap / 3, kx = tap - ky * 3;
+                    const bf16x8 xf = tr_read8(lds_x, (row + ky) * PW + xh + kx, lane);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf, gf, acc[i], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // ---- one partial per workgroup: partials[split][tap][ci][co] ----
+    const size_t nw = (size_t)9 * c_in * C_OUT;
+    float* out = a.partials + (size_t)split * nw;
+    const int col = lane & 31, half = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        const int j = wave + 4 * i;
+        if (j < 9 * NTC) {
+            const int tap = j / NTC;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = cc + (r & 3) + 8 * (r >> 2) + 4 * half;
+                out[((size_t)tap * c_in + ci) * C_OUT + nt_mine * 32 + col] = acc[i][r];
+            }
+        }
+    }
+}
+
+__global__ void reduce_partials_mfma_kernel(const float* partials, int splits, int64_t nw, float* out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nw) return;
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += partials[(size_t)k * nw + i];
+    out[i] = s;
+}
+
+int wgrad_splits(const WgradArgs& a) {
+    const int tiles = ((a.w_out + TW - 1) / TW) * ((a.h_out + TH - 1) / TH) * a.n;
+    const int slabs = a.c_in / 32;
+    const int target_blocks = a.c_out == 128 ? 256 : 512;
+    int splits = target_blocks / slabs;
+    if (splits < 1) splits = 1;
+    if (splits > tiles) splits = tiles;
+    return splits;
+}
+
+template <int NTC>
+void launch_wgrad_s1(const WgradArgs& a, hipStream_t s) {
+    const int tiles_x = (a.w_out + TW - 1) / TW, tiles_y = (a.h_out + TH - 1) / TH;
+    const int total = tiles_x * tiles_y * a.n;
+    const int splits = wgrad_splits(a);
+    const dim3 grid(splits, a.c_in / 32), block(256);
+    const size_t lds = X_BYTES + (size_t)NTC * G_BYTES_PER_NT;
+    auto go = [&](auto kernel) {
+        if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kernel, grid, block, lds, s, a, tiles_x, tiles_y, total, splits);
+    };
+    switch (a.src.kind) {
+        case SRC_RAW: go(wgrad3x3s1_mfma_kernel<NTC, SRC_RAW>); break;
+        case SRC_ACT: go(wgrad3x3s1_mfma_kernel<NTC, SRC_ACT>); break;
+        default: go(wgrad3x3s1_mfma_kernel<NTC, SRC_ACT2>); break;
+    }
+    HIP_CHECK(hipGetLastError());
+    const int64_t nw = (int64_t)9 * a.c_in * a.c_out;
+    hipLaunchKernelGGL(reduce_partials_mfma_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s, a.partials, splits, nw, a.dw);
+    HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace
+
+bool mfma_conv_supported(const ConvArgs& a) {
+    if (a.k != 3 || a.stride != 1 || a.pad != 1) return false;
+    if (a.src.kind == SRC_IMAGE || a.src.dtype != DT_BF16 || a.out_dtype != DT_BF16 || a.out_nchw || a.bias) return false;
+    if (a.c_red % 32 != 0 || !(a.c_out == 32 || a.c_out == 64 || a.c_out == 128)) return false;
+    if (a.h_in != a.h_out || a.w_in != a.w_out || !a.w_bf16) return false;
+    return true;
+}
+
+void launch_conv_mfma(const ConvArgs& a, hipStream_t s) {
+    if (!mfma_conv_supported(a)) fail(ANH_ERR_INTERNAL, "conv_mfma: unsupported shape");
+    if ((int64_t)a.n * a.h_out * a.w_out == 0) return;
+    if (a.c_out == 32) launch_s1<1, 9>(a, s);
+    else if (a.c_out == 64) launch_s1<2, 9>(a, s);
+    else launch_s1<4, 3>(a, s);
+}
+
+bool mfma_wgrad_supported(const WgradArgs& a) {
+    if (a.k != 3 || a.stride != 1 || a.pad != 1 || a.gather != 0) return false;
+    if (a.src.kind == SRC_IMAGE || a.src.dtype != DT_BF16 || a.dy_dtype != DT_BF16) return false;
+    if (a.c_in % 32 != 0 || !(a.c_out == 32 || a.c_out == 64 || a.c_out == 128)) return false;
+    return a.h_in == a.h_out && a.w_in == a.w_out;
+}
+
+int64_t wgrad_mfma_scratch_floats(const WgradArgs& a) { return (int64_t)wgrad_splits(a) * 9 * a.c_in * a.c_out; }
+
+void launch_wgrad_mfma(const WgradArgs& a, hipStream_t s) {
+    if (!mfma_wgrad_supported(a)) fail(ANH_ERR_INTERNAL, "wgrad_mfma: unsupported shape");
+    ANH_REQUIRE(wgrad_mfma_scratch_floats(a) <= a.partials_capacity, "wgrad scratch too small");
+    if ((int64_t)a.n * a.h_out * a.w_out == 0) return;
+    if (a.c_out == 32) launch_wgrad_s1<1>(a, s);
+    else if (a.c_out == 64) launch_wgrad_s1<2>(a, s);
+    else launch_wgrad_s1<4>(a, s);
+}
 
 }  // namespace anh

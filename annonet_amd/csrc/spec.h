@@ -26,7 +26,8 @@ struct Spec {
         return (int64_t)L.k * L.k * L.cin * L.cout;
     }
     static int out_dim(const anh_layer_desc& L, int in) {
-        return L.type == 0 ? (in + 2 * L.pad - L.k) / L.stride + 1 : L.stride * (in - 1) + L.k - 2 * L.pad;
+        if (L.type == 0) return in + 2 * L.pad < L.k ? 0 : (in + 2 * L.pad - L.k) / L.stride + 1;
+        return L.stride * (in - 1) + L.k - 2 * L.pad;
     }
     int required_input_dim() const;
     static int recommended_input_dim(int levels, int n);

@@ -123,7 +123,7 @@ Spec build_spec(int levels, int in_ch, int classes, double scaler, int min_filte
 }
 
 int out_dim(const Layer& L, int in) {
-    if (L.type == 0) return (in + 2 * L.pad - L.k) / L.stride + 1;
+    if (L.type == 0) return in + 2 * L.pad < L.k ? 0 : (in + 2 * L.pad - L.k) / L.stride + 1;
     return L.stride * (in - 1) + L.k - 2 * L.pad;
 }
 
