@@ -14,6 +14,8 @@
 //   * fp32 accumulate; 2 workgroups per CU (<= 59 KB LDS, <= 256 VGPR) overlap one tile's staging with the other's MFMAs.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -208,25 +210,44 @@ void launch_s1(const ConvArgs& a, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// wgrad3x3s1_mfma: filter gradient of a 3x3 stride-1 conv.  dw[tap][ci][co] = sum over pixels x[p + tap][ci] * dy[p][co].
+// wgrad3x3_mfma: filter gradient of the 3x3 layers.
+//   con, stride 1 pad 1 :  dw[t][ci][co] = sum_p x[p + t - 1][ci] * dy[p][co]
+//   con, stride 2 pad 0 :  dw[t][ci][co] = sum_o x[2o + t][ci]   * dy[o][co]
+//   cont, stride 2 pad 0:  dw[t][ci][co] = sum_i x[i][ci]        * dy[2i + t][co]
+// All three are "sum over the pixels of a low-res TILE tensor of  PATCH[stride*p + t + origin] (x) TILE[p]".
 // The reduction runs over PIXELS, which NHWC keeps strided — so both MFMA operands are fetched with the transposing
-// LDS read ds_read_b64_tr_b16 (4 pixels x 16 channels per 16-lane group, delivered channel-major): the tile is staged
-// exactly as in the forward kernel (64-byte pixel records, XOR-swizzled chunks) and never transposed in memory.
-// One workgroup = (32-channel input slab) x (all output channels) x a strided set of 8x32 pixel tiles; the 9*NTC
-// 32x32 output tiles are dealt round-robin to the 4 waves and stay in accumulators across all of the workgroup's
-// pixel tiles; each workgroup then writes ONE partial, and a fixed-order reduction sums them (deterministic).
+// LDS read ds_read_b64_tr_b16 (4 pixels x 16 channels per 16-lane group, delivered channel-major): tensors are staged
+// as in the forward kernel (64-byte pixel records, XOR-swizzled chunks, producer bn+relu applied on the way in) and are
+// never transposed in memory.  For stride 2 the patch is stored split by column parity, so a tap still reads 16
+// CONSECUTIVE records.  One workgroup = (32-channel patch slab) x (all tile channels) x a strided set of pixel tiles;
+// its 9*NTC 32x32 output tiles are dealt round-robin to the 4 waves and stay in accumulators across all of its pixel
+// tiles; it writes ONE partial, and a fixed-order pass sums the partials (deterministic, no float atomics).
 // ---------------------------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(4))) short s16x4;
-constexpr int G_BYTES_PER_NT = TH * TW * 64;  // 16,384: dy tile of one 32-channel group
 
-__device__ __forceinline__ bf16x8 tr_read8(const char* base, int pix_first, int lane) {
-    // this lane's share of a 16(k = pixel) x 32(channel) operand: pixels pix_first + 8*half + {0..7}, channel = lane & 31
+struct WgSide {
+    const bf16* a; const float* a_scale; const float* a_shift;
+    const bf16* b; const float* b_scale; const float* b_shift;
+    int h, w, c;
+};
+struct WgParams {
+    WgSide patch, tile;
+    int n, c_in, c_out, transpose_out;  // transpose_out: patch channels are the OUTPUT channels (cont)
+    float* partials;
+};
+
+template <int STRIDE> struct WgGeom;
+template <> struct WgGeom<1> { static constexpr int TH = 8, TW = 32, RECS = 10 * 34, ORIGIN = -1; };
+template <> struct WgGeom<2> { static constexpr int TH = 4, TW = 32, RECS = 9 * 66, ORIGIN = 0; };
+
+__device__ __forceinline__ bf16x8 tr_read8(const char* base, int rec_first, int lane) {
+    // this lane's share of a 16(k = pixel) x 32(channel) operand: records rec_first + 8*half + {0..7}, channel = lane & 31
     const int i16 = lane & 15, q = i16 >> 2, p = i16 & 3, cg = (lane >> 4) & 1, half = lane >> 5;
     s16x4 r[2];
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
-        const int pix = pix_first + 8 * half + 4 * rr + q;
-        const char* addr = base + pix * 64 + ((((cg << 1) | (p >> 1)) ^ ((pix >> 2) & 3)) << 4) + ((p & 1) << 3);
+        const int rec = rec_first + 8 * half + 4 * rr + q;
+        const char* addr = base + rec * 64 + ((((cg << 1) | (p >> 1)) ^ ((rec >> 2) & 3)) << 4) + ((p & 1) << 3);
         r[rr] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(addr));
     }
     typedef __attribute__((ext_vector_type(8))) short s16x8;
@@ -234,33 +255,37 @@ __device__ __forceinline__ bf16x8 tr_read8(const char* base, int pix_first, int 
     return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int NTC, int KIND>
-__global__ __launch_bounds__(256, (NTC == 4 ? 1 : 2)) void wgrad3x3s1_mfma_kernel(WgradArgs a, int tiles_x, int tiles_y, int total_tiles, int splits) {
+// one 16-byte chunk (8 channels starting at channel ch) of pixel `pix` through the side's prologue
+template <int KIND>
+__device__ __forceinline__ uint4 side_chunk(const WgSide& s, size_t pix, int ch) {
+    const size_t off = pix * s.c + ch;
+    const uint4 raw = *reinterpret_cast<const uint4*>(s.a + off);
+    if (KIND == SRC_RAW) return raw;
+    float v[8];
+    affine8(raw, s.a_scale + ch, s.a_shift + ch, v);
+    if (KIND == SRC_ACT2) {
+        float u[8];
+        affine8(*reinterpret_cast<const uint4*>(s.b + off), s.b_scale + ch, s.b_shift + ch, u);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += u[j];
+    }
+    return make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
+}
+
+template <int NTC, int KP, int KT, int STRIDE>
+__global__ __launch_bounds__(256, ((STRIDE == 1 && NTC == 4) ? 1 : 2)) void wgrad3x3_mfma_kernel(WgParams a, int tiles_x, int tiles_y, int total_tiles, int splits) {
+    using G = WgGeom<STRIDE>;
+    constexpr int TH = G::TH, TW = G::TW, TILE_PIX = TH * TW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* lds_x = smem;
-    char* lds_g = smem + X_BYTES;
-    constexpr int C_OUT = NTC * 32;
+    char* lds_p = smem;
+    char* lds_t = smem + G::RECS * 64;
     constexpr int TPW = (9 * NTC + 3) / 4;  // output tiles per wave
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int slab = blockIdx.y, split = blockIdx.x;
-    const int H = a.h_out, W = a.w_out, c_in = a.c_in;
     const int cc = slab * 32;
-    const bf16* xa = reinterpret_cast<const bf16*>(a.src.a);
-    const bf16* xb = reinterpret_cast<const bf16*>(a.src.b);
-    const bf16* dy = reinterpret_cast<const bf16*>(a.dy);
     const int c16 = tid & 3;
     const int nt_mine = wave % NTC;
-
-    float sa[8], ta[8], sb[8], tb[8];
-    if (KIND != SRC_RAW) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { sa[j] = a.src.a_scale[cc + c16 * 8 + j]; ta[j] = a.src.a_shift[cc + c16 * 8 + j]; }
-        if (KIND == SRC_ACT2) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { sb[j] = a.src.b_scale[cc + c16 * 8 + j]; tb[j] = a.src.b_shift[cc + c16 * 8 + j]; }
-        }
-    }
 
     f32x16 acc[TPW];
 #pragma unroll
@@ -272,58 +297,47 @@ __global__ __launch_bounds__(256, (NTC == 4 ? 1 : 2)) void wgrad3x3s1_mfma_kerne
         const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
         const int x0 = tx * TW, y0 = ty * TH;
         __syncthreads();
-        // ---- x patch of this channel slab (same staging as the forward kernel) ----
-        for (int item = tid; item < PATCH_PIX * 4; item += 256) {
-            const int px = item >> 2;
-            const int py = px / PW, pxx = px - py * PW;
-            const int iy = y0 - 1 + py, ix = x0 - 1 + pxx;
-            uint4 packed = make_uint4(0u, 0u, 0u, 0u);
-            if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
-                const size_t off = (((size_t)n * H + iy) * W + ix) * c_in + cc + c16 * 8;
-                const uint4 raw = *reinterpret_cast<const uint4*>(xa + off);
-                if (KIND == SRC_RAW) packed = raw;
-                else {
-                    float v[8];
-                    affine8(raw, sa, ta, v);
-                    if (KIND == SRC_ACT2) {
-                        float u[8];
-                        affine8(*reinterpret_cast<const uint4*>(xb + off), sb, tb, u);
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) v[j] += u[j];
-                    }
-                    packed = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
-                }
-            }
-            *reinterpret_cast<uint4*>(lds_x + px * 64 + ((c16 ^ ((px >> 2) & 3)) << 4)) = packed;
+        // ---- patch slab ----
+        for (int item = tid; item < G::RECS * 4; item += 256) {
+            const int rec = item >> 2;
+            int py, pxx;
+            if (STRIDE == 1) { py = rec / 34; pxx = rec - py * 34; }
+            else { py = rec / 66; const int rem = rec - py * 66; const int par = rem >= 33; pxx = 2 * (rem - 33 * par) + par; }
+            const int iy = STRIDE * y0 + G::ORIGIN + py, ix = STRIDE * x0 + G::ORIGIN + pxx;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (iy >= 0 && iy < a.patch.h && ix >= 0 && ix < a.patch.w)
+                v = side_chunk<KP>(a.patch, ((size_t)n * a.patch.h + iy) * a.patch.w + ix, cc + c16 * 8);
+            *reinterpret_cast<uint4*>(lds_p + rec * 64 + ((c16 ^ ((rec >> 2) & 3)) << 4)) = v;
         }
-        // ---- dy tile: [nt][pixel][32 channels]; pixels outside the image contribute zeros ----
-        for (int item = tid; item < TH * TW * NTC * 4; item += 256) {
-            const int rec = item >> 2;          // nt * 256 + pixel
-            const int nt = rec / (TH * TW), pt = rec - nt * (TH * TW);
+        // ---- tile: [nt][pixel][32 channels]; pixels outside the tensor contribute zeros ----
+        for (int item = tid; item < TILE_PIX * NTC * 4; item += 256) {
+            const int rec = item >> 2;
+            const int nt = rec / TILE_PIX, pt = rec - nt * TILE_PIX;
             const int oy = y0 + pt / TW, ox = x0 + (pt % TW);
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (oy < H && ox < W) v = *reinterpret_cast<const uint4*>(dy + (((size_t)n * H + oy) * W + ox) * C_OUT + nt * 32 + c16 * 8);
-            *reinterpret_cast<uint4*>(lds_g + rec * 64 + ((c16 ^ ((pt >> 2) & 3)) << 4)) = v;
+            if (oy < a.tile.h && ox < a.tile.w) v = side_chunk<KT>(a.tile, ((size_t)n * a.tile.h + oy) * a.tile.w + ox, nt * 32 + c16 * 8);
+            *reinterpret_cast<uint4*>(lds_t + rec * 64 + ((c16 ^ ((pt >> 2) & 3)) << 4)) = v;
         }
         __syncthreads();
 #pragma unroll 2
-        for (int ks = 0; ks < 16; ++ks) {
+        for (int ks = 0; ks < TILE_PIX / 16; ++ks) {
             const int row = ks >> 1, xh = (ks & 1) << 4;
-            const bf16x8 gf = tr_read8(lds_g + nt_mine * G_BYTES_PER_NT, row * TW + xh, lane);
+            const bf16x8 tf = tr_read8(lds_t + nt_mine * (TILE_PIX * 64), row * TW + xh, lane);
 #pragma unroll
             for (int i = 0; i < TPW; ++i) {
                 const int j = wave + 4 * i;
                 if (j < 9 * NTC) {
                     const int tap = j / NTC;
                     const int ky = tap / 3, kx = tap - ky * 3;
-                    const bf16x8 xf = tr_read8(lds_x, (row + ky) * PW + xh + kx, lane);
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf, gf, acc[i], 0, 0, 0);
+                    const int first = STRIDE == 1 ? (row + ky) * 34 + xh + kx : ((2 * row + ky) * 2 + (kx & 1)) * 33 + xh + (kx >> 1);
+                    const bf16x8 pf = tr_read8(lds_p, first, lane);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, tf, acc[i], 0, 0, 0);
                 }
             }
         }
     }
-    // ---- one partial per workgroup: partials[split][tap][ci][co] ----
-    const size_t nw = (size_t)9 * c_in * C_OUT;
+    // ---- one partial per workgroup, laid out as dw: [tap][ci][co] ----
+    const size_t nw = (size_t)9 * a.c_in * a.c_out;
     float* out = a.partials + (size_t)split * nw;
     const int col = lane & 31, half = lane >> 5;
 #pragma unroll
@@ -333,8 +347,10 @@ __global__ __launch_bounds__(256, (NTC == 4 ? 1 : 2)) void wgrad3x3s1_mfma_kerne
             const int tap = j / NTC;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int ci = cc + (r & 3) + 8 * (r >> 2) + 4 * half;
-                out[((size_t)tap * c_in + ci) * C_OUT + nt_mine * 32 + col] = acc[i][r];
+                const int pch = cc + (r & 3) + 8 * (r >> 2) + 4 * half;  // patch channel (accumulator row)
+                const int tch = nt_mine * 32 + col;                      // tile channel (accumulator column)
+                const int ci = a.transpose_out ? tch : pch, co = a.transpose_out ? pch : tch;
+                out[((size_t)tap * a.c_in + ci) * a.c_out + co] = acc[i][r];
             }
         }
     }
@@ -348,35 +364,68 @@ __global__ void reduce_partials_mfma_kernel(const float* partials, int splits, i
     out[i] = s;
 }
 
-int wgrad_splits(const WgradArgs& a) {
-    const int tiles = ((a.w_out + TW - 1) / TW) * ((a.h_out + TH - 1) / TH) * a.n;
-    const int slabs = a.c_in / 32;
-    const int target_blocks = a.c_out == 128 ? 256 : 512;
-    int splits = target_blocks / slabs;
-    if (splits < 1) splits = 1;
-    if (splits > tiles) splits = tiles;
-    return splits;
+struct WgPlan { int stride, ntc, slabs, tiles_x, tiles_y, total, splits; size_t lds; bool cont; };
+
+WgPlan wgrad_plan_mfma(const WgradArgs& a) {
+    WgPlan p{};
+    p.stride = a.stride;
+    p.cont = a.gather == 1;
+    const int th = a.stride == 1 ? 8 : 4;
+    const int lr_h = p.cont ? a.h_in : a.h_out, lr_w = p.cont ? a.w_in : a.w_out;   // the low-res (tile) tensor
+    const int c_tile = p.cont ? a.c_in : a.c_out, c_patch = p.cont ? a.c_out : a.c_in;
+    p.ntc = c_tile / 32;
+    p.slabs = c_patch / 32;
+    p.tiles_x = (lr_w + 31) / 32;
+    p.tiles_y = (lr_h + th - 1) / th;
+    p.total = p.tiles_x * p.tiles_y * a.n;
+    p.lds = (size_t)(a.stride == 1 ? 340 : 594) * 64 + (size_t)p.ntc * th * 32 * 64;
+    const int target = p.lds > 80 * 1024 ? 256 : 512;
+    p.splits = std::max(1, std::min(p.total, target / p.slabs));
+    return p;
 }
 
-template <int NTC>
-void launch_wgrad_s1(const WgradArgs& a, hipStream_t s) {
-    const int tiles_x = (a.w_out + TW - 1) / TW, tiles_y = (a.h_out + TH - 1) / TH;
-    const int total = tiles_x * tiles_y * a.n;
-    const int splits = wgrad_splits(a);
-    const dim3 grid(splits, a.c_in / 32), block(256);
-    const size_t lds = X_BYTES + (size_t)NTC * G_BYTES_PER_NT;
-    auto go = [&](auto kernel) {
-        if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kernel, grid, block, lds, s, a, tiles_x, tiles_y, total, splits);
-    };
-    switch (a.src.kind) {
-        case SRC_RAW: go(wgrad3x3s1_mfma_kernel<NTC, SRC_RAW>); break;
-        case SRC_ACT: go(wgrad3x3s1_mfma_kernel<NTC, SRC_ACT>); break;
-        default: go(wgrad3x3s1_mfma_kernel<NTC, SRC_ACT2>); break;
+template <int NTC, int KP, int KT, int STRIDE>
+void launch_wg(const WgParams& prm, const WgPlan& p, hipStream_t s) {
+    auto kernel = wgrad3x3_mfma_kernel<NTC, KP, KT, STRIDE>;
+    if (p.lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
+    hipLaunchKernelGGL(kernel, dim3(p.splits, p.slabs), dim3(256), p.lds, s, prm, p.tiles_x, p.tiles_y, p.total, p.splits);
+}
+
+template <int NTC, int STRIDE>
+void launch_wg_kinds(const WgParams& prm, const WgPlan& p, int kp, int kt, hipStream_t s) {
+    if (kt == SRC_RAW) {
+        if (kp == SRC_RAW) launch_wg<NTC, SRC_RAW, SRC_RAW, STRIDE>(prm, p, s);
+        else if (kp == SRC_ACT) launch_wg<NTC, SRC_ACT, SRC_RAW, STRIDE>(prm, p, s);
+        else launch_wg<NTC, SRC_ACT2, SRC_RAW, STRIDE>(prm, p, s);
+    } else if (STRIDE == 2) {  // cont: the patch is dy (raw), the tile carries the prologue
+        if (kt == SRC_ACT) launch_wg<NTC, SRC_RAW, SRC_ACT, 2>(prm, p, s);
+        else launch_wg<NTC, SRC_RAW, SRC_ACT2, 2>(prm, p, s);
+    }
+}
+
+void launch_wgrad_any(const WgradArgs& a, hipStream_t s) {
+    const WgPlan p = wgrad_plan_mfma(a);
+    WgSide x{reinterpret_cast<const bf16*>(a.src.a), a.src.a_scale, a.src.a_shift, reinterpret_cast<const bf16*>(a.src.b), a.src.b_scale, a.src.b_shift,
+             a.h_in, a.w_in, a.c_in};
+    WgSide g{reinterpret_cast<const bf16*>(a.dy), nullptr, nullptr, nullptr, nullptr, nullptr, a.h_out, a.w_out, a.c_out};
+    WgParams prm{};
+    prm.patch = p.cont ? g : x;
+    prm.tile = p.cont ? x : g;
+    prm.n = a.n; prm.c_in = a.c_in; prm.c_out = a.c_out; prm.transpose_out = p.cont ? 1 : 0;
+    prm.partials = a.partials;
+    const int kp = p.cont ? SRC_RAW : a.src.kind, kt = p.cont ? a.src.kind : SRC_RAW;
+    if (a.stride == 1) {
+        if (p.ntc == 1) launch_wg_kinds<1, 1>(prm, p, kp, kt, s);
+        else if (p.ntc == 2) launch_wg_kinds<2, 1>(prm, p, kp, kt, s);
+        else launch_wg_kinds<4, 1>(prm, p, kp, kt, s);
+    } else {
+        if (p.ntc == 1) launch_wg_kinds<1, 2>(prm, p, kp, kt, s);
+        else if (p.ntc == 2) launch_wg_kinds<2, 2>(prm, p, kp, kt, s);
+        else launch_wg_kinds<4, 2>(prm, p, kp, kt, s);
     }
     HIP_CHECK(hipGetLastError());
     const int64_t nw = (int64_t)9 * a.c_in * a.c_out;
-    hipLaunchKernelGGL(reduce_partials_mfma_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s, a.partials, splits, nw, a.dw);
+    hipLaunchKernelGGL(reduce_partials_mfma_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s, a.partials, p.splits, nw, a.dw);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -399,21 +448,21 @@ void launch_conv_mfma(const ConvArgs& a, hipStream_t s) {
 }
 
 bool mfma_wgrad_supported(const WgradArgs& a) {
-    if (a.k != 3 || a.stride != 1 || a.pad != 1 || a.gather != 0) return false;
-    if (a.src.kind == SRC_IMAGE || a.src.dtype != DT_BF16 || a.dy_dtype != DT_BF16) return false;
-    if (a.c_in % 32 != 0 || !(a.c_out == 32 || a.c_out == 64 || a.c_out == 128)) return false;
-    return a.h_in == a.h_out && a.w_in == a.w_out;
+    if (a.k != 3 || a.src.kind == SRC_IMAGE || a.src.dtype != DT_BF16 || a.dy_dtype != DT_BF16) return false;
+    const bool s1 = a.stride == 1 && a.pad == 1 && a.gather == 0 && a.h_in == a.h_out && a.w_in == a.w_out;
+    const bool s2 = a.stride == 2 && a.pad == 0;
+    if (!s1 && !s2) return false;
+    const int c_tile = a.gather == 1 ? a.c_in : a.c_out, c_patch = a.gather == 1 ? a.c_out : a.c_in;
+    return c_patch % 32 == 0 && (c_tile == 32 || c_tile == 64 || c_tile == 128);
 }
 
-int64_t wgrad_mfma_scratch_floats(const WgradArgs& a) { return (int64_t)wgrad_splits(a) * 9 * a.c_in * a.c_out; }
+int64_t wgrad_mfma_scratch_floats(const WgradArgs& a) { return (int64_t)wgrad_plan_mfma(a).splits * 9 * a.c_in * a.c_out; }
 
 void launch_wgrad_mfma(const WgradArgs& a, hipStream_t s) {
     if (!mfma_wgrad_supported(a)) fail(ANH_ERR_INTERNAL, "wgrad_mfma: unsupported shape");
     ANH_REQUIRE(wgrad_mfma_scratch_floats(a) <= a.partials_capacity, "wgrad scratch too small");
     if ((int64_t)a.n * a.h_out * a.w_out == 0) return;
-    if (a.c_out == 32) launch_wgrad_s1<1>(a, s);
-    else if (a.c_out == 64) launch_wgrad_s1<2>(a, s);
-    else launch_wgrad_s1<4>(a, s);
+    launch_wgrad_any(a, s);
 }
 
 }  // namespace anh

@@ -158,6 +158,11 @@ def main():
             roof["arithmetic_intensity"] = ai
         total_ms = sum(e["total_ms"] for e in prof_all) or 1.0
         breakdown = sorted(((e["name"], round(100 * e["total_ms"] / total_ms, 1)) for e in prof_all), key=lambda x: -x[1])[:8]
+        if os.environ.get("ANH_BENCH_VERBOSE"):
+            for e in sorted(prof_all, key=lambda e: -e["total_ms"]):
+                per = e["total_ms"] / 2.0
+                print(f"  {e['name']:44s} {per:8.3f} ms/step  {e['launches'] // 2:3d} launches  "
+                      f"{e['flops'] / 2 / per / 1e9 if per else 0:9.1f} TFLOP/s  {e['bytes'] / 2 / per / 1e6 if per else 0:9.1f} GB/s", file=sys.stderr)
         out = {
             "metric": "227x227 RGB tiles/sec fwd+bwd @ batch 32", "value": BATCH * world * args.steps / elapsed, "unit": "tiles/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
