@@ -429,22 +429,246 @@ void launch_wgrad_any(const WgradArgs& a, hipStream_t s) {
     HIP_CHECK(hipGetLastError());
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Stride-2 layers, same machinery as conv3x3s1_mfma (patch slab in LDS as swizzled 64-byte records, weights staged by
+// tap group, A = weights, B = pixels, permlane-swapped 16-byte NHWC stores).
+//   conv3x3_down_mfma  (gather 0: con s2 forward, cont backward-data):  out[o] = sum_t in[2o + t] * W[t]
+//       4x32 output tile; the 9x65 input patch is stored split by column parity so that the lanes of a wave (consecutive
+//       output columns) read consecutive records for every tap.
+//   conv3x3_up_mfma    (gather 1: cont forward, con s2 backward-data):  out[2i + t] += in[i] * W[t]
+//       4x32 tile of LOW-RES positions; the four output parity classes (even/odd row x column) take 4 / 2 / 2 / 1 taps
+//       and each owns an accumulator, so no MFMA multiplies by a structural zero.
+// ---------------------------------------------------------------------------------------------------------------
+template <int C_OUT>
+__device__ __forceinline__ void stage_weights(char* lds_w, const bf16* wsrc, int t0, int ntaps, int c_red, int cc, int tid) {
+    const int c16 = tid & 3;
+    for (int item = tid; item < ntaps * C_OUT * 4; item += 256) {
+        const int rec = item >> 2;
+        const int tl = rec / C_OUT, co = rec - tl * C_OUT;
+        const bf16* src = wsrc + ((size_t)(t0 + tl) * C_OUT + co) * c_red + cc + c16 * 8;
+        *reinterpret_cast<uint4*>(lds_w + rec * 64 + ((c16 ^ ((co >> 2) & 3)) << 4)) = *reinterpret_cast<const uint4*>(src);
+    }
+}
+
+__device__ __forceinline__ uint4 add_bf16x8(const uint4& p, const uint4& q) {
+    return make_uint4(pack2(lo_f(p.x) + lo_f(q.x), hi_f(p.x) + hi_f(q.x)), pack2(lo_f(p.y) + lo_f(q.y), hi_f(p.y) + hi_f(q.y)),
+                      pack2(lo_f(p.z) + lo_f(q.z), hi_f(p.z) + hi_f(q.z)), pack2(lo_f(p.w) + lo_f(q.w), hi_f(p.w) + hi_f(q.w)));
+}
+
+// one 32-channel accumulator tile -> NHWC bf16 (lane = pixel x half; see conv3x3s1_mfma's epilogue)
+template <int C_OUT>
+__device__ __forceinline__ void store_tile32(const f32x16& v, const ConvArgs& a, size_t pix, bool valid, int nt, int half) {
+    bf16* out = reinterpret_cast<bf16*>(a.out);
+    bf16* out2 = reinterpret_cast<bf16*>(a.out2);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        unsigned a0 = pack2(v[8 * s + 0], v[8 * s + 1]), a1 = pack2(v[8 * s + 2], v[8 * s + 3]);
+        unsigned b0 = pack2(v[8 * s + 4], v[8 * s + 5]), b1 = pack2(v[8 * s + 6], v[8 * s + 7]);
+        auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+        auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+        const uint4 q = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+        if (!valid) continue;
+        const size_t o = pix * C_OUT + nt * 32 + 16 * s + 8 * half;
+        *reinterpret_cast<uint4*>(out + o) = a.out_accumulate ? add_bf16x8(*reinterpret_cast<const uint4*>(out + o), q) : q;
+        if (out2) *reinterpret_cast<uint4*>(out2 + o) = a.out2_accumulate ? add_bf16x8(*reinterpret_cast<const uint4*>(out2 + o), q) : q;
+    }
+}
+
+template <int NT, int KIND, int TAPS>
+__global__ __launch_bounds__(256, 2) void conv3x3_down_mfma_kernel(ConvArgs a, WgSide src, int tiles_x, int tiles_y) {
+    constexpr int DTH = 4, RECS = 9 * 66, C_OUT = NT * 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* lds_x = smem;
+    char* lds_w = smem + RECS * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31, c16 = tid & 3;
+    const int tile = blockIdx.x;
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+    const int x0 = tx * 32, y0 = ty * DTH;
+    const bf16* wsrc = reinterpret_cast<const bf16*>(a.w_bf16);
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+
+    for (int cc = 0; cc < a.c_red; cc += 32) {
+        __syncthreads();
+        for (int item = tid; item < RECS * 4; item += 256) {
+            const int rec = item >> 2;
+            const int py = rec / 66, rem = rec - py * 66, par = rem >= 33, pxx = 2 * (rem - 33 * par) + par;
+            const int iy = 2 * y0 + py, ix = 2 * x0 + pxx;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (iy < a.h_in && ix < a.w_in) v = side_chunk<KIND>(src, ((size_t)n * a.h_in + iy) * a.w_in + ix, cc + c16 * 8);
+            *reinterpret_cast<uint4*>(lds_x + rec * 64 + ((c16 ^ ((rec >> 2) & 3)) << 4)) = v;
+        }
+        for (int t0 = 0; t0 < 9; t0 += TAPS) {
+            if (t0 > 0) __syncthreads();
+            stage_weights<C_OUT>(lds_w, wsrc, t0, TAPS, a.c_red, cc, tid);
+            __syncthreads();
+#pragma unroll
+            for (int tl = 0; tl < TAPS; ++tl) {
+                const int tap = t0 + tl;
+                const int ky = tap / 3, kx = tap - ky * 3;
+                const int rec = ((2 * wave + ky) * 2 + (kx & 1)) * 33 + col + (kx >> 1);
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int chunk = (ks << 1) | half;
+                    const bf16x8 xf = *reinterpret_cast<const bf16x8*>(lds_x + rec * 64 + ((chunk ^ ((rec >> 2) & 3)) << 4));
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const int co = nt * 32 + col;
+                        const bf16x8 wf = *reinterpret_cast<const bf16x8*>(lds_w + (tl * C_OUT + co) * 64 + ((chunk ^ ((co >> 2) & 3)) << 4));
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc[nt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    const int oy = y0 + wave, ox = x0 + col;
+    const bool valid = oy < a.h_out && ox < a.w_out;
+    const size_t pix = ((size_t)n * a.h_out + (valid ? oy : 0)) * a.w_out + (valid ? ox : 0);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) store_tile32<C_OUT>(acc[nt], a, pix, valid, nt, half);
+}
+
+template <int NT, int KIND>
+__global__ __launch_bounds__(256, 2) void conv3x3_up_mfma_kernel(ConvArgs a, WgSide src, int tiles_x, int tiles_y) {
+    constexpr int UTH = 4, UPW = 33, RECS = (UTH + 1) * UPW, C_OUT = NT * 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* lds_x = smem;
+    char* lds_w = smem + RECS * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31, c16 = tid & 3;
+    const int tile = blockIdx.x;
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+    const int j0 = tx * 32, i0 = ty * UTH;  // low-res positions; output pixel = (2i + py, 2j + px)
+    const bf16* wsrc = reinterpret_cast<const bf16*>(a.w_bf16);
+
+    f32x16 acc[4][NT];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][nt][r] = 0.f;
+
+    for (int cc = 0; cc < a.c_red; cc += 32) {
+        __syncthreads();
+        for (int item = tid; item < RECS * 4; item += 256) {
+            const int rec = item >> 2;
+            const int py = rec / UPW, pxx = rec - py * UPW;
+            const int iy = i0 - 1 + py, ix = j0 - 1 + pxx;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (iy >= 0 && iy < a.h_in && ix >= 0 && ix < a.w_in) v = side_chunk<KIND>(src, ((size_t)n * a.h_in + iy) * a.w_in + ix, cc + c16 * 8);
+            *reinterpret_cast<uint4*>(lds_x + rec * 64 + ((c16 ^ ((rec >> 2) & 3)) << 4)) = v;
+        }
+        stage_weights<C_OUT>(lds_w, wsrc, 0, 9, a.c_red, cc, tid);
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int chunk = (ks << 1) | half;
+            bf16x8 xf[2][2];  // [a][b]: input (i - a, j - b)
+#pragma unroll
+            for (int ia = 0; ia < 2; ++ia)
+#pragma unroll
+                for (int ib = 0; ib < 2; ++ib) {
+                    const int rec = (wave + 1 - ia) * UPW + col + 1 - ib;
+                    xf[ia][ib] = *reinterpret_cast<const bf16x8*>(lds_x + rec * 64 + ((chunk ^ ((rec >> 2) & 3)) << 4));
+                }
+#pragma unroll
+            for (int py = 0; py < 2; ++py)
+#pragma unroll
+                for (int px = 0; px < 2; ++px)
+#pragma unroll
+                    for (int ia = 0; ia < 2 - py; ++ia)
+#pragma unroll
+                        for (int ib = 0; ib < 2 - px; ++ib) {
+                            const int tap = (py + 2 * ia) * 3 + px + 2 * ib;
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt) {
+                                const int co = nt * 32 + col;
+                                const bf16x8 wf = *reinterpret_cast<const bf16x8*>(lds_w + (tap * C_OUT + co) * 64 + ((chunk ^ ((co >> 2) & 3)) << 4));
+                                acc[py * 2 + px][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf[ia][ib], acc[py * 2 + px][nt], 0, 0, 0);
+                            }
+                        }
+        }
+    }
+#pragma unroll
+    for (int py = 0; py < 2; ++py)
+#pragma unroll
+        for (int px = 0; px < 2; ++px) {
+            const int oy = 2 * (i0 + wave) + py, ox = 2 * (j0 + col) + px;
+            const bool valid = oy < a.h_out && ox < a.w_out;
+            const size_t pix = ((size_t)n * a.h_out + (valid ? oy : 0)) * a.w_out + (valid ? ox : 0);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) store_tile32<C_OUT>(acc[py * 2 + px][nt], a, pix, valid, nt, half);
+        }
+}
+
+WgSide side_of(const ConvArgs& a) {
+    return WgSide{reinterpret_cast<const bf16*>(a.src.a), a.src.a_scale, a.src.a_shift, reinterpret_cast<const bf16*>(a.src.b), a.src.b_scale, a.src.b_shift,
+                  a.h_in, a.w_in, a.c_red};
+}
+
+template <int NT, int TAPS>
+void launch_down(const ConvArgs& a, hipStream_t s) {
+    const int tiles_x = (a.w_out + 31) / 32, tiles_y = (a.h_out + 3) / 4;
+    const dim3 grid((unsigned)(tiles_x * tiles_y * a.n)), block(256);
+    const size_t lds = (size_t)9 * 66 * 64 + (size_t)TAPS * NT * 32 * 64;
+    const WgSide src = side_of(a);
+    switch (a.src.kind) {
+        case SRC_RAW: hipLaunchKernelGGL((conv3x3_down_mfma_kernel<NT, SRC_RAW, TAPS>), grid, block, lds, s, a, src, tiles_x, tiles_y); break;
+        case SRC_ACT: hipLaunchKernelGGL((conv3x3_down_mfma_kernel<NT, SRC_ACT, TAPS>), grid, block, lds, s, a, src, tiles_x, tiles_y); break;
+        default: hipLaunchKernelGGL((conv3x3_down_mfma_kernel<NT, SRC_ACT2, TAPS>), grid, block, lds, s, a, src, tiles_x, tiles_y); break;
+    }
+    HIP_CHECK(hipGetLastError());
+}
+
+template <int NT>
+void launch_up(const ConvArgs& a, hipStream_t s) {
+    const int tiles_x = (a.w_in + 1 + 31) / 32, tiles_y = (a.h_in + 1 + 3) / 4;
+    const dim3 grid((unsigned)(tiles_x * tiles_y * a.n)), block(256);
+    const size_t lds = (size_t)5 * 33 * 64 + (size_t)9 * NT * 32 * 64;
+    const WgSide src = side_of(a);
+    switch (a.src.kind) {
+        case SRC_RAW: hipLaunchKernelGGL((conv3x3_up_mfma_kernel<NT, SRC_RAW>), grid, block, lds, s, a, src, tiles_x, tiles_y); break;
+        case SRC_ACT: hipLaunchKernelGGL((conv3x3_up_mfma_kernel<NT, SRC_ACT>), grid, block, lds, s, a, src, tiles_x, tiles_y); break;
+        default: hipLaunchKernelGGL((conv3x3_up_mfma_kernel<NT, SRC_ACT2>), grid, block, lds, s, a, src, tiles_x, tiles_y); break;
+    }
+    HIP_CHECK(hipGetLastError());
+}
+
 }  // namespace
 
 bool mfma_conv_supported(const ConvArgs& a) {
-    if (a.k != 3 || a.stride != 1 || a.pad != 1) return false;
+    if (a.k != 3 || !a.w_bf16) return false;
     if (a.src.kind == SRC_IMAGE || a.src.dtype != DT_BF16 || a.out_dtype != DT_BF16 || a.out_nchw || a.bias) return false;
-    if (a.c_red % 32 != 0 || !(a.c_out == 32 || a.c_out == 64 || a.c_out == 128)) return false;
-    if (a.h_in != a.h_out || a.w_in != a.w_out || !a.w_bf16) return false;
-    return true;
+    if (a.c_red % 32 != 0) return false;
+    if (a.stride == 1 && a.pad == 1)
+        return (a.c_out == 32 || a.c_out == 64 || a.c_out == 128) && a.h_in == a.h_out && a.w_in == a.w_out;
+    if (a.stride == 2 && a.pad == 0 && a.gather == 0)
+        return (a.c_out == 32 || a.c_out == 64 || a.c_out == 128) && a.h_in >= 3 && a.w_in >= 3 && a.h_out == (a.h_in - 3) / 2 + 1 &&
+               a.w_out == (a.w_in - 3) / 2 + 1;
+    if (a.stride == 2 && a.pad == 0 && a.gather == 1)
+        return (a.c_out == 32 || a.c_out == 64) && a.h_out == 2 * a.h_in + 1 && a.w_out == 2 * a.w_in + 1;
+    return false;
 }
 
 void launch_conv_mfma(const ConvArgs& a, hipStream_t s) {
     if (!mfma_conv_supported(a)) fail(ANH_ERR_INTERNAL, "conv_mfma: unsupported shape");
     if ((int64_t)a.n * a.h_out * a.w_out == 0) return;
-    if (a.c_out == 32) launch_s1<1, 9>(a, s);
-    else if (a.c_out == 64) launch_s1<2, 9>(a, s);
-    else launch_s1<4, 3>(a, s);
+    if (a.stride == 1) {
+        if (a.c_out == 32) launch_s1<1, 9>(a, s);
+        else if (a.c_out == 64) launch_s1<2, 9>(a, s);
+        else launch_s1<4, 3>(a, s);
+    } else if (a.gather == 0) {
+        if (a.c_out == 32) launch_down<1, 9>(a, s);
+        else if (a.c_out == 64) launch_down<2, 9>(a, s);
+        else launch_down<4, 3>(a, s);
+    } else {
+        if (a.c_out == 32) launch_up<1>(a, s);
+        else launch_up<2>(a, s);
+    }
 }
 
 bool mfma_wgrad_supported(const WgradArgs& a) {
