@@ -296,6 +296,79 @@ __global__ void reduce_partials_kernel(const float* partials, int splits, int64_
     out[i] = (float)s;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// wgrad_stem: filter gradient of the 5x5 stem on the u8 image.  dw[tap][ci][co] = sum_p img(p + tap - 2)[ci]/256 * dy[p][co]:
+// only 25*CIN x 32 outputs but a reduction over every pixel, so it is a streaming kernel: one thread owns one (tap, ci) row
+// and 8 output channels; an 8x32 pixel tile (image patch as fp32, dy as fp32) is staged in LDS; workgroups are persistent
+// over a strided set of tiles and write one partial each (fixed-order reduction afterwards).
+// ---------------------------------------------------------------------------------------------------
+constexpr int kStemTH = 8, kStemTW = 32, kStemPH = kStemTH + 4, kStemPW = kStemTW + 4;
+
+template <int CIN, typename TDY>
+__global__ __launch_bounds__(320) void wgrad_stem_kernel(WgradArgs a, int tiles_x, int tiles_y, int total_tiles, int splits) {
+    constexpr int ROWS = 25 * CIN;
+    __shared__ float xs[kStemPH * kStemPW * CIN];
+    __shared__ __attribute__((aligned(16))) float gs[kStemTH * kStemTW * 32];
+    const int tid = threadIdx.x, nthreads = blockDim.x;
+    const int row = tid >> 2, co0 = (tid & 3) * 8;
+    const bool active = row < ROWS;
+    const int tap = row / CIN, ci = row - tap * CIN;
+    const int ky = tap / 5, kx = tap - ky * 5;
+    const TDY* dy = reinterpret_cast<const TDY*>(a.dy);
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+
+    for (int tile = blockIdx.x; tile < total_tiles; tile += splits) {
+        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+        const int x0 = tx * kStemTW, y0 = ty * kStemTH;
+        __syncthreads();
+        for (int i = tid; i < kStemPH * kStemPW * CIN; i += nthreads) {
+            const int c = i % CIN, px = (i / CIN) % kStemPW, py = i / (CIN * kStemPW);
+            const int iy = y0 - 2 + py, ix = x0 - 2 + px;
+            xs[i] = (iy >= 0 && iy < a.h_in && ix >= 0 && ix < a.w_in) ? fetch1<float, SRC_IMAGE>(a.src, n, iy, ix, a.h_in, a.w_in, CIN, c) : 0.f;
+        }
+        for (int i = tid; i < kStemTH * kStemTW * 4; i += nthreads) {
+            const int p = i >> 2, c8 = (i & 3) * 8;
+            const int oy = y0 + (p >> 5), ox = x0 + (p & 31);
+            float v[8];
+            if (oy < a.h_out && ox < a.w_out) load8<TDY>(dy + (((size_t)n * a.h_out + oy) * a.w_out + ox) * 32 + c8, v);
+            else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = 0.f;
+            }
+            store8<float>(gs + p * 32 + c8, v);
+        }
+        __syncthreads();
+        if (active) {
+            for (int py = 0; py < kStemTH; ++py) {
+                const float* xr = xs + ((py + ky) * kStemPW + kx) * CIN + ci;
+                const float* gr = gs + (py * kStemTW) * 32 + co0;
+#pragma unroll 8
+                for (int px = 0; px < kStemTW; ++px) {
+                    const float x = xr[px * CIN];
+                    const float4 g0 = *reinterpret_cast<const float4*>(gr + px * 32), g1 = *reinterpret_cast<const float4*>(gr + px * 32 + 4);
+                    acc[0] = fmaf(x, g0.x, acc[0]); acc[1] = fmaf(x, g0.y, acc[1]); acc[2] = fmaf(x, g0.z, acc[2]); acc[3] = fmaf(x, g0.w, acc[3]);
+                    acc[4] = fmaf(x, g1.x, acc[4]); acc[5] = fmaf(x, g1.y, acc[5]); acc[6] = fmaf(x, g1.z, acc[6]); acc[7] = fmaf(x, g1.w, acc[7]);
+                }
+            }
+        }
+    }
+    if (active) {
+        float* out = a.partials + (size_t)blockIdx.x * ROWS * 32 + (size_t)row * 32 + co0;
+        store8<float>(out, acc);
+    }
+}
+
+bool stem_wgrad_ok(const WgradArgs& a) {
+    return a.src.kind == SRC_IMAGE && a.k == 5 && a.stride == 1 && a.pad == 2 && a.gather == 0 && a.c_out == 32 && (a.c_in == 1 || a.c_in == 3) &&
+           a.h_in == a.h_out && a.w_in == a.w_out;
+}
+int stem_wgrad_splits(const WgradArgs& a) {
+    const int tiles = ((a.w_out + kStemTW - 1) / kStemTW) * ((a.h_out + kStemTH - 1) / kStemTH) * a.n;
+    return std::max(1, std::min(tiles, 1024));
+}
+
 void wgrad_plan(const WgradArgs& a, int& splits, int64_t& pix_per_split, int& n_ci_tiles, int& n_co_tiles) {
     const int64_t total = (int64_t)a.n * a.h_out * a.w_out;
     n_ci_tiles = (a.c_in + 31) / 32;
@@ -321,15 +394,22 @@ void wgrad_generic_dispatch(const WgradArgs& a, dim3 grid, int64_t pps, int nco,
 // ---------------------------------------------------------------------------------------------------
 // batch norm
 // ---------------------------------------------------------------------------------------------------
-constexpr int kBnPixelsPerBlock = 1024;
+// pixels per workgroup: small layers get smaller slabs so that the grid still covers the chip
+inline int bn_pixels_per_block(int64_t pixels) {
+    int64_t ppb = (pixels + 2047) / 2048;  // aim at ~2048 workgroups
+    ppb = (ppb + 63) / 64 * 64;
+    if (ppb < 256) ppb = 256;
+    if (ppb > 4096) ppb = 4096;
+    return (int)ppb;
+}
 
 // block (cx, 256/cx): thread (c, r) walks pixels r, r+rows, ... of this block's slab for channels c, c+cx, ...
 template <typename T>
-__global__ __launch_bounds__(256) void bn_stats_kernel(const T* y, int64_t pixels, int c, double* partials) {
+__global__ __launch_bounds__(256) void bn_stats_kernel(const T* y, int64_t pixels, int c, double* partials, int ppb) {
     extern __shared__ float sh[];  // [rows][2*c]
     const int cx = blockDim.x, rows = blockDim.y;
-    const int64_t p0 = (int64_t)blockIdx.x * kBnPixelsPerBlock;
-    const int64_t p1 = min(pixels, p0 + kBnPixelsPerBlock);
+    const int64_t p0 = (int64_t)blockIdx.x * ppb;
+    const int64_t p1 = min(pixels, p0 + ppb);
     for (int ch = threadIdx.x; ch < c; ch += cx) {
         float s = 0.f, q = 0.f;
         for (int64_t p = p0 + threadIdx.y; p < p1; p += rows) {
@@ -349,12 +429,20 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* y, int64_t pixel
     }
 }
 
-__global__ void bn_finalize_kernel(const double* partials, int blocks, int64_t pixels, int c, const float* gamma, const float* beta,
-                                   float eps, float* mean, float* invstd, float* scale, float* shift, double* var_out) {
-    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ch >= c) return;
+// one wave per channel: lanes stride over the per-workgroup partials, then a shuffle tree (fixed order => deterministic)
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(64) void bn_finalize_kernel(const double* partials, int blocks, int64_t pixels, int c, const float* gamma, const float* beta,
+                                                         float eps, float* mean, float* invstd, float* scale, float* shift, double* var_out) {
+    const int ch = blockIdx.x;
     double s = 0, q = 0;
-    for (int b = 0; b < blocks; ++b) { s += partials[((size_t)b * c + ch) * 2]; q += partials[((size_t)b * c + ch) * 2 + 1]; }
+    for (int b = threadIdx.x; b < blocks; b += 64) { s += partials[((size_t)b * c + ch) * 2]; q += partials[((size_t)b * c + ch) * 2 + 1]; }
+    s = wave_sum(s); q = wave_sum(q);
+    if (threadIdx.x != 0) return;
     const double m = s / (double)pixels;
     double var = q / (double)pixels - m * m;
     if (var < 0) var = 0;
@@ -374,11 +462,11 @@ __global__ void bn_running_kernel(const float* mean, const double* var, float* r
 
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* da, const T* y, int64_t pixels, int c, const float* mean, const float* invstd,
-                                                            const float* scale, const float* shift, double* partials) {
+                                                            const float* scale, const float* shift, double* partials, int ppb) {
     extern __shared__ float sh[];
     const int cx = blockDim.x, rows = blockDim.y;
-    const int64_t p0 = (int64_t)blockIdx.x * kBnPixelsPerBlock;
-    const int64_t p1 = min(pixels, p0 + kBnPixelsPerBlock);
+    const int64_t p0 = (int64_t)blockIdx.x * ppb;
+    const int64_t p1 = min(pixels, p0 + ppb);
     for (int ch = threadIdx.x; ch < c; ch += cx) {
         const float m = mean[ch], is = invstd[ch], sc = scale[ch], sf = shift[ch];
         float sg = 0.f, sb = 0.f;
@@ -402,12 +490,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* da, const T
     }
 }
 
-__global__ void bn_bwd_finalize_kernel(const double* partials, int blocks, int64_t pixels, int c, const float* gamma, const float* invstd,
-                                       float* dgamma, float* dbeta, float* coef) {
-    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ch >= c) return;
+__global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const double* partials, int blocks, int64_t pixels, int c, const float* gamma, const float* invstd,
+                                                             float* dgamma, float* dbeta, float* coef) {
+    const int ch = blockIdx.x;
     double g = 0, b = 0;
-    for (int k = 0; k < blocks; ++k) { g += partials[((size_t)k * c + ch) * 2]; b += partials[((size_t)k * c + ch) * 2 + 1]; }
+    for (int k = threadIdx.x; k < blocks; k += 64) { g += partials[((size_t)k * c + ch) * 2]; b += partials[((size_t)k * c + ch) * 2 + 1]; }
+    g = wave_sum(g); b = wave_sum(b);
+    if (threadIdx.x != 0) return;
     dgamma[ch] = (float)g; dbeta[ch] = (float)b;
     coef[ch] = gamma[ch] * invstd[ch];
     coef[c + ch] = (float)(b / (double)pixels);
@@ -426,6 +515,105 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(T* da, const T* y, in
         da[i] = from_f<T>(coef[ch] * (dz - coef[c + ch] - xhat * coef[2 * c + ch]));
     }
 }
+
+// ---- vectorized batch-norm kernels (C a multiple of 8 that divides 2048): every thread owns one fixed 8-channel group
+// and walks pixels with 16-byte (bf16) / 32-byte (fp32) loads; consecutive threads read consecutive chunks, so a wave
+// streams 1 KiB of contiguous NHWC per instruction.  Partials go out as doubles; the finalize kernels are shared. ----
+template <typename T>
+__global__ __launch_bounds__(256) void bn_stats_vec_kernel(const T* y, int64_t pixels, int c, double* partials, int ppb) {
+    __shared__ float sh[256][17];
+    const int groups = c >> 3, cg = threadIdx.x % groups, lane_px = threadIdx.x / groups, px_step = 256 / groups;
+    const int64_t p0 = (int64_t)blockIdx.x * ppb;
+    const int64_t p1 = min(pixels, p0 + ppb);
+    float s[8], q[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
+#pragma unroll 4
+    for (int64_t p = p0 + lane_px; p < p1; p += px_step) {
+        float v[8];
+        load8<T>(y + (size_t)p * c + cg * 8, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s[j] += v[j]; q[j] = fmaf(v[j], v[j], q[j]); }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sh[threadIdx.x][j] = s[j]; sh[threadIdx.x][8 + j] = q[j]; }
+    __syncthreads();
+    // thread t < 2*c finalises (channel, which) = (t >> 1, t & 1)
+    for (int t = threadIdx.x; t < 2 * c; t += 256) {
+        const int ch = t >> 1, which = t & 1;
+        const int g = ch >> 3, j = ch & 7;
+        double acc = 0;
+        for (int r = 0; r < px_step; ++r) acc += sh[r * groups + g][which * 8 + j];
+        partials[((size_t)blockIdx.x * c + ch) * 2 + which] = acc;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_vec_kernel(const T* da, const T* y, int64_t pixels, int c, const float* mean, const float* invstd,
+                                                                const float* scale, const float* shift, double* partials, int ppb) {
+    __shared__ float sh[256][17];
+    const int groups = c >> 3, cg = threadIdx.x % groups, lane_px = threadIdx.x / groups, px_step = 256 / groups;
+    const int64_t p0 = (int64_t)blockIdx.x * ppb;
+    const int64_t p1 = min(pixels, p0 + ppb);
+    float m[8], is[8], sc[8], sf[8], sg[8], sb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        m[j] = mean[cg * 8 + j]; is[j] = invstd[cg * 8 + j]; sc[j] = scale[cg * 8 + j]; sf[j] = shift[cg * 8 + j];
+        sg[j] = 0.f; sb[j] = 0.f;
+    }
+#pragma unroll 2
+    for (int64_t p = p0 + lane_px; p < p1; p += px_step) {
+        float yv[8], dv[8];
+        load8<T>(y + (size_t)p * c + cg * 8, yv);
+        load8<T>(da + (size_t)p * c + cg * 8, dv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float dz = fmaf(yv[j], sc[j], sf[j]) > 0.f ? dv[j] : 0.f;
+            sg[j] = fmaf(dz, (yv[j] - m[j]) * is[j], sg[j]);
+            sb[j] += dz;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sh[threadIdx.x][j] = sg[j]; sh[threadIdx.x][8 + j] = sb[j]; }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 2 * c; t += 256) {
+        const int ch = t >> 1, which = t & 1;
+        const int g = ch >> 3, j = ch & 7;
+        double acc = 0;
+        for (int r = 0; r < px_step; ++r) acc += sh[r * groups + g][which * 8 + j];
+        partials[((size_t)blockIdx.x * c + ch) * 2 + which] = acc;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(T* da, const T* y, int64_t chunks, int c, const float* mean, const float* invstd,
+                                                               const float* scale, const float* shift, const float* coef) {
+    const int groups = c >> 3;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;  // a multiple of `groups`: a thread keeps its channel group
+    const int64_t first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int cg = (int)(first % groups);
+    float m[8], is[8], sc[8], sf[8], k0[8], k1[8], k2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int ch = cg * 8 + j;
+        m[j] = mean[ch]; is[j] = invstd[ch]; sc[j] = scale[ch]; sf[j] = shift[ch];
+        k0[j] = coef[ch]; k1[j] = coef[c + ch]; k2[j] = coef[2 * c + ch];
+    }
+    for (int64_t i = first; i < chunks; i += stride) {
+        float yv[8], dv[8], r[8];
+        load8<T>(y + (size_t)i * 8, yv);
+        load8<T>(da + (size_t)i * 8, dv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float dz = fmaf(yv[j], sc[j], sf[j]) > 0.f ? dv[j] : 0.f;
+            const float xhat = (yv[j] - m[j]) * is[j];
+            r[j] = k0[j] * (dz - k1[j] - xhat * k2[j]);
+        }
+        store8<T>(da + (size_t)i * 8, r);
+    }
+}
+
+inline bool bn_vec_ok(int c) { return c >= 8 && (c % 8) == 0 && (256 % (c / 8)) == 0; }
 
 // ---------------------------------------------------------------------------------------------------
 // loss_multiclass_log_per_pixel_weighted
@@ -624,12 +812,32 @@ void launch_conv_generic(const ConvArgs& a, hipStream_t s) {
 }
 
 int64_t wgrad_generic_scratch_floats(const WgradArgs& a) {
+    if (stem_wgrad_ok(a)) return (int64_t)stem_wgrad_splits(a) * a.k * a.k * a.c_in * a.c_out;
     int splits, nci, nco; int64_t pps;
     wgrad_plan(a, splits, pps, nci, nco);
     return (int64_t)splits * a.k * a.k * a.c_in * a.c_out;
 }
 
 void launch_wgrad_generic(const WgradArgs& a, hipStream_t s) {
+    if (stem_wgrad_ok(a)) {
+        const int splits = stem_wgrad_splits(a);
+        const int64_t nw = (int64_t)a.k * a.k * a.c_in * a.c_out;
+        ANH_REQUIRE((int64_t)splits * nw <= a.partials_capacity, "wgrad scratch too small");
+        const int tiles_x = (a.w_out + kStemTW - 1) / kStemTW, tiles_y = (a.h_out + kStemTH - 1) / kStemTH;
+        const int total = tiles_x * tiles_y * a.n;
+        const bool bf = a.dy_dtype == DT_BF16;
+        if (a.c_in == 3) {
+            if (bf) hipLaunchKernelGGL((wgrad_stem_kernel<3, bf16>), dim3(splits), dim3(320), 0, s, a, tiles_x, tiles_y, total, splits);
+            else hipLaunchKernelGGL((wgrad_stem_kernel<3, float>), dim3(splits), dim3(320), 0, s, a, tiles_x, tiles_y, total, splits);
+        } else {
+            if (bf) hipLaunchKernelGGL((wgrad_stem_kernel<1, bf16>), dim3(splits), dim3(128), 0, s, a, tiles_x, tiles_y, total, splits);
+            else hipLaunchKernelGGL((wgrad_stem_kernel<1, float>), dim3(splits), dim3(128), 0, s, a, tiles_x, tiles_y, total, splits);
+        }
+        HIP_CHECK(hipGetLastError());
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s, a.partials, splits, nw, a.dw);
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
     int splits, nci, nco; int64_t pps;
     wgrad_plan(a, splits, pps, nci, nco);
     const int64_t nw = (int64_t)a.k * a.k * a.c_in * a.c_out;
@@ -649,7 +857,7 @@ void launch_wgrad_generic(const WgradArgs& a, hipStream_t s) {
     HIP_CHECK(hipGetLastError());
 }
 
-int bn_partial_blocks(int64_t pixels) { return (int)((pixels + kBnPixelsPerBlock - 1) / kBnPixelsPerBlock); }
+int bn_partial_blocks(int64_t pixels) { const int ppb = bn_pixels_per_block(pixels); return (int)((pixels + ppb - 1) / ppb); }
 
 static dim3 bn_block(int c) {
     int cx = 1;
@@ -659,14 +867,19 @@ static dim3 bn_block(int c) {
 
 void launch_bn_forward_stats(const BnFwdArgs& a, hipStream_t s) {
     const int blocks = bn_partial_blocks(a.pixels);
-    const dim3 block = bn_block(a.c);
-    const size_t shmem = (size_t)block.y * a.c * 2 * sizeof(float);
-    if (a.dtype == DT_BF16)
-        hipLaunchKernelGGL(bn_stats_kernel<bf16>, dim3(blocks), block, shmem, s, reinterpret_cast<const bf16*>(a.y), a.pixels, a.c, a.partials);
-    else
-        hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(blocks), block, shmem, s, reinterpret_cast<const float*>(a.y), a.pixels, a.c, a.partials);
+    if (bn_vec_ok(a.c)) {
+        if (a.dtype == DT_BF16) hipLaunchKernelGGL(bn_stats_vec_kernel<bf16>, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const bf16*>(a.y), a.pixels, a.c, a.partials, bn_pixels_per_block(a.pixels));
+        else hipLaunchKernelGGL(bn_stats_vec_kernel<float>, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const float*>(a.y), a.pixels, a.c, a.partials, bn_pixels_per_block(a.pixels));
+    } else {
+        const dim3 block = bn_block(a.c);
+        const size_t shmem = (size_t)block.y * a.c * 2 * sizeof(float);
+        if (a.dtype == DT_BF16)
+            hipLaunchKernelGGL(bn_stats_kernel<bf16>, dim3(blocks), block, shmem, s, reinterpret_cast<const bf16*>(a.y), a.pixels, a.c, a.partials, bn_pixels_per_block(a.pixels));
+        else
+            hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(blocks), block, shmem, s, reinterpret_cast<const float*>(a.y), a.pixels, a.c, a.partials, bn_pixels_per_block(a.pixels));
+    }
     HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((a.c + 63) / 64), dim3(64), 0, s, a.partials, blocks, a.pixels, a.c, a.gamma, a.beta, a.eps,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(a.c), dim3(64), 0, s, a.partials, blocks, a.pixels, a.c, a.gamma, a.beta, a.eps,
                        a.mean, a.invstd, a.scale, a.shift, a.var);
     HIP_CHECK(hipGetLastError());
 }
@@ -679,27 +892,39 @@ void launch_bn_running_update(const float* mean, const double* var, float* runni
 
 void launch_bn_backward(const BnBwdArgs& a, hipStream_t s) {
     const int blocks = bn_partial_blocks(a.pixels);
-    const dim3 block = bn_block(a.c);
-    const size_t shmem = (size_t)block.y * a.c * 2 * sizeof(float);
     const int64_t total = a.pixels * a.c;
-    const int apply_blocks = (int)std::min<int64_t>((total + 255) / 256, 256 * 16);
-    if (a.dtype == DT_BF16) {
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16>, dim3(blocks), block, shmem, s, reinterpret_cast<const bf16*>(a.da),
-                           reinterpret_cast<const bf16*>(a.y), a.pixels, a.c, a.mean, a.invstd, a.scale, a.shift, a.partials);
+    const bool vec = bn_vec_ok(a.c);
+    const bool bf = a.dtype == DT_BF16;
+    if (vec) {
+        if (bf) hipLaunchKernelGGL(bn_bwd_reduce_vec_kernel<bf16>, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const bf16*>(a.da), reinterpret_cast<const bf16*>(a.y),
+                                   a.pixels, a.c, a.mean, a.invstd, a.scale, a.shift, a.partials, bn_pixels_per_block(a.pixels));
+        else hipLaunchKernelGGL(bn_bwd_reduce_vec_kernel<float>, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const float*>(a.da), reinterpret_cast<const float*>(a.y),
+                                a.pixels, a.c, a.mean, a.invstd, a.scale, a.shift, a.partials, bn_pixels_per_block(a.pixels));
     } else {
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(blocks), block, shmem, s, reinterpret_cast<const float*>(a.da),
-                           reinterpret_cast<const float*>(a.y), a.pixels, a.c, a.mean, a.invstd, a.scale, a.shift, a.partials);
+        const dim3 block = bn_block(a.c);
+        const size_t shmem = (size_t)block.y * a.c * 2 * sizeof(float);
+        if (bf) hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16>, dim3(blocks), block, shmem, s, reinterpret_cast<const bf16*>(a.da), reinterpret_cast<const bf16*>(a.y),
+                                   a.pixels, a.c, a.mean, a.invstd, a.scale, a.shift, a.partials, bn_pixels_per_block(a.pixels));
+        else hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(blocks), block, shmem, s, reinterpret_cast<const float*>(a.da), reinterpret_cast<const float*>(a.y),
+                                a.pixels, a.c, a.mean, a.invstd, a.scale, a.shift, a.partials, bn_pixels_per_block(a.pixels));
     }
     HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((a.c + 63) / 64), dim3(64), 0, s, a.partials, blocks, a.pixels, a.c, a.gamma, a.invstd,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(a.c), dim3(64), 0, s, a.partials, blocks, a.pixels, a.c, a.gamma, a.invstd,
                        a.dgamma, a.dbeta, a.coef);
     HIP_CHECK(hipGetLastError());
-    if (a.dtype == DT_BF16) {
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16>, dim3(apply_blocks), dim3(256), 0, s, reinterpret_cast<bf16*>(a.da),
-                           reinterpret_cast<const bf16*>(a.y), total, a.c, a.mean, a.invstd, a.scale, a.shift, a.coef);
+    if (vec) {
+        const int64_t chunks = total / 8;
+        const int apply_blocks = (int)std::min<int64_t>((chunks + 255) / 256, 256 * 8);  // 256 threads: a multiple of every group count
+        if (bf) hipLaunchKernelGGL(bn_bwd_apply_vec_kernel<bf16>, dim3(apply_blocks), dim3(256), 0, s, reinterpret_cast<bf16*>(a.da), reinterpret_cast<const bf16*>(a.y),
+                                   chunks, a.c, a.mean, a.invstd, a.scale, a.shift, a.coef);
+        else hipLaunchKernelGGL(bn_bwd_apply_vec_kernel<float>, dim3(apply_blocks), dim3(256), 0, s, reinterpret_cast<float*>(a.da), reinterpret_cast<const float*>(a.y),
+                                chunks, a.c, a.mean, a.invstd, a.scale, a.shift, a.coef);
     } else {
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(apply_blocks), dim3(256), 0, s, reinterpret_cast<float*>(a.da),
-                           reinterpret_cast<const float*>(a.y), total, a.c, a.mean, a.invstd, a.scale, a.shift, a.coef);
+        const int apply_blocks = (int)std::min<int64_t>((total + 255) / 256, 256 * 16);
+        if (bf) hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16>, dim3(apply_blocks), dim3(256), 0, s, reinterpret_cast<bf16*>(a.da), reinterpret_cast<const bf16*>(a.y),
+                                   total, a.c, a.mean, a.invstd, a.scale, a.shift, a.coef);
+        else hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(apply_blocks), dim3(256), 0, s, reinterpret_cast<float*>(a.da), reinterpret_cast<const float*>(a.y),
+                                total, a.c, a.mean, a.invstd, a.scale, a.shift, a.coef);
     }
     HIP_CHECK(hipGetLastError());
 }
