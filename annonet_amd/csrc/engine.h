@@ -92,6 +92,7 @@ class Engine {
 
   private:
     void plan_dims(int n, int h, int w);
+    bool head_is_fused() const;
     Src layer_source(int li, const Src& image) const;
     void run_conv_forward(int li, const Src& image, bool training_pass, float* d_out_nchw);
     void refresh_compute_weights();

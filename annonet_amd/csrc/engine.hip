@@ -254,7 +254,10 @@ void Engine::plan_dims(int n, int h, int w) {
         const size_t P = (size_t)n * h * w;
         logits.reserve(P * head.cout * 4);
         dlogits.reserve(P * head.cout * 4);
-        loss_partials.reserve((size_t)loss_partial_blocks((int64_t)P) * (head.cout + 1) * sizeof(double));
+        HeadTrainArgs ht;
+        ht.c_in = head.cin; ht.k = head.cout; ht.pixels = (int64_t)P; ht.src.kind = SRC_ACT;
+        const size_t fused_need = head_train_supported(ht) ? (size_t)head_train_partial_doubles(ht) * sizeof(double) : 0;
+        loss_partials.reserve(std::max((size_t)loss_partial_blocks((int64_t)P) * (head.cout + 1) * sizeof(double), fused_need));
         bn_partials.reserve(bn_need);
     }
 }
@@ -331,6 +334,15 @@ void Engine::run_conv_forward(int li, const Src& image, bool training_pass, floa
     }
 }
 
+// training-time tail: 1x1 head + loss + head backward in one kernel when the shape allows it
+bool Engine::head_is_fused() const {
+    const anh_layer_desc& head = spec.layers.back();
+    HeadTrainArgs t;
+    t.src = layer_source((int)spec.layers.size() - 1, Src{});
+    t.c_in = head.cin; t.k = head.cout;
+    return training && head.k == 1 && head.in_a >= 0 && head_train_supported(t);
+}
+
 void Engine::forward_inference(const Src& image, int n, int h, int w, float* d_out_nchw) {
     ANH_REQUIRE(!training, "forward_inference on a training net: take a runtime snapshot first");
     plan_dims(n, h, w);
@@ -340,7 +352,8 @@ void Engine::forward_inference(const Src& image, int n, int h, int w, float* d_o
 void Engine::forward_training(const Src& image, int n, int h, int w) {
     ANH_REQUIRE(training, "not a training net");
     plan_dims(n, h, w);
-    for (size_t li = 0; li < spec.layers.size(); ++li) run_conv_forward((int)li, image, true, nullptr);
+    const size_t n_run = head_is_fused() ? spec.layers.size() - 1 : spec.layers.size();  // the fused tail computes the logits itself
+    for (size_t li = 0; li < n_run; ++li) run_conv_forward((int)li, image, true, nullptr);
     last_image = image; last_n = n; last_h = h; last_w = w;
     have_forward = true;
 }
@@ -354,7 +367,25 @@ void Engine::backward(const uint16_t* d_labels, const float* d_weights, double l
     const anh_layer_desc& head = spec.layers.back();
     const int64_t P = (int64_t)last_n * last_h * last_w;
     const double es = (double)elem_size(dtype);
-    {
+    const bool fused_head = head_is_fused();
+    for (auto& s : ls) s.dact_written = false;
+    if (fused_head) {
+        HeadTrainArgs t;
+        t.src = layer_source(nl - 1, last_image); t.c_in = head.cin; t.k = head.cout;
+        t.w_tm = w_tm_f32.as<float>() + head.w_off; t.w_km = w_km_f32.as<float>() + head.w_off;
+        t.bias = master.as<float>() + head.b_off;
+        t.labels = d_labels; t.weights = d_weights;
+        t.logits = logits.as<float>(); t.da = ls[head.in_a].dact.p;
+        t.pixels = P; t.scale = 1.0 / (loss_scale_n * (double)last_h * (double)last_w);
+        t.partials = loss_partials.as<double>();
+        t.loss_out = loss_dev; t.loss_out_f32 = grad.as<float>() + spec.n_params;
+        t.dbias = grad.as<float>() + head.b_off; t.dw = grad.as<float>() + head.w_off;
+        t.error_flag = error_flag;
+        const int tok = prof.begin(stream, "head_fused_fwd_loss_bwd", 2.0 * 3 * head.cin * head.cout * (double)P, (double)P * (head.cin * es * 2 + head.cout * 4.0 + 6.0));
+        launch_head_train(t, stream);
+        prof.end(stream, tok);
+        ls[head.in_a].dact_written = true;
+    } else {
         LossArgs a;
         a.logits = logits.as<float>(); a.labels = d_labels; a.weights = d_weights; a.dlogits = dlogits.as<float>();
         a.pixels = P; a.k = head.cout;
@@ -367,8 +398,7 @@ void Engine::backward(const uint16_t* d_labels, const float* d_weights, double l
         launch_loss(a, stream);
         prof.end(stream, tok);
     }
-    for (auto& s : ls) s.dact_written = false;
-    for (int li = nl - 1; li >= 0; --li) {
+    for (int li = fused_head ? nl - 2 : nl - 1; li >= 0; --li) {
         const anh_layer_desc& L = spec.layers[li];
         LayerState& s = ls[li];
         const int64_t p_out = (int64_t)s.n * s.h * s.w, p_in = (int64_t)s.n * s.h_in * s.w_in;

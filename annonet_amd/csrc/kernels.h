@@ -142,6 +142,23 @@ void launch_blend(const BlendArgs& a, hipStream_t s);
 void launch_argmax(const float* blended, int k, int64_t pixels, const double* gains_or_null, uint16_t* labels, hipStream_t s);
 
 void launch_fill_zero(void* p, size_t bytes, hipStream_t s);
+void launch_reduce_partials(const float* partials, int splits, int64_t nw, float* out, hipStream_t s);
+
+// training-time tail fused into one pass: 1x1 head forward + weighted softmax log-loss + head backward-data + head
+// filter / bias gradient (32 input channels, up to 4 classes; other shapes take the separate kernels)
+struct HeadTrainArgs {
+    Src src; int c_in = 0;
+    const float* w_tm = nullptr; const float* w_km = nullptr; const float* bias = nullptr;
+    const uint16_t* labels = nullptr; const float* weights = nullptr;
+    float* logits = nullptr; void* da = nullptr;
+    int64_t pixels = 0; int k = 0; double scale = 0;
+    double* partials = nullptr;
+    double* loss_out = nullptr; float* loss_out_f32 = nullptr; float* dbias = nullptr; float* dw = nullptr;
+    int* error_flag = nullptr;
+};
+bool head_train_supported(const HeadTrainArgs& a);
+int64_t head_train_partial_doubles(const HeadTrainArgs& a);
+void launch_head_train(const HeadTrainArgs& a, hipStream_t s);
 
 // kernels_mfma.hip: bf16 MFMA implicit-GEMM kernels; *_supported() says whether a shape is covered
 bool mfma_conv_supported(const ConvArgs& a);

@@ -35,6 +35,12 @@ __device__ __forceinline__ float relu_affine(float y, float s, float t) {
     return z > 0.f ? z : 0.f;
 }
 
+__device__ __forceinline__ double wave_sum(double v) {  // fixed shuffle tree: deterministic
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
 template <typename T> __device__ __forceinline__ void load8(const T* p, float v[8]);
 template <> __device__ __forceinline__ void load8<float>(const float* p, float v[8]) {
     const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
@@ -288,12 +294,21 @@ __global__ __launch_bounds__(256) void wgrad_generic_kernel(WgradArgs a, int64_t
     if (ci + 1 < a.c_in && co + 1 < a.c_out) out[(size_t)(ci + 1) * a.c_out + co + 1] = acc11;
 }
 
-__global__ void reduce_partials_kernel(const float* partials, int splits, int64_t nw, float* out) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nw) return;
+// out[i] = sum over splits of partials[split][i], in a fixed order: block (64 elements) x (16 split groups)
+__global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* partials, int splits, int64_t nw, float* out) {
+    __shared__ double sh[16][65];
+    const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
     double s = 0.0;
-    for (int k = 0; k < splits; ++k) s += (double)partials[(size_t)k * nw + i];
-    out[i] = (float)s;
+    if (i < nw)
+        for (int k = threadIdx.y; k < splits; k += 16) s += (double)partials[(size_t)k * nw + i];
+    sh[threadIdx.y][threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.y == 0 && i < nw) {
+        double t = 0.0;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t += sh[g][threadIdx.x];
+        out[i] = (float)t;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -430,12 +445,6 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* y, int64_t pixel
 }
 
 // one wave per channel: lanes stride over the per-workgroup partials, then a shuffle tree (fixed order => deterministic)
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
-}
-
 __global__ __launch_bounds__(64) void bn_finalize_kernel(const double* partials, int blocks, int64_t pixels, int c, const float* gamma, const float* beta,
                                                          float eps, float* mean, float* invstd, float* scale, float* shift, double* var_out) {
     const int ch = blockIdx.x;
@@ -672,13 +681,143 @@ __global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
     }
 }
 
-__global__ void loss_finalize_kernel(const double* partials, int blocks, int k, double* loss_out, float* loss_out_f32, float* dbias) {
-    const int slot = threadIdx.x;
-    if (slot > k) return;
+// one wave per slot (0 = loss, 1..k = bias gradient)
+__global__ __launch_bounds__(64) void loss_finalize_kernel(const double* partials, int blocks, int k, double* loss_out, float* loss_out_f32, float* dbias) {
+    const int slot = blockIdx.x;
     double s = 0;
-    for (int b = 0; b < blocks; ++b) s += partials[(size_t)b * (k + 1) + slot];
+    for (int b = threadIdx.x; b < blocks; b += 64) s += partials[(size_t)b * (k + 1) + slot];
+    s = wave_sum(s);
+    if (threadIdx.x != 0) return;
     if (slot == 0) { *loss_out = s; if (loss_out_f32) *loss_out_f32 = (float)s; }
     else dbias[slot - 1] = (float)s;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// head_train: the whole tail of a training step in one pass over the last hidden tensor —
+//   logits = relu(bn(y)) . W + b   (1x1 head, fp32, same k-ordered fmaf chain as conv_generic)
+//   weighted per-pixel softmax log-loss and its gradient (as loss_kernel)
+//   dA   = dlogits . W^T            (head backward-data, written in the storage type)
+//   dW  += a (x) dlogits, db += dlogits   (head filter / bias gradient, per-thread registers -> wave tree -> partials)
+// One thread = one pixel at a time (C = 32 channels = one 64-byte record), grid-stride.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kHeadC = 32, kHeadKMax = 4;
+
+struct HeadArgs {
+    Src src;                       // SRC_ACT or SRC_ACT2, 32 channels
+    const float* w_tm;             // [ci][k]   (tap-major with one tap), bf16-rounded values in bf16 mode
+    const float* w_km;             // [k][ci]
+    const float* bias;
+    const uint16_t* labels; const float* weights;
+    float* logits;                 // [P][K] fp32 (kept for inspection)
+    void* da;                      // [P][32] storage type
+    int64_t pixels; int k;
+    double scale;
+    double* partials;              // [blocks][1 + K + 32*K]
+    int* error_flag;
+};
+
+template <typename T, int KIND>
+__global__ __launch_bounds__(256) void head_train_kernel(HeadArgs a) {
+    constexpr int C = kHeadC, KM = kHeadKMax;
+    const int K = a.k;
+    float w[C][KM], wt[KM][C], bias[KM];
+#pragma unroll
+    for (int k = 0; k < KM; ++k) {
+        bias[k] = k < K ? a.bias[k] : 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) { w[c][k] = k < K ? a.w_tm[c * K + k] : 0.f; wt[k][c] = k < K ? a.w_km[k * C + c] : 0.f; }
+    }
+    float dw[C][KM], db[KM];
+#pragma unroll
+    for (int k = 0; k < KM; ++k) {
+        db[k] = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) dw[c][k] = 0.f;
+    }
+    double loss = 0.0;
+    T* da = reinterpret_cast<T*>(a.da);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < a.pixels; p += stride) {
+        float x[C];
+#pragma unroll
+        for (int c8 = 0; c8 < C; c8 += 8) fetch8<T, KIND>(a.src, (size_t)p, C, c8, x + c8);
+        float z[KM];
+#pragma unroll
+        for (int k = 0; k < KM; ++k) z[k] = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+#pragma unroll
+            for (int k = 0; k < KM; ++k) z[k] = fmaf(x[c], w[c][k], z[k]);
+#pragma unroll
+        for (int k = 0; k < KM; ++k) if (k < K) { z[k] = z[k] + bias[k]; a.logits[(size_t)p * K + k] = z[k]; }
+        const uint16_t y = a.labels[p];
+        float g[KM];
+#pragma unroll
+        for (int k = 0; k < KM; ++k) g[k] = 0.f;
+        if (y != ANH_LABEL_IGNORE && y < K) {
+            float m = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < KM; ++k) if (k < K) m = fmaxf(m, z[k]);
+            float e[KM], sum = 0.f;
+#pragma unroll
+            for (int k = 0; k < KM; ++k) if (k < K) { e[k] = expf(z[k] - m); sum += e[k]; }
+            const float sw = (float)a.scale * a.weights[p];
+#pragma unroll
+            for (int k = 0; k < KM; ++k) if (k < K) {
+                const float pk = e[k] / sum;
+                if (k == y) { loss += (double)sw * (double)(-logf(fmaxf(pk, 1e-10f))); g[k] = sw * (pk - 1.f); }
+                else g[k] = sw * pk;
+            }
+        } else if (y != ANH_LABEL_IGNORE && a.error_flag) *a.error_flag = 1;
+        float dx[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < KM; ++k) acc = fmaf(g[k], wt[k][c], acc);
+            dx[c] = acc;
+#pragma unroll
+            for (int k = 0; k < KM; ++k) dw[c][k] = fmaf(x[c], g[k], dw[c][k]);
+        }
+#pragma unroll
+        for (int k = 0; k < KM; ++k) db[k] += g[k];
+#pragma unroll
+        for (int c8 = 0; c8 < C; c8 += 8) store8<T>(da + (size_t)p * C + c8, dx + c8);
+    }
+    // wave tree, then one row of partials per workgroup
+    __shared__ double red[4][1 + KM + C * KM];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    {
+        double v = wave_sum(loss);
+        if (lane == 0) red[wave][0] = v;
+#pragma unroll
+        for (int k = 0; k < KM; ++k) { v = wave_sum((double)db[k]); if (lane == 0) red[wave][1 + k] = v; }
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+#pragma unroll
+            for (int k = 0; k < KM; ++k) { v = wave_sum((double)dw[c][k]); if (lane == 0) red[wave][1 + KM + c * KM + k] = v; }
+    }
+    __syncthreads();
+    const int slots = 1 + K + C * K;
+    for (int sidx = threadIdx.x; sidx < slots; sidx += blockDim.x) {
+        int src;
+        if (sidx <= K) src = sidx;  // loss, db[k]
+        else { const int e = sidx - 1 - K, c = e / K, k = e - c * K; src = 1 + KM + c * KM + k; }
+        a.partials[(size_t)blockIdx.x * slots + sidx] = red[0][src] + red[1][src] + red[2][src] + red[3][src];
+    }
+}
+
+// slot 0 -> loss, 1..K -> dbias, then dW[ci][k]
+__global__ __launch_bounds__(64) void head_finalize_kernel(const double* partials, int blocks, int slots, int k, double* loss_out, float* loss_out_f32,
+                                                           float* dbias, float* dw) {
+    const int slot = blockIdx.x;
+    double s = 0;
+    for (int b = threadIdx.x; b < blocks; b += 64) s += partials[(size_t)b * slots + slot];
+    s = wave_sum(s);
+    if (threadIdx.x != 0) return;
+    if (slot == 0) { *loss_out = s; if (loss_out_f32) *loss_out_f32 = (float)s; }
+    else if (slot <= k) dbias[slot - 1] = (float)s;
+    else dw[slot - 1 - k] = (float)s;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -834,7 +973,7 @@ void launch_wgrad_generic(const WgradArgs& a, hipStream_t s) {
             else hipLaunchKernelGGL((wgrad_stem_kernel<1, float>), dim3(splits), dim3(128), 0, s, a, tiles_x, tiles_y, total, splits);
         }
         HIP_CHECK(hipGetLastError());
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s, a.partials, splits, nw, a.dw);
+        launch_reduce_partials(a.partials, splits, nw, a.dw, s);
         HIP_CHECK(hipGetLastError());
         return;
     }
@@ -853,7 +992,38 @@ void launch_wgrad_generic(const WgradArgs& a, hipStream_t s) {
         else wgrad_generic_dispatch<float, float>(a, grid, pps, nco, s);
     }
     HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s, a.partials, splits, nw, a.dw);
+    launch_reduce_partials(a.partials, splits, nw, a.dw, s);
+    HIP_CHECK(hipGetLastError());
+}
+
+void launch_reduce_partials(const float* partials, int splits, int64_t nw, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((nw + 63) / 64)), dim3(64, 16), 0, s, partials, splits, nw, out);
+    HIP_CHECK(hipGetLastError());
+}
+
+bool head_train_supported(const HeadTrainArgs& a) {
+    return a.c_in == kHeadC && a.k >= 1 && a.k <= kHeadKMax && (a.src.kind == SRC_ACT || a.src.kind == SRC_ACT2);
+}
+int head_train_blocks(int64_t pixels) { return (int)std::max<int64_t>(1, std::min<int64_t>((pixels + 255) / 256, 2048)); }
+int64_t head_train_partial_doubles(const HeadTrainArgs& a) { return (int64_t)head_train_blocks(a.pixels) * (1 + a.k + kHeadC * a.k); }
+
+void launch_head_train(const HeadTrainArgs& t, hipStream_t s) {
+    ANH_REQUIRE(head_train_supported(t), "head_train: unsupported shape");
+    HeadArgs a;
+    a.src = t.src; a.w_tm = t.w_tm; a.w_km = t.w_km; a.bias = t.bias; a.labels = t.labels; a.weights = t.weights;
+    a.logits = t.logits; a.da = t.da; a.pixels = t.pixels; a.k = t.k; a.scale = t.scale; a.partials = t.partials; a.error_flag = t.error_flag;
+    const int blocks = head_train_blocks(t.pixels);
+    const bool bf = t.src.dtype == DT_BF16;
+    if (t.src.kind == SRC_ACT) {
+        if (bf) hipLaunchKernelGGL((head_train_kernel<bf16, SRC_ACT>), dim3(blocks), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((head_train_kernel<float, SRC_ACT>), dim3(blocks), dim3(256), 0, s, a);
+    } else {
+        if (bf) hipLaunchKernelGGL((head_train_kernel<bf16, SRC_ACT2>), dim3(blocks), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((head_train_kernel<float, SRC_ACT2>), dim3(blocks), dim3(256), 0, s, a);
+    }
+    HIP_CHECK(hipGetLastError());
+    const int slots = 1 + t.k + kHeadC * t.k;
+    hipLaunchKernelGGL(head_finalize_kernel, dim3(slots), dim3(64), 0, s, t.partials, blocks, slots, t.k, t.loss_out, t.loss_out_f32, t.dbias, t.dw);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -938,7 +1108,7 @@ void launch_loss(const LossArgs& a, hipStream_t s) {
     else if (a.k <= 8) hipLaunchKernelGGL(loss_kernel<8>, dim3(blocks), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(loss_kernel<64>, dim3(blocks), dim3(256), 0, s, a);
     HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(128), 0, s, a.partials, blocks, a.k, a.loss_out, a.loss_out_f32, a.dbias);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(a.k + 1), dim3(64), 0, s, a.partials, blocks, a.k, a.loss_out, a.loss_out_f32, a.dbias);
     HIP_CHECK(hipGetLastError());
 }
 

@@ -356,14 +356,6 @@ __global__ __launch_bounds__(256, ((STRIDE == 1 && NTC == 4) ? 1 : 2)) void wgra
     }
 }
 
-__global__ void reduce_partials_mfma_kernel(const float* partials, int splits, int64_t nw, float* out) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nw) return;
-    float s = 0.f;
-    for (int k = 0; k < splits; ++k) s += partials[(size_t)k * nw + i];
-    out[i] = s;
-}
-
 struct WgPlan { int stride, ntc, slabs, tiles_x, tiles_y, total, splits; size_t lds; bool cont; };
 
 WgPlan wgrad_plan_mfma(const WgradArgs& a) {
@@ -425,8 +417,7 @@ void launch_wgrad_any(const WgradArgs& a, hipStream_t s) {
     }
     HIP_CHECK(hipGetLastError());
     const int64_t nw = (int64_t)9 * a.c_in * a.c_out;
-    hipLaunchKernelGGL(reduce_partials_mfma_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s, a.partials, p.splits, nw, a.dw);
-    HIP_CHECK(hipGetLastError());
+    launch_reduce_partials(a.partials, p.splits, nw, a.dw, s);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
