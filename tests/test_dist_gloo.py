@@ -1,0 +1,114 @@
+"""The N>1 logic on CPU with world_size-2 gloo (torch.distributed): the data-parallel step is
+    forward_backward(loss scale = GLOBAL batch) -> all-reduce(SUM) of the flat gradient bucket (+ trailing loss slot) -> identical update
+(SURVEY.md §8e).  The compute here is the oracle standing in for a rank's GPU (allowed: tests/ may use the oracle as the
+checker); what is under test is the exchange protocol in annonet_amd/dist.py and its invariants:
+  * every rank ends the step with identical parameters;
+  * the summed bucket equals the gradient of the global-batch loss with per-rank batch-norm statistics (the declared
+    BN policy), computed in one process;
+  * tile sharding covers every tile exactly once, in row-major order."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from annonet_amd import dist as aad
+from conftest import random_params
+from oracle import oracle as orc
+from oracle.oracle import OracleNet
+
+CFG = dict(levels=1, in_ch=3, classes=3, scaler=0.25, min_filters=4)
+
+
+def make_rank_batch(rank, d):
+    rng = np.random.default_rng(100 + rank)
+    img = rng.integers(0, 256, (2, d, d, 3), dtype=np.uint8)
+    lab = rng.integers(0, 3, (2, d, d)).astype(np.uint16)
+    w = np.stack([orc.set_weights(lab[i], 0.5, 0.5) for i in range(2)])
+    return img, lab, w
+
+
+class OracleTrainer:
+    """Duck-types the TrainingNet methods data_parallel_step uses, with the oracle as the compute."""
+
+    def __init__(self):
+        self.net = OracleNet(**CFG)
+        p, r = random_params(self.net, 5)
+        self.net.params[:], self.net.running[:] = p, r
+        self.net.set_hyper(lr=0.05)
+        self.bucket = torch.zeros(self.net.n_params + 1, dtype=torch.float32)
+        self.batch = None
+
+    def forward_backward_device(self, d_images, d_labels, d_weights, n, h, w, loss_scale_n):
+        img, lab, wt = self.batch
+        loss = self.net.train_step(img, lab, wt, loss_scale_n=loss_scale_n, apply_update=False)
+        self.bucket[:-1] = torch.from_numpy(self.net.grads.copy())
+        self.bucket[-1] = loss
+
+    def apply_update(self, grad_scale):
+        g = self.bucket[:-1].numpy() * grad_scale
+        lr, wd, mom = 0.05, 0.0005, 0.9
+        mask = np.zeros(self.net.n_params)
+        for L in self.net.layers:
+            mask[L.w_off:L.w_off + L.k * L.k * L.cin * L.cout] = 1
+        v = mom * self.net.momentum - wd * lr * mask * self.net.params - lr * g
+        self.net.momentum[:] = v
+        self.net.params[:] = self.net.params + v
+
+
+def worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = OracleTrainer()
+    d = t.net.recommended_input_dim(15)
+    t.batch = make_rank_batch(rank, d)
+    aad.data_parallel_step(t, t.bucket, 0, 0, 0, 2, d, d, world)
+    gathered = [torch.zeros_like(torch.from_numpy(t.net.params.copy())) for _ in range(world)]
+    dist.all_gather(gathered, torch.from_numpy(t.net.params.copy()))
+    if rank == 0:
+        out["params"] = [g.numpy() for g in gathered]
+        out["bucket"] = t.bucket.numpy().copy()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_two_rank_data_parallel_step_over_gloo():
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(worker, args=(2, free_port(), out), nprocs=2, join=True)
+    p0, p1 = out["params"]
+    np.testing.assert_array_equal(p0, p1)  # identical update on every rank
+    # single-process statement of the same step: per-rank BN statistics, loss scale = global batch, gradients summed
+    want_g, want_loss = None, 0.0
+    d = OracleNet(**CFG).recommended_input_dim(15)
+    for rank in range(2):
+        net = OracleNet(**CFG)
+        p, r = random_params(net, 5)
+        net.params[:], net.running[:] = p, r
+        img, lab, w = make_rank_batch(rank, d)
+        want_loss += net.train_step(img, lab, w, loss_scale_n=4, apply_update=False)
+        want_g = net.grads.copy() if want_g is None else want_g + net.grads
+    np.testing.assert_allclose(out["bucket"][:-1], want_g, rtol=1e-6, atol=1e-9)
+    assert abs(out["bucket"][-1] - want_loss) < 1e-6
+
+
+def test_tile_sharding_partitions_the_tile_list():
+    tiles = orc.get_tiles(4096, 3000, 1024, 1024, 35, 35)
+    for world in (1, 2, 3, 8, 40):
+        shards = [aad.shard_tiles(tiles, r, world) for r in range(world)]
+        assert sum(shards, []) == tiles
+        assert max(map(len, shards)) - min(map(len, shards)) <= 1
+    a = np.arange(12, dtype=np.float32).reshape(3, 2, 2)
+    np.testing.assert_array_equal(aad.reduce_shard_planes([a, 2 * a]), 3 * a)
