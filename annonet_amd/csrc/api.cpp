@@ -69,10 +69,20 @@ struct anh_trainer {
     std::vector<uint16_t> pack_lab;
     std::vector<float> pack_w;
 
+    bool initialized = false, dirty = false;
+    // The reference configures AFTER Initialize() (annonet_train_main.cpp:400-410: Initialize, SetNetWidth, ..., SetClassCount);
+    // dlib allocates lazily, so the net is (re)built here on first use after a structural setting changed.
     Engine& engine() {
-        if (!eng) fail(ANH_ERR_INVALID, "TrainingNet::Initialize has not been called");
+        if (!initialized) fail(ANH_ERR_INVALID, "TrainingNet::Initialize has not been called");
+        if (!eng || dirty) {
+            if (steps > 0) fail(ANH_ERR_INVALID, "the net structure cannot change once training has started");
+            eng = std::make_unique<Engine>(cfg, true);
+            eng->random_init(seed);
+            dirty = false;
+        }
         return *eng;
     }
+    void structural_change() { if (steps > 0) fail(ANH_ERR_INVALID, "the net structure cannot change once training has started"); dirty = true; }
     void consume(bool wait) {
         while (!pending.empty()) {
             PendingLoss p = pending.front();
@@ -331,32 +341,28 @@ void anh_trainer_destroy(anh_trainer* h) { delete h; }
 #define TRAINER_SETTER(name, body) \
     return guarded([&] { ANH_REQUIRE(h, "null handle"); body; })
 
-static void require_not_built(anh_trainer* h) { ANH_REQUIRE(!h->eng, "the net is already built: set this before Initialize()"); }
-
 int anh_trainer_set_net_width(anh_trainer* h, double scaler, int min_filters) {
     TRAINER_SETTER(net_width, { ANH_REQUIRE(scaler > 0 && min_filters >= 1, "bad net width");
-        if (h->eng) ANH_REQUIRE(scaler == h->cfg.width_scaler && min_filters == h->cfg.min_filters, "SetNetWidth after the net was built must not change it");
+        if (scaler != h->cfg.width_scaler || min_filters != h->cfg.min_filters) h->structural_change();
         h->cfg.width_scaler = scaler; h->cfg.min_filters = min_filters; });
 }
 int anh_trainer_set_class_count(anh_trainer* h, size_t classes) {
     TRAINER_SETTER(class_count, { ANH_REQUIRE(classes >= 1 && classes <= 64, "class count must be 1..64");
-        if (h->eng && (int)classes != h->cfg.classes) {  // dlib sets the output filter count lazily; rebuild with the new head
-            h->cfg.classes = (int)classes;
-            h->eng = std::make_unique<Engine>(h->cfg, true);
-            h->eng->random_init(h->seed);
-        }
+        if ((int)classes != h->cfg.classes) h->structural_change();
         h->cfg.classes = (int)classes; });
 }
-int anh_trainer_set_levels(anh_trainer* h, int levels) { TRAINER_SETTER(levels, { require_not_built(h); ANH_REQUIRE(levels >= 0 && levels <= 3, "level count must be 0..3"); h->cfg.levels = levels; }); }
-int anh_trainer_set_input_channels(anh_trainer* h, int c) { TRAINER_SETTER(channels, { require_not_built(h); ANH_REQUIRE(c == 1 || c == 3, "input channels must be 1 or 3"); h->cfg.in_channels = c; }); }
-int anh_trainer_set_precision(anh_trainer* h, int p) { TRAINER_SETTER(precision, { require_not_built(h); ANH_REQUIRE(p == ANH_FP32 || p == ANH_BF16, "unknown precision"); h->cfg.precision = p; }); }
-int anh_trainer_set_seed(anh_trainer* h, uint64_t seed) { TRAINER_SETTER(seed, { h->seed = seed; if (h->eng) h->eng->random_init(seed); }); }
+int anh_trainer_set_levels(anh_trainer* h, int levels) { TRAINER_SETTER(levels, { ANH_REQUIRE(levels >= 0 && levels <= 3, "level count must be 0..3"); if (levels != h->cfg.levels) h->structural_change(); h->cfg.levels = levels; }); }
+int anh_trainer_set_input_channels(anh_trainer* h, int c) { TRAINER_SETTER(channels, { ANH_REQUIRE(c == 1 || c == 3, "input channels must be 1 or 3"); if (c != h->cfg.in_channels) h->structural_change(); h->cfg.in_channels = c; }); }
+int anh_trainer_set_precision(anh_trainer* h, int p) { TRAINER_SETTER(precision, { ANH_REQUIRE(p == ANH_FP32 || p == ANH_BF16, "unknown precision"); if (p != h->cfg.precision) h->structural_change(); h->cfg.precision = p; }); }
+int anh_trainer_set_seed(anh_trainer* h, uint64_t seed) { TRAINER_SETTER(seed, { if (seed != h->seed) h->structural_change(); h->seed = seed; }); }
 
 int anh_trainer_initialize(anh_trainer* h) {
     return guarded([&] {
         ANH_REQUIRE(h, "null handle");
-        h->eng = std::make_unique<Engine>(h->cfg, true);
-        h->eng->random_init(h->seed);
+        if (anh_device_count() == 0) fail(ANH_ERR_DEVICE, "no MI355X / HIP device visible");
+        (void)Spec::build(h->cfg);  // validates the configuration
+        h->initialized = true;
+        h->dirty = true;
         if (!h->loss_ring) HIP_CHECK(hipHostMalloc((void**)&h->loss_ring, 256 * sizeof(float), hipHostMallocDefault));
     });
 }
@@ -373,7 +379,7 @@ int anh_trainer_set_synchronization_file(anh_trainer* h, const char* path, doubl
         h->sync_path = path; h->sync_seconds = seconds;
         h->last_sync = std::chrono::steady_clock::now();
         std::ifstream probe(path, std::ios::binary);
-        if (probe.good() && h->eng) {  // dlib's trainer resumes from an existing synchronization file
+        if (probe.good() && h->initialized) {  // dlib's trainer resumes from an existing synchronization file
             probe.close();
             const int rc = anh_trainer_load_state(h, path);
             if (rc != ANH_OK) fail(rc, g_error);
