@@ -55,8 +55,109 @@ __device__ __forceinline__ void affine8(const uint4& raw, const float* sc, const
     }
 }
 
+
+// ---- staging helpers shared by every MFMA kernel --------------------------------------------------------------------
+// A "side" is a tensor read through its producer's bn+relu (+ skip add).  Staging a batch of 16-byte chunks is done in
+// two phases: (1) EVERY global load of the batch is issued, unconditionally, from a clamped (always valid) address —
+// a predicated load makes hipcc branch around it and wait vmcnt(0) per element, which serialises the memory round
+// trips; (2) the prologue runs on the values, out-of-range chunks are zeroed, and the chunks go to LDS as 64-byte
+// records whose 16-byte chunk index is XOR-ed with (record >> 2) & 3.
+
+struct WgSide {
+    const bf16* a; const float* a_scale; const float* a_shift;
+    const bf16* b; const float* b_scale; const float* b_shift;
+    int h, w, c;
+};
+
+template <int KIND> struct RawChunk { uint4 a, b; };
+
+template <int KIND>
+__device__ __forceinline__ RawChunk<KIND> side_load(const WgSide& s, size_t pix, int ch) {
+    RawChunk<KIND> r;
+    const size_t off = pix * s.c + ch;
+    r.a = *reinterpret_cast<const uint4*>(s.a + off);
+    if (KIND == SRC_ACT2) r.b = *reinterpret_cast<const uint4*>(s.b + off);
+    return r;
+}
+
+template <int KIND>
+__device__ __forceinline__ uint4 side_convert(const WgSide& s, const RawChunk<KIND>& r, int ch) {
+    if (KIND == SRC_RAW) return r.a;
+    float v[8];
+    affine8(r.a, s.a_scale + ch, s.a_shift + ch, v);
+    if (KIND == SRC_ACT2) {
+        float u[8];
+        affine8(r.b, s.b_scale + ch, s.b_shift + ch, u);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += u[j];
+    }
+    return make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
+}
+
+// Stages ITEMS chunks (= ITEMS/4 records) with 256 threads, at most BATCH chunks per thread in flight.
+// geo(rec, pix, ch0) -> bool: global pixel index (clamped into the tensor) and first channel of record `rec`; returns
+// whether the record lies inside the tensor (otherwise it is zero-filled).
+template <int KIND, int ITEMS, int BATCH, typename Geo>
+__device__ __forceinline__ void stage_side(char* lds, const WgSide& s, int tid, const Geo& geo) {
+    constexpr int N = (ITEMS + 255) / 256;
+    const int c16 = tid & 3;
+#pragma unroll
+    for (int b0 = 0; b0 < N; b0 += BATCH) {
+        RawChunk<KIND> raw[BATCH];
+        int ch[BATCH];
+        unsigned okmask = 0;
+#pragma unroll
+        for (int jj = 0; jj < BATCH; ++jj) {
+            if (b0 + jj < N) {
+                const int item = min(tid + 256 * (b0 + jj), ITEMS - 1);
+                size_t pix; int ch0;
+                const bool ok = geo(item >> 2, pix, ch0);
+                ch[jj] = ch0 + c16 * 8;
+                raw[jj] = side_load<KIND>(s, pix, ch[jj]);
+                okmask |= (ok ? 1u : 0u) << jj;
+            }
+        }
+#pragma unroll
+        for (int jj = 0; jj < BATCH; ++jj) {
+            if (b0 + jj < N) {
+                const int item = tid + 256 * (b0 + jj);
+                const int rec = item >> 2;
+                uint4 v = side_convert<KIND>(s, raw[jj], ch[jj]);
+                if (!((okmask >> jj) & 1u)) v = make_uint4(0u, 0u, 0u, 0u);
+                if (item < ITEMS) *reinterpret_cast<uint4*>(lds + rec * 64 + ((c16 ^ ((rec >> 2) & 3)) << 4)) = v;
+            }
+        }
+    }
+}
+
+// weights of NTAPS taps for one 32-channel slab -> LDS records [tap][co][32 ci]; loads first, then writes
+template <int C_OUT, int NTAPS>
+__device__ __forceinline__ void stage_weights(char* lds_w, const bf16* wsrc, int t0, int c_red, int cc, int tid) {
+    constexpr int ITEMS = NTAPS * C_OUT * 4, WI = (ITEMS + 255) / 256;
+    const int c16 = tid & 3;
+    uint4 r[WI];
+#pragma unroll
+    for (int j = 0; j < WI; ++j) {
+        const int item = min(tid + 256 * j, ITEMS - 1);  // clamped: the load stays unconditional
+        const int rec = item >> 2;
+        const int tl = rec / C_OUT, co = rec - tl * C_OUT;
+        r[j] = *reinterpret_cast<const uint4*>(wsrc + ((size_t)(t0 + tl) * C_OUT + co) * c_red + cc + c16 * 8);
+    }
+#pragma unroll
+    for (int j = 0; j < WI; ++j) {
+        const int item = tid + 256 * j;
+        const int rec = item >> 2;
+        const int co = rec % C_OUT;
+        if (item < ITEMS) *reinterpret_cast<uint4*>(lds_w + rec * 64 + ((c16 ^ ((co >> 2) & 3)) << 4)) = r[j];
+    }
+}
+
+__host__ __device__ inline WgSide side_of_src(const Src& src, int h, int w, int c) {
+    return WgSide{reinterpret_cast<const bf16*>(src.a), src.a_scale, src.a_shift, reinterpret_cast<const bf16*>(src.b), src.b_scale, src.b_shift, h, w, c};
+}
+
 template <int NT, int KIND, int TAPS>
-__global__ __launch_bounds__(256, 2) void conv3x3s1_mfma_kernel(ConvArgs a, int tiles_x, int tiles_y, int flip) {
+__global__ __launch_bounds__(256, (NT == 4 ? 1 : 2)) void conv3x3s1_mfma_kernel(ConvArgs a, int tiles_x, int tiles_y, int flip) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* lds_x = smem;
     char* lds_w = smem + X_BYTES;
@@ -69,8 +170,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3s1_mfma_kernel(ConvArgs a, int 
     const int x0 = tx * TW, y0 = ty * TH;
     const int H = a.h_out, W = a.w_out;  // stride 1, pad 1: input and output planes have the same size
     const int c_red = a.c_red;
-    const bf16* xa = reinterpret_cast<const bf16*>(a.src.a);
-    const bf16* xb = reinterpret_cast<const bf16*>(a.src.b);
     const bf16* wsrc = reinterpret_cast<const bf16*>(a.w_bf16);
 
     f32x16 acc[2][NT];
@@ -81,52 +180,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3s1_mfma_kernel(ConvArgs a, int 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[g][nt][r] = 0.f;
 
-    const int c16 = tid & 3;  // this thread always stages the same 16-byte chunk (8 channels) of a record
+    const WgSide side = side_of_src(a.src, H, W, c_red);
 
     for (int cc = 0; cc < c_red; cc += 32) {
-        float sa[8], ta[8], sb[8], tb[8];
-        if (KIND != SRC_RAW) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { sa[j] = a.src.a_scale[cc + c16 * 8 + j]; ta[j] = a.src.a_shift[cc + c16 * 8 + j]; }
-            if (KIND == SRC_ACT2) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { sb[j] = a.src.b_scale[cc + c16 * 8 + j]; tb[j] = a.src.b_shift[cc + c16 * 8 + j]; }
-            }
-        }
         __syncthreads();  // every wave is done reading the previous slab's patch and weights
         // ---- stage the input patch of this 32-channel slab ----
-        for (int item = tid; item < PATCH_PIX * 4; item += 256) {
-            const int px = item >> 2;
-            const int py = px / PW, pxx = px - py * PW;
+        stage_side<KIND, PATCH_PIX * 4, 6>(lds_x, side, tid, [&](int rec, size_t& pix, int& ch0) {
+            const int py = rec / PW, pxx = rec - py * PW;
             const int iy = y0 - 1 + py, ix = x0 - 1 + pxx;
-            uint4 packed = make_uint4(0u, 0u, 0u, 0u);
-            if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
-                const size_t off = (((size_t)n * H + iy) * W + ix) * c_red + cc + c16 * 8;
-                const uint4 raw = *reinterpret_cast<const uint4*>(xa + off);
-                if (KIND == SRC_RAW) packed = raw;
-                else {
-                    float v[8];
-                    affine8(raw, sa, ta, v);
-                    if (KIND == SRC_ACT2) {
-                        float u[8];
-                        affine8(*reinterpret_cast<const uint4*>(xb + off), sb, tb, u);
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) v[j] += u[j];
-                    }
-                    packed = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
-                }
-            }
-            *reinterpret_cast<uint4*>(lds_x + px * 64 + ((c16 ^ ((px >> 2) & 3)) << 4)) = packed;
-        }
+            pix = ((size_t)n * H + min(max(iy, 0), H - 1)) * W + min(max(ix, 0), W - 1);
+            ch0 = cc;
+            return iy >= 0 && iy < H && ix >= 0 && ix < W;
+        });
         for (int t0 = 0; t0 < 9; t0 += TAPS) {
             if (t0 > 0) __syncthreads();  // the previous tap group's weight reads are done
-            // ---- stage the weights of taps [t0, t0+TAPS) for this slab ----
-            for (int item = tid; item < TAPS * C_OUT * 4; item += 256) {
-                const int rec = item >> 2;
-                const int tl = rec / C_OUT, co = rec - tl * C_OUT;
-                const bf16* src = wsrc + ((size_t)(t0 + tl) * C_OUT + co) * c_red + cc + c16 * 8;
-                *reinterpret_cast<uint4*>(lds_w + rec * 64 + ((c16 ^ ((co >> 2) & 3)) << 4)) = *reinterpret_cast<const uint4*>(src);
-            }
+            stage_weights<C_OUT, TAPS>(lds_w, wsrc, t0, c_red, cc, tid);
             __syncthreads();
             // ---- MFMA over the staged taps ----
 #pragma unroll
@@ -225,11 +293,6 @@ void launch_s1(const ConvArgs& a, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
-struct WgSide {
-    const bf16* a; const float* a_scale; const float* a_shift;
-    const bf16* b; const float* b_scale; const float* b_shift;
-    int h, w, c;
-};
 struct WgParams {
     WgSide patch, tile;
     int n, c_in, c_out, transpose_out;  // transpose_out: patch channels are the OUTPUT channels (cont)
@@ -255,25 +318,8 @@ __device__ __forceinline__ bf16x8 tr_read8(const char* base, int rec_first, int 
     return __builtin_bit_cast(bf16x8, v);
 }
 
-// one 16-byte chunk (8 channels starting at channel ch) of pixel `pix` through the side's prologue
-template <int KIND>
-__device__ __forceinline__ uint4 side_chunk(const WgSide& s, size_t pix, int ch) {
-    const size_t off = pix * s.c + ch;
-    const uint4 raw = *reinterpret_cast<const uint4*>(s.a + off);
-    if (KIND == SRC_RAW) return raw;
-    float v[8];
-    affine8(raw, s.a_scale + ch, s.a_shift + ch, v);
-    if (KIND == SRC_ACT2) {
-        float u[8];
-        affine8(*reinterpret_cast<const uint4*>(s.b + off), s.b_scale + ch, s.b_shift + ch, u);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] += u[j];
-    }
-    return make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
-}
-
 template <int NTC, int KP, int KT, int STRIDE>
-__global__ __launch_bounds__(256, ((STRIDE == 1 && NTC == 4) ? 1 : 2)) void wgrad3x3_mfma_kernel(WgParams a, int tiles_x, int tiles_y, int total_tiles, int splits) {
+__global__ __launch_bounds__(256, (NTC == 4 ? 1 : 2)) void wgrad3x3_mfma_kernel(WgParams a, int tiles_x, int tiles_y, int total_tiles, int splits) {
     using G = WgGeom<STRIDE>;
     constexpr int TH = G::TH, TW = G::TW, TILE_PIX = TH * TW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -284,7 +330,6 @@ __global__ __launch_bounds__(256, ((STRIDE == 1 && NTC == 4) ? 1 : 2)) void wgra
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int slab = blockIdx.y, split = blockIdx.x;
     const int cc = slab * 32;
-    const int c16 = tid & 3;
     const int nt_mine = wave % NTC;
 
     f32x16 acc[TPW];
@@ -297,27 +342,23 @@ __global__ __launch_bounds__(256, ((STRIDE == 1 && NTC == 4) ? 1 : 2)) void wgra
         const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
         const int x0 = tx * TW, y0 = ty * TH;
         __syncthreads();
-        // ---- patch slab ----
-        for (int item = tid; item < G::RECS * 4; item += 256) {
-            const int rec = item >> 2;
+        // ---- patch slab, then the tile ([nt][pixel][32 channels]); pixels outside a tensor contribute zeros ----
+        stage_side<KP, G::RECS * 4, (NTC == 4 ? 3 : 5)>(lds_p, a.patch, tid, [&](int rec, size_t& pix, int& ch0) {
             int py, pxx;
             if (STRIDE == 1) { py = rec / 34; pxx = rec - py * 34; }
             else { py = rec / 66; const int rem = rec - py * 66; const int par = rem >= 33; pxx = 2 * (rem - 33 * par) + par; }
             const int iy = STRIDE * y0 + G::ORIGIN + py, ix = STRIDE * x0 + G::ORIGIN + pxx;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (iy >= 0 && iy < a.patch.h && ix >= 0 && ix < a.patch.w)
-                v = side_chunk<KP>(a.patch, ((size_t)n * a.patch.h + iy) * a.patch.w + ix, cc + c16 * 8);
-            *reinterpret_cast<uint4*>(lds_p + rec * 64 + ((c16 ^ ((rec >> 2) & 3)) << 4)) = v;
-        }
-        // ---- tile: [nt][pixel][32 channels]; pixels outside the tensor contribute zeros ----
-        for (int item = tid; item < TILE_PIX * NTC * 4; item += 256) {
-            const int rec = item >> 2;
+            pix = ((size_t)n * a.patch.h + min(max(iy, 0), a.patch.h - 1)) * a.patch.w + min(max(ix, 0), a.patch.w - 1);
+            ch0 = cc;
+            return iy >= 0 && iy < a.patch.h && ix >= 0 && ix < a.patch.w;
+        });
+        stage_side<KT, TILE_PIX * NTC * 4, 4>(lds_t, a.tile, tid, [&](int rec, size_t& pix, int& ch0) {
             const int nt = rec / TILE_PIX, pt = rec - nt * TILE_PIX;
             const int oy = y0 + pt / TW, ox = x0 + (pt % TW);
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (oy < a.tile.h && ox < a.tile.w) v = side_chunk<KT>(a.tile, ((size_t)n * a.tile.h + oy) * a.tile.w + ox, nt * 32 + c16 * 8);
-            *reinterpret_cast<uint4*>(lds_t + rec * 64 + ((c16 ^ ((pt >> 2) & 3)) << 4)) = v;
-        }
+            pix = ((size_t)n * a.tile.h + min(oy, a.tile.h - 1)) * a.tile.w + min(ox, a.tile.w - 1);
+            ch0 = nt * 32;
+            return oy < a.tile.h && ox < a.tile.w;
+        });
         __syncthreads();
 #pragma unroll 2
         for (int ks = 0; ks < TILE_PIX / 16; ++ks) {
@@ -430,17 +471,6 @@ void launch_wgrad_any(const WgradArgs& a, hipStream_t s) {
 //       4x32 tile of LOW-RES positions; the four output parity classes (even/odd row x column) take 4 / 2 / 2 / 1 taps
 //       and each owns an accumulator, so no MFMA multiplies by a structural zero.
 // ---------------------------------------------------------------------------------------------------------------
-template <int C_OUT>
-__device__ __forceinline__ void stage_weights(char* lds_w, const bf16* wsrc, int t0, int ntaps, int c_red, int cc, int tid) {
-    const int c16 = tid & 3;
-    for (int item = tid; item < ntaps * C_OUT * 4; item += 256) {
-        const int rec = item >> 2;
-        const int tl = rec / C_OUT, co = rec - tl * C_OUT;
-        const bf16* src = wsrc + ((size_t)(t0 + tl) * C_OUT + co) * c_red + cc + c16 * 8;
-        *reinterpret_cast<uint4*>(lds_w + rec * 64 + ((c16 ^ ((co >> 2) & 3)) << 4)) = *reinterpret_cast<const uint4*>(src);
-    }
-}
-
 __device__ __forceinline__ uint4 add_bf16x8(const uint4& p, const uint4& q) {
     return make_uint4(pack2(lo_f(p.x) + lo_f(q.x), hi_f(p.x) + hi_f(q.x)), pack2(lo_f(p.y) + lo_f(q.y), hi_f(p.y) + hi_f(q.y)),
                       pack2(lo_f(p.z) + lo_f(q.z), hi_f(p.z) + hi_f(q.z)), pack2(lo_f(p.w) + lo_f(q.w), hi_f(p.w) + hi_f(q.w)));
@@ -471,7 +501,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_down_mfma_kernel(ConvArgs a, W
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* lds_x = smem;
     char* lds_w = smem + RECS * 64;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31, c16 = tid & 3;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
     const int tile = blockIdx.x;
     const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
     const int x0 = tx * 32, y0 = ty * DTH;
@@ -485,17 +515,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_down_mfma_kernel(ConvArgs a, W
 
     for (int cc = 0; cc < a.c_red; cc += 32) {
         __syncthreads();
-        for (int item = tid; item < RECS * 4; item += 256) {
-            const int rec = item >> 2;
+        stage_side<KIND, RECS * 4, 5>(lds_x, src, tid, [&](int rec, size_t& pix, int& ch0) {
             const int py = rec / 66, rem = rec - py * 66, par = rem >= 33, pxx = 2 * (rem - 33 * par) + par;
             const int iy = 2 * y0 + py, ix = 2 * x0 + pxx;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (iy < a.h_in && ix < a.w_in) v = side_chunk<KIND>(src, ((size_t)n * a.h_in + iy) * a.w_in + ix, cc + c16 * 8);
-            *reinterpret_cast<uint4*>(lds_x + rec * 64 + ((c16 ^ ((rec >> 2) & 3)) << 4)) = v;
-        }
+            pix = ((size_t)n * a.h_in + min(iy, a.h_in - 1)) * a.w_in + min(ix, a.w_in - 1);
+            ch0 = cc;
+            return iy < a.h_in && ix < a.w_in;
+        });
         for (int t0 = 0; t0 < 9; t0 += TAPS) {
             if (t0 > 0) __syncthreads();
-            stage_weights<C_OUT>(lds_w, wsrc, t0, TAPS, a.c_red, cc, tid);
+            stage_weights<C_OUT, TAPS>(lds_w, wsrc, t0, a.c_red, cc, tid);
             __syncthreads();
 #pragma unroll
             for (int tl = 0; tl < TAPS; ++tl) {
@@ -529,7 +558,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_up_mfma_kernel(ConvArgs a, WgS
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* lds_x = smem;
     char* lds_w = smem + RECS * 64;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31, c16 = tid & 3;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
     const int tile = blockIdx.x;
     const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
     const int j0 = tx * 32, i0 = ty * UTH;  // low-res positions; output pixel = (2i + py, 2j + px)
@@ -545,15 +574,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_up_mfma_kernel(ConvArgs a, WgS
 
     for (int cc = 0; cc < a.c_red; cc += 32) {
         __syncthreads();
-        for (int item = tid; item < RECS * 4; item += 256) {
-            const int rec = item >> 2;
+        stage_side<KIND, RECS * 4, 3>(lds_x, src, tid, [&](int rec, size_t& pix, int& ch0) {
             const int py = rec / UPW, pxx = rec - py * UPW;
             const int iy = i0 - 1 + py, ix = j0 - 1 + pxx;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (iy >= 0 && iy < a.h_in && ix >= 0 && ix < a.w_in) v = side_chunk<KIND>(src, ((size_t)n * a.h_in + iy) * a.w_in + ix, cc + c16 * 8);
-            *reinterpret_cast<uint4*>(lds_x + rec * 64 + ((c16 ^ ((rec >> 2) & 3)) << 4)) = v;
-        }
-        stage_weights<C_OUT>(lds_w, wsrc, 0, 9, a.c_red, cc, tid);
+            pix = ((size_t)n * a.h_in + min(max(iy, 0), a.h_in - 1)) * a.w_in + min(max(ix, 0), a.w_in - 1);
+            ch0 = cc;
+            return iy >= 0 && iy < a.h_in && ix >= 0 && ix < a.w_in;
+        });
+        stage_weights<C_OUT, 9>(lds_w, wsrc, 0, a.c_red, cc, tid);
         __syncthreads();
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -596,10 +624,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_up_mfma_kernel(ConvArgs a, WgS
         }
 }
 
-WgSide side_of(const ConvArgs& a) {
-    return WgSide{reinterpret_cast<const bf16*>(a.src.a), a.src.a_scale, a.src.a_shift, reinterpret_cast<const bf16*>(a.src.b), a.src.b_scale, a.src.b_shift,
-                  a.h_in, a.w_in, a.c_red};
-}
+WgSide side_of(const ConvArgs& a) { return side_of_src(a.src, a.h_in, a.w_in, a.c_red); }
 
 template <int NT, int TAPS>
 void launch_down(const ConvArgs& a, hipStream_t s) {
