@@ -56,6 +56,59 @@ __device__ __forceinline__ void affine8(const uint4& raw, const float* sc, const
 }
 
 
+__device__ __forceinline__ uint4 add_bf16x8(const uint4& p, const uint4& q) {
+    return make_uint4(pack2(lo_f(p.x) + lo_f(q.x), hi_f(p.x) + hi_f(q.x)), pack2(lo_f(p.y) + lo_f(q.y), hi_f(p.y) + hi_f(q.y)),
+                      pack2(lo_f(p.z) + lo_f(q.z), hi_f(p.z) + hi_f(q.z)), pack2(lo_f(p.w) + lo_f(q.w), hi_f(p.w) + hi_f(q.w)));
+}
+
+// NT 32-channel accumulator tiles of one pixel per lane -> NHWC bf16.  Lane = pixel x half; registers 4q..4q+3 of a tile
+// hold channels 8q + 4*half + 0..3, so two v_permlane32_swap per 16 channels leave 8 consecutive channels (16 bytes) in
+// every lane.  With "accumulate" the old values are fetched by one batch of unconditional loads (pix is clamped by the
+// caller) before any add/store, instead of a load -> wait -> store chain per 16 bytes.
+template <int NT>
+__device__ __forceinline__ void store_pixel_tiles(const f32x16 (&acc)[NT], const ConvArgs& a, size_t pix, bool valid, int half) {
+    constexpr int C_OUT = NT * 32;
+    uint4 q[NT][2];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const f32x16& v = acc[nt];
+            unsigned a0 = pack2(v[8 * s + 0], v[8 * s + 1]), a1 = pack2(v[8 * s + 2], v[8 * s + 3]);
+            unsigned b0 = pack2(v[8 * s + 4], v[8 * s + 5]), b1 = pack2(v[8 * s + 6], v[8 * s + 7]);
+            auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+            auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+            q[nt][s] = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+        }
+    bf16* outs[2] = {reinterpret_cast<bf16*>(a.out), reinterpret_cast<bf16*>(a.out2)};
+    const int accumulate[2] = {a.out_accumulate, a.out2_accumulate};
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        bf16* out = outs[d];
+        if (!out) continue;
+        const size_t base = pix * C_OUT + 8 * half;
+        if (accumulate[d]) {
+            uint4 old[NT][2];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) old[nt][s] = *reinterpret_cast<const uint4*>(out + base + nt * 32 + 16 * s);
+            if (valid) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) *reinterpret_cast<uint4*>(out + base + nt * 32 + 16 * s) = add_bf16x8(old[nt][s], q[nt][s]);
+            }
+        } else if (valid) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) *reinterpret_cast<uint4*>(out + base + nt * 32 + 16 * s) = q[nt][s];
+        }
+    }
+}
+
+
 // ---- staging helpers shared by every MFMA kernel --------------------------------------------------------------------
 // A "side" is a tensor read through its producer's bn+relu (+ skip add).  Staging a batch of 16-byte chunks is done in
 // two phases: (1) EVERY global load of the batch is issued, unconditionally, from a clamped (always valid) address —
@@ -196,7 +249,7 @@ __global__ __launch_bounds__(256, (NT == 4 ? 1 : 2)) void conv3x3s1_mfma_kernel(
             if (t0 > 0) __syncthreads();  // the previous tap group's weight reads are done
             stage_weights<C_OUT, TAPS>(lds_w, wsrc, t0, c_red, cc, tid);
             __syncthreads();
-            // ---- MFMA over the staged taps ----
+            // ---- MFMA over the staged taps (2 waves per SIMD: the partner wave covers the LDS read latency) ----
 #pragma unroll
             for (int tl = 0; tl < TAPS; ++tl) {
                 const int tap = t0 + tl;
@@ -223,43 +276,13 @@ __global__ __launch_bounds__(256, (NT == 4 ? 1 : 2)) void conv3x3s1_mfma_kernel(
         }
     }
 
-    // ---- epilogue: lane = pixel (col) x half; registers 4q..4q+3 = channels 8q+4*half+0..3 of the 32-channel tile ----
-    bf16* out = reinterpret_cast<bf16*>(a.out);
-    bf16* out2 = reinterpret_cast<bf16*>(a.out2);
+    // ---- epilogue ----
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         const int oy = y0 + wave * 2 + g, ox = x0 + col;
         const bool valid = oy < H && ox < W;
         const size_t pix = ((size_t)n * H + (valid ? oy : 0)) * W + (valid ? ox : 0);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const f32x16& v = acc[g][nt];
-                unsigned a0 = pack2(v[8 * s + 0], v[8 * s + 1]), a1 = pack2(v[8 * s + 2], v[8 * s + 3]);
-                unsigned b0 = pack2(v[8 * s + 4], v[8 * s + 5]), b1 = pack2(v[8 * s + 6], v[8 * s + 7]);
-                // lanes 32-63 of a* swap with lanes 0-31 of b*: afterwards every lane holds 8 consecutive channels
-                auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
-                auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
-                uint4 q = make_uint4(r0[0], r1[0], r0[1], r1[1]);
-                if (!valid) continue;
-                const size_t o = pix * C_OUT + nt * 32 + 16 * s + 8 * half;
-                if (a.out_accumulate) {
-                    const uint4 old = *reinterpret_cast<const uint4*>(out + o);
-                    const uint4 sum = make_uint4(pack2(lo_f(old.x) + lo_f(q.x), hi_f(old.x) + hi_f(q.x)), pack2(lo_f(old.y) + lo_f(q.y), hi_f(old.y) + hi_f(q.y)),
-                                                 pack2(lo_f(old.z) + lo_f(q.z), hi_f(old.z) + hi_f(q.z)), pack2(lo_f(old.w) + lo_f(q.w), hi_f(old.w) + hi_f(q.w)));
-                    *reinterpret_cast<uint4*>(out + o) = sum;
-                } else *reinterpret_cast<uint4*>(out + o) = q;
-                if (out2) {
-                    if (a.out2_accumulate) {
-                        const uint4 old = *reinterpret_cast<const uint4*>(out2 + o);
-                        const uint4 sum = make_uint4(pack2(lo_f(old.x) + lo_f(q.x), hi_f(old.x) + hi_f(q.x)), pack2(lo_f(old.y) + lo_f(q.y), hi_f(old.y) + hi_f(q.y)),
-                                                     pack2(lo_f(old.z) + lo_f(q.z), hi_f(old.z) + hi_f(q.z)), pack2(lo_f(old.w) + lo_f(q.w), hi_f(old.w) + hi_f(q.w)));
-                        *reinterpret_cast<uint4*>(out2 + o) = sum;
-                    } else *reinterpret_cast<uint4*>(out2 + o) = q;
-                }
-            }
-        }
+        store_pixel_tiles<NT>(acc[g], a, pix, valid, half);
     }
 }
 
@@ -471,30 +494,6 @@ void launch_wgrad_any(const WgradArgs& a, hipStream_t s) {
 //       4x32 tile of LOW-RES positions; the four output parity classes (even/odd row x column) take 4 / 2 / 2 / 1 taps
 //       and each owns an accumulator, so no MFMA multiplies by a structural zero.
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint4 add_bf16x8(const uint4& p, const uint4& q) {
-    return make_uint4(pack2(lo_f(p.x) + lo_f(q.x), hi_f(p.x) + hi_f(q.x)), pack2(lo_f(p.y) + lo_f(q.y), hi_f(p.y) + hi_f(q.y)),
-                      pack2(lo_f(p.z) + lo_f(q.z), hi_f(p.z) + hi_f(q.z)), pack2(lo_f(p.w) + lo_f(q.w), hi_f(p.w) + hi_f(q.w)));
-}
-
-// one 32-channel accumulator tile -> NHWC bf16 (lane = pixel x half; see conv3x3s1_mfma's epilogue)
-template <int C_OUT>
-__device__ __forceinline__ void store_tile32(const f32x16& v, const ConvArgs& a, size_t pix, bool valid, int nt, int half) {
-    bf16* out = reinterpret_cast<bf16*>(a.out);
-    bf16* out2 = reinterpret_cast<bf16*>(a.out2);
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        unsigned a0 = pack2(v[8 * s + 0], v[8 * s + 1]), a1 = pack2(v[8 * s + 2], v[8 * s + 3]);
-        unsigned b0 = pack2(v[8 * s + 4], v[8 * s + 5]), b1 = pack2(v[8 * s + 6], v[8 * s + 7]);
-        auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
-        auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
-        const uint4 q = make_uint4(r0[0], r1[0], r0[1], r1[1]);
-        if (!valid) continue;
-        const size_t o = pix * C_OUT + nt * 32 + 16 * s + 8 * half;
-        *reinterpret_cast<uint4*>(out + o) = a.out_accumulate ? add_bf16x8(*reinterpret_cast<const uint4*>(out + o), q) : q;
-        if (out2) *reinterpret_cast<uint4*>(out2 + o) = a.out2_accumulate ? add_bf16x8(*reinterpret_cast<const uint4*>(out2 + o), q) : q;
-    }
-}
-
 template <int NT, int KIND, int TAPS>
 __global__ __launch_bounds__(256, 2) void conv3x3_down_mfma_kernel(ConvArgs a, WgSide src, int tiles_x, int tiles_y) {
     constexpr int DTH = 4, RECS = 9 * 66, C_OUT = NT * 32;
@@ -548,8 +547,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_down_mfma_kernel(ConvArgs a, W
     const int oy = y0 + wave, ox = x0 + col;
     const bool valid = oy < a.h_out && ox < a.w_out;
     const size_t pix = ((size_t)n * a.h_out + (valid ? oy : 0)) * a.w_out + (valid ? ox : 0);
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) store_tile32<C_OUT>(acc[nt], a, pix, valid, nt, half);
+    store_pixel_tiles<NT>(acc, a, pix, valid, half);
 }
 
 template <int NT, int KIND>
@@ -619,8 +617,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_up_mfma_kernel(ConvArgs a, WgS
             const int oy = 2 * (i0 + wave) + py, ox = 2 * (j0 + col) + px;
             const bool valid = oy < a.h_out && ox < a.w_out;
             const size_t pix = ((size_t)n * a.h_out + (valid ? oy : 0)) * a.w_out + (valid ? ox : 0);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) store_tile32<C_OUT>(acc[py * 2 + px][nt], a, pix, valid, nt, half);
+            store_pixel_tiles<NT>(acc[py * 2 + px], a, pix, valid, half);
         }
 }
 
