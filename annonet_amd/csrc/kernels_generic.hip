@@ -237,6 +237,59 @@ void conv_generic_dispatch(const ConvArgs& a, dim3 grid, dim3 block, hipStream_t
 }
 
 // ---------------------------------------------------------------------------------------------------
+// stem_forward: the 5x5 stem on the u8 image (CIN = 1 or 3 -> 32 channels).  One thread = one output pixel x 32
+// channels; the (8+4)x(32+4) image patch (already /256, clamp-to-edge window, zero padding) and the 25*CIN x 32 filter
+// block live in LDS, filter rows are read as wave-wide broadcasts.  Same k-ordered fmaf chain as conv_generic / the
+// oracle (taps row-major, input channel innermost), so the fp32 mode stays bit-exact.
+// ---------------------------------------------------------------------------------------------------
+template <int CIN, typename TOUT>
+__global__ __launch_bounds__(256) void stem_forward_kernel(ConvArgs a, int tiles_x, int tiles_y) {
+    constexpr int PH = 12, PW = 36, ROWS = 25 * CIN;
+    __shared__ float xs[PH * PW * CIN];
+    __shared__ __attribute__((aligned(16))) float ws[ROWS * 32];
+    const int tid = threadIdx.x;
+    const int tile = blockIdx.x;
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+    const int x0 = tx * 32, y0 = ty * 8;
+    for (int i = tid; i < ROWS * 32; i += 256) ws[i] = a.w_f32[i];
+    for (int i = tid; i < PH * PW * CIN; i += 256) {
+        const int c = i % CIN, px = (i / CIN) % PW, py = i / (CIN * PW);
+        const int iy = y0 - 2 + py, ix = x0 - 2 + px;
+        xs[i] = (iy >= 0 && iy < a.h_in && ix >= 0 && ix < a.w_in) ? fetch1<float, SRC_IMAGE>(a.src, n, iy, ix, a.h_in, a.w_in, CIN, c) : 0.f;
+    }
+    __syncthreads();
+    const int py = tid >> 5, px = tid & 31;
+    float acc[32];
+#pragma unroll
+    for (int o = 0; o < 32; ++o) acc[o] = 0.f;
+    for (int ky = 0; ky < 5; ++ky)
+        for (int kx = 0; kx < 5; ++kx) {
+            const float* xp = xs + ((py + ky) * PW + px + kx) * CIN;
+            const float* wp = ws + (ky * 5 + kx) * CIN * 32;
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) {
+                const float x = xp[ci];
+#pragma unroll
+                for (int o4 = 0; o4 < 8; ++o4) {
+                    const float4 w = *reinterpret_cast<const float4*>(wp + ci * 32 + o4 * 4);
+                    acc[o4 * 4 + 0] = fmaf(x, w.x, acc[o4 * 4 + 0]); acc[o4 * 4 + 1] = fmaf(x, w.y, acc[o4 * 4 + 1]);
+                    acc[o4 * 4 + 2] = fmaf(x, w.z, acc[o4 * 4 + 2]); acc[o4 * 4 + 3] = fmaf(x, w.w, acc[o4 * 4 + 3]);
+                }
+            }
+        }
+    const int oy = y0 + py, ox = x0 + px;
+    if (oy >= a.h_out || ox >= a.w_out) return;
+    TOUT* out = reinterpret_cast<TOUT*>(a.out) + (((size_t)n * a.h_out + oy) * a.w_out + ox) * 32;
+#pragma unroll
+    for (int o8 = 0; o8 < 32; o8 += 8) store8<TOUT>(out + o8, acc + o8);
+}
+
+bool stem_forward_ok(const ConvArgs& a) {
+    return a.src.kind == SRC_IMAGE && a.k == 5 && a.stride == 1 && a.pad == 2 && a.gather == 0 && a.c_out == 32 && (a.c_red == 1 || a.c_red == 3) &&
+           a.h_in == a.h_out && a.w_in == a.w_out && !a.bias && !a.out_nchw && !a.out_accumulate && !a.out2;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // wgrad_generic: grid = (pixel split, tap, 32x32 (ci,co) tile); 256 threads, 2x2 outputs each; pixel chunks of 32
 // staged in LDS; per-split partials, reduced in a fixed order (deterministic).
 // ---------------------------------------------------------------------------------------------------
@@ -716,40 +769,64 @@ struct HeadArgs {
     int* error_flag;
 };
 
+// Four lanes share a pixel: lane `sub` owns channels 8*sub..8*sub+7 (one 16-byte chunk), so a wave reads / writes 1 KiB
+// of contiguous NHWC per instruction; the K partial logits are combined with two xor-shuffles.
 template <typename T, int KIND>
 __global__ __launch_bounds__(256) void head_train_kernel(HeadArgs a) {
     constexpr int C = kHeadC, KM = kHeadKMax;
     const int K = a.k;
-    float w[C][KM], wt[KM][C], bias[KM];
+    const int sub = threadIdx.x & 3, c0 = sub * 8;
+    float w[8][KM], wt[KM][8], bias[KM], sa[8], ta[8], sb[8], tb[8];
 #pragma unroll
     for (int k = 0; k < KM; ++k) {
         bias[k] = k < K ? a.bias[k] : 0.f;
 #pragma unroll
-        for (int c = 0; c < C; ++c) { w[c][k] = k < K ? a.w_tm[c * K + k] : 0.f; wt[k][c] = k < K ? a.w_km[k * C + c] : 0.f; }
+        for (int c = 0; c < 8; ++c) { w[c][k] = k < K ? a.w_tm[(c0 + c) * K + k] : 0.f; wt[k][c] = k < K ? a.w_km[k * C + c0 + c] : 0.f; }
     }
-    float dw[C][KM], db[KM];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        sa[c] = a.src.a_scale[c0 + c]; ta[c] = a.src.a_shift[c0 + c];
+        sb[c] = KIND == SRC_ACT2 ? a.src.b_scale[c0 + c] : 0.f; tb[c] = KIND == SRC_ACT2 ? a.src.b_shift[c0 + c] : 0.f;
+    }
+    float dw[8][KM], db[KM];
 #pragma unroll
     for (int k = 0; k < KM; ++k) {
         db[k] = 0.f;
 #pragma unroll
-        for (int c = 0; c < C; ++c) dw[c][k] = 0.f;
+        for (int c = 0; c < 8; ++c) dw[c][k] = 0.f;
     }
-    double loss = 0.0;
+    float loss = 0.f;
+    const T* xa = reinterpret_cast<const T*>(a.src.a);
+    const T* xb = reinterpret_cast<const T*>(a.src.b);
     T* da = reinterpret_cast<T*>(a.da);
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < a.pixels; p += stride) {
-        float x[C];
+    const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 2;
+    for (int64_t p = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2; p < a.pixels; p += stride) {
+        float x[8];
+        load8<T>(xa + (size_t)p * C + c0, x);
 #pragma unroll
-        for (int c8 = 0; c8 < C; c8 += 8) fetch8<T, KIND>(a.src, (size_t)p, C, c8, x + c8);
+        for (int c = 0; c < 8; ++c) x[c] = relu_affine(x[c], sa[c], ta[c]);
+        if (KIND == SRC_ACT2) {
+            float u[8];
+            load8<T>(xb + (size_t)p * C + c0, u);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) x[c] += relu_affine(u[c], sb[c], tb[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) x[c] = operand_round<T>(x[c]);
         float z[KM];
 #pragma unroll
-        for (int k = 0; k < KM; ++k) z[k] = 0.f;
+        for (int k = 0; k < KM; ++k) {
+            float acc = 0.f;
 #pragma unroll
-        for (int c = 0; c < C; ++c)
+            for (int c = 0; c < 8; ++c) acc = fmaf(x[c], w[c][k], acc);
+            acc += __shfl_xor(acc, 1, 64);
+            acc += __shfl_xor(acc, 2, 64);
+            z[k] = acc + bias[k];
+        }
+        if (sub == 0) {
 #pragma unroll
-            for (int k = 0; k < KM; ++k) z[k] = fmaf(x[c], w[c][k], z[k]);
-#pragma unroll
-        for (int k = 0; k < KM; ++k) if (k < K) { z[k] = z[k] + bias[k]; a.logits[(size_t)p * K + k] = z[k]; }
+            for (int k = 0; k < KM; ++k) if (k < K) a.logits[(size_t)p * K + k] = z[k];
+        }
         const uint16_t y = a.labels[p];
         float g[KM];
 #pragma unroll
@@ -760,18 +837,18 @@ __global__ __launch_bounds__(256) void head_train_kernel(HeadArgs a) {
             for (int k = 0; k < KM; ++k) if (k < K) m = fmaxf(m, z[k]);
             float e[KM], sum = 0.f;
 #pragma unroll
-            for (int k = 0; k < KM; ++k) if (k < K) { e[k] = expf(z[k] - m); sum += e[k]; }
+            for (int k = 0; k < KM; ++k) { e[k] = k < K ? expf(z[k] - m) : 0.f; sum += e[k]; }
             const float sw = (float)a.scale * a.weights[p];
 #pragma unroll
             for (int k = 0; k < KM; ++k) if (k < K) {
                 const float pk = e[k] / sum;
-                if (k == y) { loss += (double)sw * (double)(-logf(fmaxf(pk, 1e-10f))); g[k] = sw * (pk - 1.f); }
+                if (k == y) { if (sub == 0) loss += sw * (-logf(fmaxf(pk, 1e-10f))); g[k] = sw * (pk - 1.f); }
                 else g[k] = sw * pk;
             }
         } else if (y != ANH_LABEL_IGNORE && a.error_flag) *a.error_flag = 1;
-        float dx[C];
+        float dx[8];
 #pragma unroll
-        for (int c = 0; c < C; ++c) {
+        for (int c = 0; c < 8; ++c) {
             float acc = 0.f;
 #pragma unroll
             for (int k = 0; k < KM; ++k) acc = fmaf(g[k], wt[k][c], acc);
@@ -779,23 +856,30 @@ __global__ __launch_bounds__(256) void head_train_kernel(HeadArgs a) {
 #pragma unroll
             for (int k = 0; k < KM; ++k) dw[c][k] = fmaf(x[c], g[k], dw[c][k]);
         }
+        if (sub == 0) {
 #pragma unroll
-        for (int k = 0; k < KM; ++k) db[k] += g[k];
-#pragma unroll
-        for (int c8 = 0; c8 < C; c8 += 8) store8<T>(da + (size_t)p * C + c8, dx + c8);
+            for (int k = 0; k < KM; ++k) db[k] += g[k];
+        }
+        store8<T>(da + (size_t)p * C + c0, dx);
     }
-    // wave tree, then one row of partials per workgroup
+    // lanes with equal `sub` hold the same (channel, class) slots: fold them (offsets 4..32 keep `sub`), then across waves
     __shared__ double red[4][1 + KM + C * KM];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    auto fold = [](float v) {
+        double d = (double)v;
+#pragma unroll
+        for (int off = 32; off >= 4; off >>= 1) d += __shfl_down(d, off, 64);
+        return d;
+    };
     {
-        double v = wave_sum(loss);
-        if (lane == 0) red[wave][0] = v;
+        const double l = fold(loss);
+        if (lane == 0) red[wave][0] = l;
 #pragma unroll
-        for (int k = 0; k < KM; ++k) { v = wave_sum((double)db[k]); if (lane == 0) red[wave][1 + k] = v; }
+        for (int k = 0; k < KM; ++k) { const double v = fold(db[k]); if (lane == 0) red[wave][1 + k] = v; }
 #pragma unroll
-        for (int c = 0; c < C; ++c)
+        for (int c = 0; c < 8; ++c)
 #pragma unroll
-            for (int k = 0; k < KM; ++k) { v = wave_sum((double)dw[c][k]); if (lane == 0) red[wave][1 + KM + c * KM + k] = v; }
+            for (int k = 0; k < KM; ++k) { const double v = fold(dw[c][k]); if (lane < 4) red[wave][1 + KM + (lane * 8 + c) * KM + k] = v; }
     }
     __syncthreads();
     const int slots = 1 + K + C * K;
@@ -935,6 +1019,20 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float* blended, int k
 void launch_conv_generic(const ConvArgs& a, hipStream_t s) {
     const int64_t total = (int64_t)a.n * a.h_out * a.w_out;
     if (total == 0) return;
+    if (stem_forward_ok(a)) {
+        const int tiles_x = (a.w_out + 31) / 32, tiles_y = (a.h_out + 7) / 8;
+        const dim3 grid((unsigned)(tiles_x * tiles_y * a.n));
+        const bool bf = a.out_dtype == DT_BF16;
+        if (a.c_red == 3) {
+            if (bf) hipLaunchKernelGGL((stem_forward_kernel<3, bf16>), grid, dim3(256), 0, s, a, tiles_x, tiles_y);
+            else hipLaunchKernelGGL((stem_forward_kernel<3, float>), grid, dim3(256), 0, s, a, tiles_x, tiles_y);
+        } else {
+            if (bf) hipLaunchKernelGGL((stem_forward_kernel<1, bf16>), grid, dim3(256), 0, s, a, tiles_x, tiles_y);
+            else hipLaunchKernelGGL((stem_forward_kernel<1, float>), grid, dim3(256), 0, s, a, tiles_x, tiles_y);
+        }
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
     const int groups = (a.c_out + 7) / 8;
     const int gy = std::min(groups, 4);
     dim3 block(64, gy), grid((unsigned)((total + 63) / 64), (groups + gy - 1) / gy);
@@ -1004,7 +1102,7 @@ void launch_reduce_partials(const float* partials, int splits, int64_t nw, float
 bool head_train_supported(const HeadTrainArgs& a) {
     return a.c_in == kHeadC && a.k >= 1 && a.k <= kHeadKMax && (a.src.kind == SRC_ACT || a.src.kind == SRC_ACT2);
 }
-int head_train_blocks(int64_t pixels) { return (int)std::max<int64_t>(1, std::min<int64_t>((pixels + 255) / 256, 2048)); }
+int head_train_blocks(int64_t pixels) { return (int)std::max<int64_t>(1, std::min<int64_t>((pixels * 4 + 255) / 256, 2048)); }
 int64_t head_train_partial_doubles(const HeadTrainArgs& a) { return (int64_t)head_train_blocks(a.pixels) * (1 + a.k + kHeadC * a.k); }
 
 void launch_head_train(const HeadTrainArgs& t, hipStream_t s) {
