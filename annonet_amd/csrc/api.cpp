@@ -408,6 +408,7 @@ int anh_trainer_forward_backward_device(anh_trainer* h, const uint8_t* d_images,
         Src img;
         img.kind = SRC_IMAGE; img.img = d_images; img.img_h = height; img.img_w = width;
         img.img_sample_stride = (int64_t)height * width * e.spec.cfg.in_channels;
+        e.bn_window = h->bn_window;
         e.forward_training(img, n, height, width);
         e.backward(d_labels, d_weights, loss_scale_n);
     });

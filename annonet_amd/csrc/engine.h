@@ -58,6 +58,8 @@ class Engine {
     hipStream_t stream = nullptr;
     bool own_stream = true;
     Profiler prof;
+    unsigned long bn_window = 100;           // SetAllBatchNormalizationRunningStatsWindowSizes
+    bool update_running_in_forward = true;   // training forwards update the running statistics (dlib bn_ semantics)
 
     // ---- parameters ----
     void set_params(const float* params, const float* running);  // host canonical blobs

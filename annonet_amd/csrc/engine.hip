@@ -328,6 +328,13 @@ void Engine::run_conv_forward(int li, const Src& image, bool training_pass, floa
         b.gamma = master.as<float>() + L.g_off; b.beta = master.as<float>() + L.beta_off;
         b.mean = s.mean; b.invstd = s.invstd; b.scale = s.scale; b.shift = s.shift; b.var = s.var;
         b.partials = bn_partials.as<double>(); b.eps = kBnEps;
+        if (update_running_in_forward) {
+            const double P = (double)p_out;
+            b.averaging_factor = 1.0 / (s.running_updates + 1.0);
+            if (s.running_updates + 1.0 < (double)bn_window) s.running_updates += 1.0;
+            b.unbias = P > 1 ? P / (P - 1.0) : 1.0;
+            b.running_mean = running.as<float>() + L.rs_off; b.running_var = running.as<float>() + L.rs_off + L.cout;
+        }
         const int tok = prof.begin(stream, "bn_forward_stats", 0, (double)p_out * L.cout * es);
         launch_bn_forward_stats(b, stream);
         prof.end(stream, tok);
@@ -449,18 +456,9 @@ void Engine::backward(const uint16_t* d_labels, const float* d_weights, double l
     }
 }
 
-void Engine::apply_update(double lr, double weight_decay, double momentum_coef, double grad_scale, unsigned long bn_window) {
+void Engine::apply_update(double lr, double weight_decay, double momentum_coef, double grad_scale, unsigned long bn_window_arg) {
     ANH_REQUIRE(training && have_forward, "apply_update without a step");
-    for (size_t li = 0; li < spec.layers.size(); ++li) {
-        const anh_layer_desc& L = spec.layers[li];
-        if (!L.has_bn) continue;
-        LayerState& s = ls[li];
-        const double P = (double)s.n * s.h * s.w;
-        const double af = 1.0 / (s.running_updates + 1.0);
-        if (s.running_updates + 1.0 < (double)bn_window) s.running_updates += 1.0;
-        launch_bn_running_update(s.mean, s.var, running.as<float>() + L.rs_off, running.as<float>() + L.rs_off + L.cout, L.cout, af,
-                                 P > 1 ? P / (P - 1.0) : 1.0, stream);
-    }
+    (void)bn_window_arg;  // running statistics are updated by the training forward (bn_finalize), as dlib's bn_ does
     SgdArgs a;
     a.segments = segments.as<ParamSegment>(); a.n_segments = (int)segments_host.size();
     a.n_params = spec.n_params;

@@ -72,6 +72,8 @@ struct BnFwdArgs {
     double* var = nullptr;            // biased batch variance (kept for the running update)
     double* partials = nullptr;       // >= bn_partial_blocks(pixels) * 2 * c doubles
     float eps = 1e-4f;
+    // running statistics, updated by the finalize kernel when running_mean != nullptr (dlib bn_: factor 1/(updates+1), unbiased var)
+    float* running_mean = nullptr; float* running_var = nullptr; double averaging_factor = 1.0, unbias = 1.0;
 };
 int bn_partial_blocks(int64_t pixels);
 void launch_bn_forward_stats(const BnFwdArgs& a, hipStream_t s);

@@ -464,7 +464,7 @@ void wgrad_generic_dispatch(const WgradArgs& a, dim3 grid, int64_t pps, int nco,
 // ---------------------------------------------------------------------------------------------------
 // pixels per workgroup: small layers get smaller slabs so that the grid still covers the chip
 inline int bn_pixels_per_block(int64_t pixels) {
-    int64_t ppb = (pixels + 2047) / 2048;  // aim at ~2048 workgroups
+    int64_t ppb = (pixels + 1023) / 1024;  // aim at ~1024 workgroups (4 per CU); fewer partials keep the finalize short
     ppb = (ppb + 63) / 64 * 64;
     if (ppb < 256) ppb = 256;
     if (ppb > 4096) ppb = 4096;
@@ -499,7 +499,8 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* y, int64_t pixel
 
 // one wave per channel: lanes stride over the per-workgroup partials, then a shuffle tree (fixed order => deterministic)
 __global__ __launch_bounds__(64) void bn_finalize_kernel(const double* partials, int blocks, int64_t pixels, int c, const float* gamma, const float* beta,
-                                                         float eps, float* mean, float* invstd, float* scale, float* shift, double* var_out) {
+                                                         float eps, float* mean, float* invstd, float* scale, float* shift, double* var_out,
+                                                         float* rmean, float* rvar, double af, double unbias) {
     const int ch = blockIdx.x;
     double s = 0, q = 0;
     for (int b = threadIdx.x; b < blocks; b += 64) { s += partials[((size_t)b * c + ch) * 2]; q += partials[((size_t)b * c + ch) * 2 + 1]; }
@@ -513,6 +514,10 @@ __global__ __launch_bounds__(64) void bn_finalize_kernel(const double* partials,
     const float sc = gamma[ch] * is;
     mean[ch] = mf; invstd[ch] = is; scale[ch] = sc; shift[ch] = fmaf(-mf, sc, beta[ch]);
     var_out[ch] = var;
+    if (rmean) {  // dlib bn_ updates its running statistics in the training forward
+        rmean[ch] = (float)((1.0 - af) * (double)rmean[ch] + af * (double)mf);
+        rvar[ch] = (float)((1.0 - af) * (double)rvar[ch] + af * unbias * var);
+    }
 }
 
 __global__ void bn_running_kernel(const float* mean, const double* var, float* rmean, float* rvar, int c, double af, double unbias) {
@@ -1148,7 +1153,7 @@ void launch_bn_forward_stats(const BnFwdArgs& a, hipStream_t s) {
     }
     HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(a.c), dim3(64), 0, s, a.partials, blocks, a.pixels, a.c, a.gamma, a.beta, a.eps,
-                       a.mean, a.invstd, a.scale, a.shift, a.var);
+                       a.mean, a.invstd, a.scale, a.shift, a.var, a.running_mean, a.running_var, a.averaging_factor, a.unbias);
     HIP_CHECK(hipGetLastError());
 }
 
