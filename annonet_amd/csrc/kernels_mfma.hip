@@ -420,6 +420,106 @@ __global__ __launch_bounds__(256, (NTC == 4 ? 1 : 2)) void wgrad3x3_mfma_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// wgrad_stem_mfma: filter gradient of the 5x5 stem on the u8 image, bf16 dy.
+//   dW[(tap,ci)][co] = sum_p img(p + tap - 2)[ci]/256 * dy[p][co]      -> a (25*CIN -> 96 or 32) x 32 MFMA output, K = pixels.
+// dy is fetched with the transposing LDS read as in wgrad3x3_mfma.  The image operand needs, per lane, 8 consecutive
+// pixels of one (tap, ci) row: the patch is kept in LDS as bf16 planes [ci][row][kx][32] — five copies shifted by the
+// tap's kx — so that every fragment is ONE 16-byte-aligned ds_read_b128 (u8/256 is exact in bf16).  Rows beyond
+// 25*CIN read an all-zero plane.  The 16 k-steps of an 8x32 tile are split over the 4 waves; accumulators persist
+// over the workgroup's tiles; every wave writes its own partial (fixed-order reduction afterwards).
+// ---------------------------------------------------------------------------------------------------------------
+template <int CIN>
+__global__ __launch_bounds__(256, 2) void wgrad_stem_mfma_kernel(WgradArgs a, WgSide dy_side, int tiles_x, int tiles_y, int total_tiles, int splits) {
+    constexpr int ROWS = 25 * CIN, RT = (ROWS + 31) / 32, PLANE = 12 * 5 * 64;  // bytes of one channel plane
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* lds_g = smem;                       // 256 pixel records of 64 B (dy tile)
+    char* lds_a = smem + 256 * 64;            // (CIN + 1) planes; the last one stays zero
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
+
+    for (int i = tid; i < PLANE / 4; i += 256) reinterpret_cast<unsigned*>(lds_a + CIN * PLANE)[i] = 0u;
+    int a_off[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const int r = rt * 32 + col;
+        const int tap = r / CIN, ci = r - tap * CIN;
+        const int ky = tap / 5, kx = tap - ky * 5;
+        a_off[rt] = r < ROWS ? ci * PLANE + (ky * 5 + kx) * 64 + half * 16 : CIN * PLANE + half * 16;
+    }
+    f32x16 acc[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;
+
+    for (int tile = blockIdx.x; tile < total_tiles; tile += splits) {
+        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+        const int x0 = tx * 32, y0 = ty * 8;
+        __syncthreads();
+        // image patch (12 x 36 x CIN) -> five shifted bf16 copies per row
+        for (int i = tid; i < 12 * 36 * CIN; i += 256) {
+            const int c = i % CIN, px = (i / CIN) % 36, py = i / (CIN * 36);
+            const int iy = y0 - 2 + py, ix = x0 - 2 + px;
+            float v = 0.f;
+            if (iy >= 0 && iy < a.h_in && ix >= 0 && ix < a.w_in) {
+                const int sy = min(max(a.src.img_top + iy, 0), a.src.img_h - 1), sx = min(max(a.src.img_left + ix, 0), a.src.img_w - 1);
+                v = (float)a.src.img[(size_t)n * a.src.img_sample_stride + ((size_t)sy * a.src.img_w + sx) * CIN + c] * (1.0f / 256.0f);
+            }
+            const bf16 b = (bf16)v;
+#pragma unroll
+            for (int kx = 0; kx < 5; ++kx) {
+                const int xx = px - kx;
+                if (xx >= 0 && xx < 32) *reinterpret_cast<bf16*>(lds_a + c * PLANE + (py * 5 + kx) * 64 + xx * 2) = b;
+            }
+        }
+        stage_side<SRC_RAW, 256 * 4, 4>(lds_g, dy_side, tid, [&](int rec, size_t& pix, int& ch0) {
+            const int oy = y0 + (rec >> 5), ox = x0 + (rec & 31);
+            pix = ((size_t)n * a.h_out + min(oy, a.h_out - 1)) * a.w_out + min(ox, a.w_out - 1);
+            ch0 = 0;
+            return oy < a.h_out && ox < a.w_out;
+        });
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ks = wave * 4 + i;
+            const int row = ks >> 1, xh = (ks & 1) << 4;
+            const bf16x8 gf = tr_read8(lds_g, row * 32 + xh, lane);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const bf16x8 af = *reinterpret_cast<const bf16x8*>(lds_a + a_off[rt] + row * 320 + xh * 2);
+                acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, gf, acc[rt], 0, 0, 0);
+            }
+        }
+    }
+    float* out = a.partials + ((size_t)blockIdx.x * 4 + wave) * ROWS * 32;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (row < ROWS) out[row * 32 + col] = acc[rt][r];
+        }
+}
+
+bool stem_wgrad_mfma_ok(const WgradArgs& a) {
+    return a.src.kind == SRC_IMAGE && a.k == 5 && a.stride == 1 && a.pad == 2 && a.gather == 0 && a.c_out == 32 && (a.c_in == 1 || a.c_in == 3) &&
+           a.h_in == a.h_out && a.w_in == a.w_out && a.dy_dtype == DT_BF16;
+}
+int stem_wgrad_mfma_blocks(const WgradArgs& a) {
+    const int tiles = ((a.w_out + 31) / 32) * ((a.h_out + 7) / 8) * a.n;
+    return std::max(1, std::min(tiles, 512));
+}
+void launch_wgrad_stem_mfma(const WgradArgs& a, hipStream_t s) {
+    const int tiles_x = (a.w_out + 31) / 32, tiles_y = (a.h_out + 7) / 8;
+    const int total = tiles_x * tiles_y * a.n, blocks = stem_wgrad_mfma_blocks(a);
+    const WgSide dy{reinterpret_cast<const bf16*>(a.dy), nullptr, nullptr, nullptr, nullptr, nullptr, a.h_out, a.w_out, 32};
+    const size_t lds = 256 * 64 + (size_t)(a.c_in + 1) * 12 * 5 * 64;
+    if (a.c_in == 3) hipLaunchKernelGGL((wgrad_stem_mfma_kernel<3>), dim3(blocks), dim3(256), lds, s, a, dy, tiles_x, tiles_y, total, blocks);
+    else hipLaunchKernelGGL((wgrad_stem_mfma_kernel<1>), dim3(blocks), dim3(256), lds, s, a, dy, tiles_x, tiles_y, total, blocks);
+    HIP_CHECK(hipGetLastError());
+    launch_reduce_partials(a.partials, blocks * 4, (int64_t)25 * a.c_in * 32, a.dw, s);
+}
+
 struct WgPlan { int stride, ntc, slabs, tiles_x, tiles_y, total, splits; size_t lds; bool cont; };
 
 WgPlan wgrad_plan_mfma(const WgradArgs& a) {
@@ -685,6 +785,7 @@ void launch_conv_mfma(const ConvArgs& a, hipStream_t s) {
 }
 
 bool mfma_wgrad_supported(const WgradArgs& a) {
+    if (stem_wgrad_mfma_ok(a)) return true;
     if (a.k != 3 || a.src.kind == SRC_IMAGE || a.src.dtype != DT_BF16 || a.dy_dtype != DT_BF16) return false;
     const bool s1 = a.stride == 1 && a.pad == 1 && a.gather == 0 && a.h_in == a.h_out && a.w_in == a.w_out;
     const bool s2 = a.stride == 2 && a.pad == 0;
@@ -693,12 +794,16 @@ bool mfma_wgrad_supported(const WgradArgs& a) {
     return c_patch % 32 == 0 && (c_tile == 32 || c_tile == 64 || c_tile == 128);
 }
 
-int64_t wgrad_mfma_scratch_floats(const WgradArgs& a) { return (int64_t)wgrad_plan_mfma(a).splits * 9 * a.c_in * a.c_out; }
+int64_t wgrad_mfma_scratch_floats(const WgradArgs& a) {
+    if (stem_wgrad_mfma_ok(a)) return (int64_t)stem_wgrad_mfma_blocks(a) * 4 * 25 * a.c_in * 32;
+    return (int64_t)wgrad_plan_mfma(a).splits * 9 * a.c_in * a.c_out;
+}
 
 void launch_wgrad_mfma(const WgradArgs& a, hipStream_t s) {
     if (!mfma_wgrad_supported(a)) fail(ANH_ERR_INTERNAL, "wgrad_mfma: unsupported shape");
     ANH_REQUIRE(wgrad_mfma_scratch_floats(a) <= a.partials_capacity, "wgrad scratch too small");
     if ((int64_t)a.n * a.h_out * a.w_out == 0) return;
+    if (stem_wgrad_mfma_ok(a)) { launch_wgrad_stem_mfma(a, s); return; }
     launch_wgrad_any(a, s);
 }
 
