@@ -57,6 +57,10 @@ class Engine {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = true;
+    // filter gradients run on a second stream, concurrently with the backward-data / bn chain (both only read dy)
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t ev_dy_ready = nullptr, ev_aux_done = nullptr;
+    bool concurrent_wgrad = true;
     Profiler prof;
     unsigned long bn_window = 100;           // SetAllBatchNormalizationRunningStatsWindowSizes
     bool update_running_in_forward = true;   // training forwards update the running statistics (dlib bn_ semantics)
@@ -101,7 +105,7 @@ class Engine {
     void fold_running_stats();  // inference: scale/shift from running stats, computed on the host
     void ensure_training_buffers();
     void conv_dispatch(const ConvArgs& a, const char* tag, double flops, double bytes);
-    void wgrad_dispatch(WgradArgs& a, const char* tag, double flops, double bytes);
+    void wgrad_dispatch(WgradArgs& a, const char* tag, double flops, double bytes, hipStream_t on);
 
     std::vector<LayerState> ls;
     std::vector<ParamSegment> segments_host;

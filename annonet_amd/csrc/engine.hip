@@ -2,6 +2,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "hostlogic.h"
@@ -65,6 +66,13 @@ Engine::Engine(const anh_net_config& cfg, bool training_) : spec(Spec::build(cfg
     if (hipGetDeviceCount(&count) != hipSuccess || count == 0) { (void)hipGetLastError(); fail(ANH_ERR_DEVICE, "no MI355X / HIP device visible"); }
     HIP_CHECK(hipGetDevice(&device));
     HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    if (training) {
+        HIP_CHECK(hipStreamCreateWithFlags(&aux_stream, hipStreamNonBlocking));
+        HIP_CHECK(hipEventCreateWithFlags(&ev_dy_ready, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&ev_aux_done, hipEventDisableTiming));
+        const char* e = getenv("ANH_CONCURRENT_WGRAD");
+        if (e && e[0] == '0') concurrent_wgrad = false;
+    }
     const size_t np = (size_t)spec.n_params;
     master.reserve(np * 4);
     w_tm_f32.reserve(np * 4);
@@ -111,7 +119,11 @@ Engine::Engine(const anh_net_config& cfg, bool training_) : spec(Spec::build(cfg
 }
 
 Engine::~Engine() {
-    if (stream && own_stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
+    if (stream) (void)hipStreamSynchronize(stream);
+    if (aux_stream) { (void)hipStreamSynchronize(aux_stream); (void)hipStreamDestroy(aux_stream); }
+    if (ev_dy_ready) (void)hipEventDestroy(ev_dy_ready);
+    if (ev_aux_done) (void)hipEventDestroy(ev_aux_done);
+    if (stream && own_stream) (void)hipStreamDestroy(stream);
 }
 
 void Engine::set_stream(hipStream_t s) {
@@ -123,6 +135,7 @@ void Engine::set_stream(hipStream_t s) {
 
 void Engine::synchronize() {
     HIP_CHECK(hipStreamSynchronize(stream));
+    if (aux_stream) HIP_CHECK(hipStreamSynchronize(aux_stream));
     if (prof.enabled) prof.collect();
 }
 
@@ -282,17 +295,17 @@ void Engine::conv_dispatch(const ConvArgs& a, const char* tag, double flops, dou
     prof.end(stream, tok);
 }
 
-void Engine::wgrad_dispatch(WgradArgs& a, const char* tag, double flops, double bytes) {
+void Engine::wgrad_dispatch(WgradArgs& a, const char* tag, double flops, double bytes, hipStream_t on) {
     const bool fast = wgrad_takes_mfma(a, dtype);
     const int64_t need = fast ? wgrad_mfma_scratch_floats(a) : wgrad_generic_scratch_floats(a);
     wgrad_partials.reserve((size_t)need * 4);
     a.partials = wgrad_partials.as<float>();
     a.partials_capacity = (int64_t)(wgrad_partials.bytes / 4);
     std::string name = std::string(fast ? "wgrad_mfma_bf16:" : (dtype == DT_BF16 ? "wgrad_generic_bf16:" : "wgrad_generic_f32:")) + tag;
-    const int tok = prof.begin(stream, name.c_str(), flops, bytes);
-    if (fast) launch_wgrad_mfma(a, stream);
-    else launch_wgrad_generic(a, stream);
-    prof.end(stream, tok);
+    const int tok = prof.begin(on, name.c_str(), flops, bytes);
+    if (fast) launch_wgrad_mfma(a, on);
+    else launch_wgrad_generic(a, on);
+    prof.end(on, tok);
 }
 
 static const char* layer_tag(const anh_layer_desc& L) {
@@ -434,7 +447,13 @@ void Engine::backward(const uint16_t* d_labels, const float* d_weights, double l
             g.k = L.k; g.stride = L.stride; g.pad = L.pad; g.gather = L.type;
             g.dw = grad.as<float>() + L.w_off;
             const double bytes = (double)p_in * L.cin * (L.in_a < 0 ? 1.0 : es) * (L.in_b >= 0 ? 2 : 1) + (double)p_out * L.cout * (L.has_bn ? es : 4.0);
-            wgrad_dispatch(g, (std::string("wgrad_") + layer_tag(L)).c_str(), flops, bytes);
+            hipStream_t on = stream;
+            if (concurrent_wgrad && aux_stream) {   // dy of this layer is final on the main stream: let the aux stream pick it up
+                HIP_CHECK(hipEventRecord(ev_dy_ready, stream));
+                HIP_CHECK(hipStreamWaitEvent(aux_stream, ev_dy_ready, 0));
+                on = aux_stream;
+            }
+            wgrad_dispatch(g, (std::string("wgrad_") + layer_tag(L)).c_str(), flops, bytes, on);
         }
         if (L.in_a >= 0) {   // data gradient -> d(activation of the producing layers)
             ConvArgs a;
@@ -453,6 +472,10 @@ void Engine::backward(const uint16_t* d_labels, const float* d_weights, double l
             const double bytes = (double)p_out * L.cout * (L.has_bn ? es : 4.0) + (double)p_in * L.cin * es * (L.in_b >= 0 ? 2 : 1) * (a.out_accumulate ? 2 : 1);
             conv_dispatch(a, (std::string("dgrad_") + layer_tag(L)).c_str(), flops, bytes);
         }
+    }
+    if (concurrent_wgrad && aux_stream) {  // gradients are complete on the main stream only after the aux stream drains
+        HIP_CHECK(hipEventRecord(ev_aux_done, aux_stream));
+        HIP_CHECK(hipStreamWaitEvent(stream, ev_aux_done, 0));
     }
 }
 
