@@ -21,11 +21,11 @@ def grad_bucket_tensor(trainer):
     return device_tensor(ptr, n)
 
 
-def data_parallel_step(trainer, bucket, d_images, d_labels, d_weights, n, h, w, world_size, group=None):
+def data_parallel_step(trainer, bucket, d_images, d_labels, d_weights, n, h, w, world_size, group=None, force_collective=False):
     """One optimiser step of a data-parallel job.  The loss scale uses the GLOBAL batch (n * world_size), so the
     all-reduce is a plain SUM and every rank then applies the identical update."""
     trainer.forward_backward_device(d_images, d_labels, d_weights, n, h, w, n * world_size)
-    if world_size > 1:
+    if world_size > 1 or force_collective:
         import torch.distributed as dist
         dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=group)
     trainer.apply_update(1.0)

@@ -210,6 +210,21 @@ def annonet_infer(net, input_image, gains=None, detection_levels=None, tiling_pa
     return (res, bl) if want_blended else res
 
 
+def annonet_infer_device(net, d_image_ptr, height, width, d_labels_ptr, d_blended_ptr, gains=None, tiling_parameters=None, tiles=None):
+    """annonet_infer() with the image, the label map and the blended planes resident in HBM (device pointers as ints).
+    `tiles` (list of (full, unique) rects) restricts the call to a shard of the tile list (multi-GPU inference)."""
+    g = np.ascontiguousarray(gains, dtype=np.float64) if gains is not None else None
+    tp = tiling_parameters._c() if tiling_parameters is not None else None
+    arr, n = None, 0
+    if tiles is not None:
+        n = len(tiles)
+        arr = (_lib.Tile * max(n, 1))()
+        for i, (full, uniq) in enumerate(tiles):
+            arr[i].full_rect = _lib.Rect(*full)
+            arr[i].unique_rect = _lib.Rect(*uniq)
+    check(net.L.anh_infer_device(net.h, d_image_ptr, height, width, _ptr(g), C.byref(tp) if tp is not None else None, arr, n, d_labels_ptr, d_blended_ptr))
+
+
 class TrainingNet(_Profiled):
     """NetPimpl::TrainingNet (annonet_train_main.cpp:396-410)."""
     _is_trainer = 1

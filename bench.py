@@ -61,6 +61,60 @@ def cpu_baseline(sample_tiles=4):
             "sample": f"1 training step on {sample_tiles} tiles of {TILE}x{TILE}x3 (same net, fp32 CPU oracle, {dt:.2f} s)"}
 
 
+def bench_infer(args, aa, aad, torch, dist, prec, rank, local_rank, world, use_dist):
+    """BASELINE.json configs[2] / [4]: tiled sliding-window inference over one synthetic image, tiles sharded across ranks
+    (no collective in the data path).  Timed: tile cut + forward + blend + argmax, image and label map resident in HBM."""
+    side = args.image_side
+    dev = torch.device("cuda", local_rank)
+    cfg = aa.net_config(LEVELS, 3, CLASSES, WIDTH, 1, prec)
+    tr = aa.TrainingNet(LEVELS, 3, prec, seed=2)
+    tr.SetNetWidth(WIDTH, 1); tr.SetClassCount(CLASSES); tr.Initialize()
+    net = tr.GetRuntimeNet(prec)
+    del tr
+    stream = torch.cuda.current_stream()
+    net.set_stream(stream.cuda_stream)
+    rng = np.random.default_rng(3)
+    image = torch.from_numpy(rng.integers(0, 256, (side, side, 3), dtype=np.uint8)).to(dev)
+    labels = torch.empty((side, side), dtype=torch.int16, device=dev)
+    blended = torch.empty((CLASSES, side, side), dtype=torch.float32, device=dev)
+    import ctypes as C
+    ov = aa.lib().anh_required_input_dim(C.byref(cfg))
+    tp = aa.tiling.parameters(1024, 1024, ov, ov)  # GPU defaults of the reference (annonet_infer_main.cpp:300-303,423-427)
+    tiles = aa.tiling.get_tiles(side, side, tp)
+    mine = aad.shard_tiles(tiles, rank, world)
+
+    def run():
+        aa.annonet_infer_device(net, image.data_ptr(), side, side, labels.data_ptr(), blended.data_ptr(), tiling_parameters=tp, tiles=mine)
+
+    def fence():
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup, 1)):
+        run()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if use_dist:
+        el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        elapsed = float(el.item())
+    if rank == 0:
+        out = {"metric": f"Mpixels/s tiled inference, {side}x{side} image, 1024^2 tiles, overlap {ov}", "value": side * side * args.steps / elapsed / 1e6,
+               "unit": "Mpx/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+               "config": {"workload": f"annonet_infer(): {len(tiles)} tiles ({len(mine)} on rank 0), levels={LEVELS} width={WIDTH} K={CLASSES}", "parallelism": f"tile-shard{world}"}}
+        print(json.dumps(out), flush=True)
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -68,6 +122,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", default="train", choices=["train", "infer"], help="train = BASELINE.json's metric (default); infer = tiled inference over a 4096x4096 image")
+    ap.add_argument("--image-side", type=int, default=4096)
     args = ap.parse_args()
 
     import torch
@@ -81,12 +137,16 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     torch.cuda.set_device(local_rank)
     aa._lib.check(aa.lib().anh_set_device(local_rank))
-    if world > 1:
-        import torch.distributed as dist
+    import torch.distributed as dist
+    use_dist = world > 1 or "RANK" in os.environ  # launched by torch.distributed.run: take the RCCL path even at world 1
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     prec = aa.ANH_BF16 if args.precision == "bf16" else aa.ANH_FP32
+    if args.mode == "infer":
+        return bench_infer(args, aa, aad, torch, dist, prec, rank, local_rank, world, use_dist)
     t = aa.TrainingNet(LEVELS, 3, prec, seed=2)
     t.SetNetWidth(WIDTH, 1)
     t.SetClassCount(CLASSES)
@@ -103,11 +163,11 @@ def main():
     d_w = torch.from_numpy(w).to(dev)
 
     def step():
-        aad.data_parallel_step(t, bucket, d_img.data_ptr(), d_lab.data_ptr(), d_w.data_ptr(), BATCH, TILE, TILE, world)
+        aad.data_parallel_step(t, bucket, d_img.data_ptr(), d_lab.data_ptr(), d_w.data_ptr(), BATCH, TILE, TILE, world, force_collective=use_dist)
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -130,7 +190,7 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         elapsed = float(el.item())
@@ -175,7 +235,7 @@ def main():
             "final_loss": loss,
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -268,3 +268,112 @@ def test_bf16_training_step(levels, scaler, minf):
     p, r = t.get_params()
     assert np.isfinite(p).all() and np.isfinite(r).all()
     np.testing.assert_allclose(r, o.running, rtol=2e-2, atol=1e-3)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# full-size cases (BASELINE.json configs) and the RCCL plumbing
+# ------------------------------------------------------------------------------------------------------------------
+def test_full_size_training_step_batch32_227():
+    """BASELINE config [1]: batch 32 x 3 x 227 x 227, levels 2, width 1.0.  fp32 parity mode against the oracle (which needs
+    ~15 s of host time for this batch), and the bf16 mode's loss against both oracles."""
+    rng = np.random.default_rng(0)
+    n, d = 32, 227
+    img = rng.integers(0, 256, (n, d, d, 3), dtype=np.uint8)
+    lab = rng.integers(0, 3, (n, d, d)).astype(np.uint16)
+    lab[rng.random((n, d, d)) < 0.05] = IGNORE
+    wl = [aa.set_weights(lab[i], 0.5, 0.5) for i in range(n)]
+    w = np.stack([x["weight"] for x in wl])
+    o, t = trainer_pair(2, 3, 3, 1.0, 1, aa.ANH_FP32, lr=0.1)
+    want = o.train_step(img, lab, w)
+    t.StartTraining(list(img), wl)
+    assert abs(t.get_last_loss() - want) <= 2e-5 * max(1.0, abs(want))
+    g, gw = t.get_grads(), o.grads
+    np.testing.assert_allclose(g, gw, rtol=5e-3, atol=5e-5 * np.abs(gw).max())
+    p, r = t.get_params()
+    np.testing.assert_allclose(p, o.params, rtol=1e-4, atol=5e-6)
+    np.testing.assert_allclose(r, o.running, rtol=1e-4, atol=1e-5)
+    o2, t2 = trainer_pair(2, 3, 3, 1.0, 1, aa.ANH_BF16, lr=0.1)
+    t2.StartTraining(list(img), wl)
+    assert abs(t2.get_last_loss() - want) <= 0.02 * max(1.0, abs(want))
+    g2 = t2.get_grads()
+    for L in o.layers:  # at this batch size the bf16 gradients line up with fp32 far better than on toy batches
+        nw = L.k * L.k * L.cin * L.cout
+        a, b = g2[L.w_off:L.w_off + nw], gw[L.w_off:L.w_off + nw]
+        cos = float(a @ b) / max(np.linalg.norm(a) * np.linalg.norm(b), 1e-30)
+        assert cos > 0.97, (L.cin, L.cout, cos)
+
+
+def test_large_image_tiled_inference_properties():
+    """BASELINE config [2] shape class (a multi-tile image with 1024^2 tiles), through size-independent properties:
+    fp32 labels bit-exact against the oracle on a sampled tile window, determinism, and label agreement bf16 vs fp32."""
+    o, net = pair(2, 3, 3, 0.25, 4, aa.ANH_FP32, seed=13)
+    rng = np.random.default_rng(8)
+    H, W = 1500, 2100
+    img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    ov = o.required_input_dim()
+    tp = aa.tiling.parameters(1024, 1024, ov, ov)
+    labels, blended = aa.annonet_infer(net, img, tiling_parameters=tp, want_blended=True)
+    labels2 = aa.annonet_infer(net, img, tiling_parameters=tp)
+    np.testing.assert_array_equal(labels, labels2)                       # deterministic
+    assert labels.max() < 3 and blended.shape == (3, H, W)
+    # a pixel deep inside a tile's unique rect sees only real image data: its logits equal a plain forward of a crop around it
+    tiles = aa.tiling.get_tiles(W, H, tp)
+    (fl, ft, fr, fb), (ul, ut, ur, ub) = tiles[0]
+    # the net input window of that tile (annonet_infer.cpp:46-66); the net is translation-equivariant only for shifts that
+    # are multiples of 2^levels (stride-2 grid phase), so the comparison crop is aligned to the window modulo 4
+    fw, fh = fr - fl + 1, fb - ft + 1
+    win_left = fl + fw // 2 - o.recommended_input_dim(fw) // 2
+    win_top = ft + fh // 2 - o.recommended_input_dim(fh) // 2
+    d = o.recommended_input_dim(2 * ov + 41)
+    cy, cx = (ut + ub) // 2, (ul + ur) // 2
+    top = win_top + ((cy - d // 2 - win_top) // 4) * 4
+    left = win_left + ((cx - d // 2 - win_left) // 4) * 4
+    crop = img[top:top + d, left:left + d]
+    want = o.forward(crop[None])[0]
+    m = ov  # margin: receptive field
+    np.testing.assert_array_equal(blended[:, top + m:top + d - m, left + m:left + d - m], want[:, m:d - m, m:d - m])
+    np.testing.assert_array_equal(labels[top + m:top + d - m, left + m:left + d - m], want[:, m:d - m, m:d - m].argmax(0))
+    # bf16 mode: label agreement
+    _, net16 = pair(2, 3, 3, 0.25, 4, aa.ANH_BF16, seed=13)
+    l16 = aa.annonet_infer(net16, img, tiling_parameters=tp)
+    assert (l16 == labels).mean() > 0.97
+
+
+def test_grad_bucket_is_a_live_view_and_all_reduce_runs_on_it():
+    """The gradient bucket handed to torch.distributed is the library's own HBM (zero copy), and an RCCL all-reduce on it
+    (world size 1 on this box) leaves the step's result unchanged."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from annonet_amd import dist as aad
+    o, t = trainer_pair(1, 3, 3, 0.25, 4, aa.ANH_FP32)
+    rng = np.random.default_rng(6)
+    d = o.recommended_input_dim(17)
+    img, lab, w, _ = make_batch(rng, 2, d, 3, 3)
+    dev = torch.device("cuda:0")
+    timg, tlab, tw = (torch.from_numpy(a).to(dev) for a in (img, lab.view(np.int16), w))
+    t.set_stream(torch.cuda.current_stream().cuda_stream)
+    bucket = aad.grad_bucket_tensor(t)
+    assert bucket.numel() == o.n_params + 1 and bucket.is_cuda
+    t.forward_backward_device(timg.data_ptr(), tlab.data_ptr(), tw.data_ptr(), 2, d, d, 2)
+    t.synchronize()
+    want = o.train_step(img, lab, w, apply_update=False)
+    assert abs(float(bucket[-1].item()) - want) <= 2e-5 * max(1.0, abs(want))      # trailing slot = loss
+    head = o.layers[-1]
+    got_bias_grad = bucket[head.b_off:head.b_off + 3].cpu().numpy()               # bias segment is layout-independent
+    np.testing.assert_allclose(got_bias_grad, o.grads[head.b_off:head.b_off + 3], rtol=2e-3, atol=1e-7)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        before = bucket.clone()
+        dist.all_reduce(bucket, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize()
+        assert torch.equal(before, bucket)
+        t.apply_update(1.0)
+        t.synchronize()
+    finally:
+        dist.destroy_process_group()
+    o.train_step(img, lab, w)  # same step with the update applied
+    p, _ = t.get_params()
+    np.testing.assert_allclose(p, o.params, rtol=1e-4, atol=2e-6)
