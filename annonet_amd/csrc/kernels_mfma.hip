@@ -507,7 +507,7 @@ bool stem_wgrad_mfma_ok(const WgradArgs& a) {
 }
 int stem_wgrad_mfma_blocks(const WgradArgs& a) {
     const int tiles = ((a.w_out + 31) / 32) * ((a.h_out + 7) / 8) * a.n;
-    return std::max(1, std::min(tiles, 512));
+    return std::max(1, std::min(tiles, 256));
 }
 void launch_wgrad_stem_mfma(const WgradArgs& a, hipStream_t s) {
     const int tiles_x = (a.w_out + 31) / 32, tiles_y = (a.h_out + 7) / 8;
@@ -535,7 +535,9 @@ WgPlan wgrad_plan_mfma(const WgradArgs& a) {
     p.tiles_y = (lr_h + th - 1) / th;
     p.total = p.tiles_x * p.tiles_y * a.n;
     p.lds = (size_t)(a.stride == 1 ? 340 : 594) * 64 + (size_t)p.ntc * th * 32 * 64;
-    const int target = p.lds > 80 * 1024 ? 256 : 512;
+    // one workgroup per CU: these kernels share the chip with the backward-data chain (second stream), and every
+    // workgroup writes a full partial, so fewer workgroups also means less partial-sum traffic
+    const int target = 256;
     p.splits = std::max(1, std::min(p.total, target / p.slabs));
     return p;
 }
