@@ -725,6 +725,98 @@ __global__ __launch_bounds__(256, 2) void conv3x3_up_mfma_kernel(ConvArgs a, WgS
 
 WgSide side_of(const ConvArgs& a) { return side_of_src(a.src, a.h_in, a.w_in, a.c_red); }
 
+// ---------------------------------------------------------------------------------------------------------------
+// stem_mfma: the 5x5 stem (u8 image, 1 or 3 channels -> 32) on the matrix cores.
+// K is laid out as 5 filter rows x 32, a filter row being 8 pixels x 4 channels (RGB0): positions beyond 5 pixels / 3
+// channels carry ZERO weights, so whatever finite pixel data sits there does not matter.  The image patch is kept in
+// LDS as 8-byte RGB0 bf16 pixels (u8/256 is exact in bf16), which makes a lane's B operand for (filter row, k-step)
+// 16 contiguous, 8-byte aligned bytes: two ds_read_b64.  The padded weights (A operand, 10 fragments) are gathered
+// once per workgroup into registers; workgroups are persistent over a strided set of 8x32 tiles.
+// ---------------------------------------------------------------------------------------------------------------
+template <int CIN>
+__global__ __launch_bounds__(256, 2) void stem_mfma_kernel(ConvArgs a, int tiles_x, int tiles_y, int total_tiles) {
+    constexpr int SPW = 48;                      // patch pixels per row: 36 used + padding read by the zero-weight positions
+    __shared__ __attribute__((aligned(16))) unsigned long long patch[12 * SPW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
+
+    // A fragments: W'[co = col][k = ky*32 + ks*16 + 8*half + j], k -> (kx = k'/4, ci = k'%4) within the filter row
+    bf16x8 wf[5][2];
+#pragma unroll
+    for (int ky = 0; ky < 5; ++ky)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int kk = ks * 16 + 8 * half + j;
+                const int kx = kk >> 2, ci = kk & 3;
+                float w = 0.f;
+                if (kx < 5 && ci < CIN) w = a.w_f32[((size_t)(ky * 5 + kx) * CIN + ci) * 32 + col];
+                wf[ky][ks][j] = (bf16)w;
+            }
+
+    for (int i = tid; i < 12 * SPW; i += 256) patch[i] = 0ull;
+    for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+        const int x0 = tx * 32, y0 = ty * 8;
+        __syncthreads();
+        for (int i = tid; i < 12 * 36; i += 256) {
+            const int py = i / 36, px = i - py * 36;
+            const int iy = y0 - 2 + py, ix = x0 - 2 + px;
+            unsigned long long v = 0ull;
+            if (iy >= 0 && iy < a.h_in && ix >= 0 && ix < a.w_in) {
+                const int sy = min(max(a.src.img_top + iy, 0), a.src.img_h - 1), sx = min(max(a.src.img_left + ix, 0), a.src.img_w - 1);
+                const uint8_t* src = a.src.img + (size_t)n * a.src.img_sample_stride + ((size_t)sy * a.src.img_w + sx) * CIN;
+                unsigned short c[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int ch = 0; ch < CIN; ++ch) c[ch] = __builtin_bit_cast(unsigned short, (bf16)((float)src[ch] * (1.0f / 256.0f)));
+                v = (unsigned long long)c[0] | ((unsigned long long)c[1] << 16) | ((unsigned long long)c[2] << 32) | ((unsigned long long)c[3] << 48);
+            }
+            patch[py * SPW + px] = v;
+        }
+        __syncthreads();
+        f32x16 acc[2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < 5; ++ky)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    // pixels (row wave*2+g+ky, col + 4*ks + 2*half + {0,1}) = 8 bf16 = k positions ks*16 + 8*half + 0..7
+                    const unsigned long long* p = patch + (wave * 2 + g + ky) * SPW + col + 4 * ks + 2 * half;
+                    typedef __attribute__((ext_vector_type(2))) unsigned long long u64x2;
+                    u64x2 raw = {p[0], p[1]};
+                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ky][ks], __builtin_bit_cast(bf16x8, raw), acc[g], 0, 0, 0);
+                }
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int oy = y0 + wave * 2 + g, ox = x0 + col;
+            const bool valid = oy < a.h_out && ox < a.w_out;
+            const size_t pix = ((size_t)n * a.h_out + (valid ? oy : 0)) * a.w_out + (valid ? ox : 0);
+            f32x16 one[1] = {acc[g]};
+            store_pixel_tiles<1>(one, a, pix, valid, half);
+        }
+    }
+}
+
+bool stem_mfma_ok(const ConvArgs& a) {
+    return a.src.kind == SRC_IMAGE && a.k == 5 && a.stride == 1 && a.pad == 2 && a.gather == 0 && a.c_out == 32 && (a.c_red == 1 || a.c_red == 3) &&
+           a.h_in == a.h_out && a.w_in == a.w_out && !a.bias && !a.out_nchw && a.out_dtype == DT_BF16 && a.w_f32;
+}
+void launch_stem_mfma(const ConvArgs& a, hipStream_t s) {
+    const int tiles_x = (a.w_out + 31) / 32, tiles_y = (a.h_out + 7) / 8;
+    const int total = tiles_x * tiles_y * a.n;
+    const dim3 grid((unsigned)std::min(total, 1024)), block(256);
+    if (a.c_red == 3) hipLaunchKernelGGL((stem_mfma_kernel<3>), grid, block, 0, s, a, tiles_x, tiles_y, total);
+    else hipLaunchKernelGGL((stem_mfma_kernel<1>), grid, block, 0, s, a, tiles_x, tiles_y, total);
+    HIP_CHECK(hipGetLastError());
+}
+
+
+
 template <int NT, int TAPS>
 void launch_down(const ConvArgs& a, hipStream_t s) {
     const int tiles_x = (a.w_out + 31) / 32, tiles_y = (a.h_out + 3) / 4;
@@ -756,6 +848,7 @@ void launch_up(const ConvArgs& a, hipStream_t s) {
 }  // namespace
 
 bool mfma_conv_supported(const ConvArgs& a) {
+    if (stem_mfma_ok(a)) return true;
     if (a.k != 3 || !a.w_bf16) return false;
     if (a.src.kind == SRC_IMAGE || a.src.dtype != DT_BF16 || a.out_dtype != DT_BF16 || a.out_nchw || a.bias) return false;
     if (a.c_red % 32 != 0) return false;
@@ -772,6 +865,7 @@ bool mfma_conv_supported(const ConvArgs& a) {
 void launch_conv_mfma(const ConvArgs& a, hipStream_t s) {
     if (!mfma_conv_supported(a)) fail(ANH_ERR_INTERNAL, "conv_mfma: unsupported shape");
     if ((int64_t)a.n * a.h_out * a.w_out == 0) return;
+    if (stem_mfma_ok(a)) { launch_stem_mfma(a, s); return; }
     if (a.stride == 1) {
         if (a.c_out == 32) launch_s1<1, 9>(a, s);
         else if (a.c_out == 64) launch_s1<2, 9>(a, s);
