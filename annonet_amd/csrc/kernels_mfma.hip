@@ -66,8 +66,8 @@ __device__ __forceinline__ uint4 add_bf16x8(const uint4& p, const uint4& q) {
 // every lane.  With "accumulate" the old values are fetched by one batch of unconditional loads (pix is clamped by the
 // caller) before any add/store, instead of a load -> wait -> store chain per 16 bytes.
 template <int NT>
-__device__ __forceinline__ void store_pixel_tiles(const f32x16 (&acc)[NT], const ConvArgs& a, size_t pix, bool valid, int half) {
-    constexpr int C_OUT = NT * 32;
+__device__ __forceinline__ void store_pixel_tiles(const f32x16 (&acc)[NT], const ConvArgs& a, size_t pix, bool valid, int half, int co_base = 0) {
+    const int C_OUT = a.c_out;  // a workgroup may own only NT*32 of the layer's output channels, starting at co_base
     uint4 q[NT][2];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -86,7 +86,7 @@ __device__ __forceinline__ void store_pixel_tiles(const f32x16 (&acc)[NT], const
     for (int d = 0; d < 2; ++d) {
         bf16* out = outs[d];
         if (!out) continue;
-        const size_t base = pix * C_OUT + 8 * half;
+        const size_t base = pix * C_OUT + co_base + 8 * half;
         if (accumulate[d]) {
             uint4 old[NT][2];
 #pragma unroll
@@ -185,7 +185,7 @@ __device__ __forceinline__ void stage_side(char* lds, const WgSide& s, int tid, 
 
 // weights of NTAPS taps for one 32-channel slab -> LDS records [tap][co][32 ci]; loads first, then writes
 template <int C_OUT, int NTAPS>
-__device__ __forceinline__ void stage_weights(char* lds_w, const bf16* wsrc, int t0, int c_red, int cc, int tid) {
+__device__ __forceinline__ void stage_weights(char* lds_w, const bf16* wsrc, int t0, int c_red, int cc, int tid, int c_out_total = C_OUT, int co_base = 0) {
     constexpr int ITEMS = NTAPS * C_OUT * 4, WI = (ITEMS + 255) / 256;
     const int c16 = tid & 3;
     uint4 r[WI];
@@ -194,7 +194,7 @@ __device__ __forceinline__ void stage_weights(char* lds_w, const bf16* wsrc, int
         const int item = min(tid + 256 * j, ITEMS - 1);  // clamped: the load stays unconditional
         const int rec = item >> 2;
         const int tl = rec / C_OUT, co = rec - tl * C_OUT;
-        r[j] = *reinterpret_cast<const uint4*>(wsrc + ((size_t)(t0 + tl) * C_OUT + co) * c_red + cc + c16 * 8);
+        r[j] = *reinterpret_cast<const uint4*>(wsrc + ((size_t)(t0 + tl) * c_out_total + co_base + co) * c_red + cc + c16 * 8);
     }
 #pragma unroll
     for (int j = 0; j < WI; ++j) {
@@ -219,6 +219,7 @@ __global__ __launch_bounds__(256, (NT == 4 ? 1 : 2)) void conv3x3s1_mfma_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, col = lane & 31;
     const int tile = blockIdx.x;
+    const int co_base = blockIdx.y * C_OUT;  // 128-channel layers are split over two workgroups of 64 channels (occupancy)
     const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
     const int x0 = tx * TW, y0 = ty * TH;
     const int H = a.h_out, W = a.w_out;  // stride 1, pad 1: input and output planes have the same size
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(256, (NT == 4 ? 1 : 2)) void conv3x3s1_mfma_kernel(
         });
         for (int t0 = 0; t0 < 9; t0 += TAPS) {
             if (t0 > 0) __syncthreads();  // the previous tap group's weight reads are done
-            stage_weights<C_OUT, TAPS>(lds_w, wsrc, t0, c_red, cc, tid);
+            stage_weights<C_OUT, TAPS>(lds_w, wsrc, t0, c_red, cc, tid, a.c_out, co_base);
             __syncthreads();
             // ---- MFMA over the staged taps (2 waves per SIMD: the partner wave covers the LDS read latency) ----
 #pragma unroll
@@ -282,14 +283,14 @@ __global__ __launch_bounds__(256, (NT == 4 ? 1 : 2)) void conv3x3s1_mfma_kernel(
         const int oy = y0 + wave * 2 + g, ox = x0 + col;
         const bool valid = oy < H && ox < W;
         const size_t pix = ((size_t)n * H + (valid ? oy : 0)) * W + (valid ? ox : 0);
-        store_pixel_tiles<NT>(acc[g], a, pix, valid, half);
+        store_pixel_tiles<NT>(acc[g], a, pix, valid, half, co_base);
     }
 }
 
 template <int NT, int TAPS>
 void launch_s1(const ConvArgs& a, hipStream_t s) {
     const int tiles_x = (a.w_out + TW - 1) / TW, tiles_y = (a.h_out + TH - 1) / TH;
-    const dim3 grid((unsigned)(tiles_x * tiles_y * a.n)), block(256);
+    const dim3 grid((unsigned)(tiles_x * tiles_y * a.n), (unsigned)(a.c_out / (NT * 32))), block(256);
     const size_t lds = X_BYTES + (size_t)TAPS * NT * 32 * 64;
     const int flip = a.gather;  // backward-data of a stride-1 conv = the same conv with the taps mirrored
     switch (a.src.kind) {
@@ -606,6 +607,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_down_mfma_kernel(ConvArgs a, W
     const int tile = blockIdx.x;
     const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
     const int x0 = tx * 32, y0 = ty * DTH;
+    const int co_base = blockIdx.y * C_OUT;
     const bf16* wsrc = reinterpret_cast<const bf16*>(a.w_bf16);
 
     f32x16 acc[NT];
@@ -625,7 +627,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_down_mfma_kernel(ConvArgs a, W
         });
         for (int t0 = 0; t0 < 9; t0 += TAPS) {
             if (t0 > 0) __syncthreads();
-            stage_weights<C_OUT, TAPS>(lds_w, wsrc, t0, a.c_red, cc, tid);
+            stage_weights<C_OUT, TAPS>(lds_w, wsrc, t0, a.c_red, cc, tid, a.c_out, co_base);
             __syncthreads();
 #pragma unroll
             for (int tl = 0; tl < TAPS; ++tl) {
@@ -649,7 +651,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_down_mfma_kernel(ConvArgs a, W
     const int oy = y0 + wave, ox = x0 + col;
     const bool valid = oy < a.h_out && ox < a.w_out;
     const size_t pix = ((size_t)n * a.h_out + (valid ? oy : 0)) * a.w_out + (valid ? ox : 0);
-    store_pixel_tiles<NT>(acc, a, pix, valid, half);
+    store_pixel_tiles<NT>(acc, a, pix, valid, half, co_base);
 }
 
 template <int NT, int KIND>
@@ -820,7 +822,7 @@ void launch_stem_mfma(const ConvArgs& a, hipStream_t s) {
 template <int NT, int TAPS>
 void launch_down(const ConvArgs& a, hipStream_t s) {
     const int tiles_x = (a.w_out + 31) / 32, tiles_y = (a.h_out + 3) / 4;
-    const dim3 grid((unsigned)(tiles_x * tiles_y * a.n)), block(256);
+    const dim3 grid((unsigned)(tiles_x * tiles_y * a.n), (unsigned)(a.c_out / (NT * 32))), block(256);
     const size_t lds = (size_t)9 * 66 * 64 + (size_t)TAPS * NT * 32 * 64;
     const WgSide src = side_of(a);
     switch (a.src.kind) {
@@ -868,12 +870,11 @@ void launch_conv_mfma(const ConvArgs& a, hipStream_t s) {
     if (stem_mfma_ok(a)) { launch_stem_mfma(a, s); return; }
     if (a.stride == 1) {
         if (a.c_out == 32) launch_s1<1, 9>(a, s);
-        else if (a.c_out == 64) launch_s1<2, 9>(a, s);
-        else launch_s1<4, 3>(a, s);
+        else launch_s1<2, 9>(a, s);   // 64, or 128 as two workgroups of 64 output channels
     } else if (a.gather == 0) {
         if (a.c_out == 32) launch_down<1, 9>(a, s);
         else if (a.c_out == 64) launch_down<2, 9>(a, s);
-        else launch_down<4, 3>(a, s);
+        else launch_down<4, 3>(a, s);   // measured: the unsplit 128-channel form is the faster one here
     } else {
         if (a.c_out == 32) launch_up<1>(a, s);
         else launch_up<2>(a, s);
