@@ -347,20 +347,38 @@ __global__ __launch_bounds__(256) void wgrad_generic_kernel(WgradArgs a, int64_t
     if (ci + 1 < a.c_in && co + 1 < a.c_out) out[(size_t)(ci + 1) * a.c_out + co + 1] = acc11;
 }
 
-// out[i] = sum over splits of partials[split][i], in a fixed order: block (64 elements) x (16 split groups)
-__global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* partials, int splits, int64_t nw, float* out) {
-    __shared__ double sh[16][65];
-    const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    double s = 0.0;
-    if (i < nw)
-        for (int k = threadIdx.y; k < splits; k += 16) s += (double)partials[(size_t)k * nw + i];
-    sh[threadIdx.y][threadIdx.x] = s;
+// out[i] = sum over splits of partials[split][i], in a fixed order.  A workgroup owns 256 consecutive elements (64 lanes
+// x float4) and deals the splits round-robin to its 16 lane rows; each row sums its splits in order (double), then
+// the 16 rows are summed in order.  nw is a multiple of 4 for every filter this build has (3x3 and 5x5 with >= 4
+// channel products); the scalar tail handles anything else.
+__global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __restrict__ partials, int splits, int64_t nw, float* __restrict__ out) {
+    __shared__ double sh[16][64][4];
+    const int64_t i = ((int64_t)blockIdx.x * 64 + threadIdx.x) * 4;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (i + 3 < nw && (nw & 3) == 0) {
+#pragma unroll 4
+        for (int k = threadIdx.y; k < splits; k += 16) {
+            const float4 v = *reinterpret_cast<const float4*>(partials + (size_t)k * nw + i);
+            s0 += (double)v.x; s1 += (double)v.y; s2 += (double)v.z; s3 += (double)v.w;
+        }
+    } else {
+        for (int k = threadIdx.y; k < splits; k += 16) {
+            const float* row = partials + (size_t)k * nw;
+            if (i < nw) s0 += (double)row[i];
+            if (i + 1 < nw) s1 += (double)row[i + 1];
+            if (i + 2 < nw) s2 += (double)row[i + 2];
+            if (i + 3 < nw) s3 += (double)row[i + 3];
+        }
+    }
+    double* mine = sh[threadIdx.y][threadIdx.x];
+    mine[0] = s0; mine[1] = s1; mine[2] = s2; mine[3] = s3;
     __syncthreads();
-    if (threadIdx.y == 0 && i < nw) {
+    if (threadIdx.y < 4) {  // lane row e finishes element i + e
+        const int e = threadIdx.y;
         double t = 0.0;
 #pragma unroll
-        for (int g = 0; g < 16; ++g) t += sh[g][threadIdx.x];
-        out[i] = (float)t;
+        for (int g = 0; g < 16; ++g) t += sh[g][threadIdx.x][e];
+        if (i + e < nw) out[i + e] = (float)t;
     }
 }
 
@@ -1100,7 +1118,7 @@ void launch_wgrad_generic(const WgradArgs& a, hipStream_t s) {
 }
 
 void launch_reduce_partials(const float* partials, int splits, int64_t nw, float* out, hipStream_t s) {
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((nw + 63) / 64)), dim3(64, 16), 0, s, partials, splits, nw, out);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(64, 16), 0, s, partials, splits, nw, out);
     HIP_CHECK(hipGetLastError());
 }
 

@@ -183,6 +183,54 @@ __device__ __forceinline__ void stage_side(char* lds, const WgSide& s, int tid, 
     }
 }
 
+// The same staging split in two calls, for software-pipelined kernels: side_fetch issues EVERY global load of the side
+// into registers (nothing waits on them), side_commit — called one loop iteration later — runs the prologue and writes
+// the records to LDS; conv(raw, j) is the prologue of the thread's j-th chunk.
+template <int KIND, int ITEMS> struct SideRegs {
+    static constexpr int N = (ITEMS + 255) / 256;
+    RawChunk<KIND> raw[N];
+    unsigned okmask;
+};
+template <int KIND, int ITEMS, typename Geo>
+__device__ __forceinline__ void side_fetch(SideRegs<KIND, ITEMS>& R, const WgSide& s, int tid, const Geo& geo) {
+    const int c16 = tid & 3;
+    R.okmask = 0;
+#pragma unroll
+    for (int jj = 0; jj < SideRegs<KIND, ITEMS>::N; ++jj) {
+        const int item = min(tid + 256 * jj, ITEMS - 1);
+        size_t pix; int ch0;
+        const bool ok = geo(item >> 2, pix, ch0);
+        R.raw[jj] = side_load<KIND>(s, pix, ch0 + c16 * 8);
+        R.okmask |= (ok ? 1u : 0u) << jj;
+    }
+}
+template <int KIND, int ITEMS, typename Conv>
+__device__ __forceinline__ void side_commit(const SideRegs<KIND, ITEMS>& R, char* lds, int tid, const Conv& conv) {
+    const int c16 = tid & 3;
+#pragma unroll
+    for (int jj = 0; jj < SideRegs<KIND, ITEMS>::N; ++jj) {
+        const int item = tid + 256 * jj;
+        const int rec = item >> 2;
+        uint4 v = conv(R.raw[jj], jj);  // jj is a compile-time constant after unrolling
+        if (!((R.okmask >> jj) & 1u)) v = make_uint4(0u, 0u, 0u, 0u);
+        if (item < ITEMS) *reinterpret_cast<uint4*>(lds + rec * 64 + ((c16 ^ ((rec >> 2) & 3)) << 4)) = v;
+    }
+}
+// prologue of one 16-byte chunk with the per-channel constants given as pointers (registers or an LDS table)
+template <int KIND>
+__device__ __forceinline__ uint4 chunk_convert(const RawChunk<KIND>& r, const float* sa, const float* ta, const float* sb, const float* tb) {
+    if (KIND == SRC_RAW) return r.a;
+    float v[8];
+    affine8(r.a, sa, ta, v);
+    if (KIND == SRC_ACT2) {
+        float u[8];
+        affine8(r.b, sb, tb, u);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += u[j];
+    }
+    return make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
+}
+
 // weights of NTAPS taps for one 32-channel slab -> LDS records [tap][co][32 ci]; loads first, then writes
 template <int C_OUT, int NTAPS>
 __device__ __forceinline__ void stage_weights(char* lds_w, const bf16* wsrc, int t0, int c_red, int cc, int tid, int c_out_total = C_OUT, int co_base = 0) {
@@ -329,6 +377,7 @@ template <> struct WgGeom<2> { static constexpr int TH = 4, TW = 32, RECS = 9 * 
 
 __device__ __forceinline__ bf16x8 tr_read8(const char* base, int rec_first, int lane) {
     // this lane's share of a 16(k = pixel) x 32(channel) operand: records rec_first + 8*half + {0..7}, channel = lane & 31
+    // (records swizzled by their INDEX: 32-pixel-wide tiles, where index and x-coordinate agree mod 16)
     const int i16 = lane & 15, q = i16 >> 2, p = i16 & 3, cg = (lane >> 4) & 1, half = lane >> 5;
     s16x4 r[2];
 #pragma unroll
@@ -342,19 +391,130 @@ __device__ __forceinline__ bf16x8 tr_read8(const char* base, int rec_first, int 
     return __builtin_bit_cast(bf16x8, v);
 }
 
+// The same operand with the address arithmetic taken out of the inner loop.  The wgrad kernel swizzles a record by its
+// X-COORDINATE ((x >> 2) & 3, x = column in the patch row / parity plane / tile row) instead of its index, so the
+// swizzle of "16 consecutive pixels starting at column x_first" depends on the lane and on x_first mod 16 only — not
+// on the row.  tr_lane_offset is that lane-constant byte offset (read rr covers record offsets 8*half + 4*rr + q);
+// a k-step or tap row then only adds a compile-time constant, which the LDS instruction carries as its immediate.
+__device__ __forceinline__ int tr_lane_offset(int lane, int rr, int x_first) {
+    const int i16 = lane & 15, q = i16 >> 2, p = i16 & 3, cg = (lane >> 4) & 1, half = lane >> 5;
+    const int L = 8 * half + 4 * rr + q;
+    const int key = ((x_first + L) >> 2) & 3;
+    return L * 64 + ((((cg << 1) | (p >> 1)) ^ key) << 4) + ((p & 1) << 3);
+}
+__device__ __forceinline__ bf16x8 tr_read8_at(const char* a0, const char* a1) {
+    const s16x4 r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a0));
+    const s16x4 r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a1));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    s16x8 v = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+// k-steps KS0, KS0+1 of the wgrad MFMA phase (template recursion = fully unrolled with compile-time LDS offsets):
+// fragments of step ks+1 are requested before the MFMAs of step ks issue.
+template <int KS0, int KS, int TPW, int STRIDE>
+__device__ __forceinline__ void wg_ksteps(const char* ta0, const char* ta1, const char* (&pa0)[TPW], const char* (&pa1)[TPW],
+                                          bf16x8& tf0, bf16x8 (&pf0)[TPW], bf16x8& tf1, bf16x8 (&pf1)[TPW], f32x16 (&acc)[TPW]) {
+    if constexpr (KS0 < KS) {
+        {
+            constexpr int row = (KS0 + 1) >> 1, xh = ((KS0 + 1) & 1) << 4;
+            constexpr int timm = (row * 32 + xh) * 64, pimm = (STRIDE == 1 ? row * 34 + xh : row * 132 + xh) * 64;
+            tf1 = tr_read8_at(ta0 + timm, ta1 + timm);
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) pf1[i] = tr_read8_at(pa0[i] + pimm, pa1[i] + pimm);
+        }
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf0[i], tf0, acc[i], 0, 0, 0);
+        if constexpr (KS0 + 2 < KS) {
+            constexpr int row = (KS0 + 2) >> 1, xh = ((KS0 + 2) & 1) << 4;
+            constexpr int timm = (row * 32 + xh) * 64, pimm = (STRIDE == 1 ? row * 34 + xh : row * 132 + xh) * 64;
+            tf0 = tr_read8_at(ta0 + timm, ta1 + timm);
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) pf0[i] = tr_read8_at(pa0[i] + pimm, pa1[i] + pimm);
+        }
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf1[i], tf1, acc[i], 0, 0, 0);
+        wg_ksteps<KS0 + 2, KS, TPW, STRIDE>(ta0, ta1, pa0, pa1, tf0, pf0, tf1, pf1, acc);
+    }
+}
+
+template <int KIND>
+__device__ __forceinline__ RawChunk<KIND> side_load_at(const bf16* a, const bf16* b, int off) {
+    RawChunk<KIND> r;
+    r.a = *reinterpret_cast<const uint4*>(a + off);
+    if (KIND == SRC_ACT2) r.b = *reinterpret_cast<const uint4*>(b + off);
+    return r;
+}
+
 template <int NTC, int KP, int KT, int STRIDE>
-__global__ __launch_bounds__(256, (NTC == 4 ? 1 : 2)) void wgrad3x3_mfma_kernel(WgParams a, int tiles_x, int tiles_y, int total_tiles, int splits) {
+__global__ __launch_bounds__(256, 1) void wgrad3x3_mfma_kernel(WgParams a, int tiles_x, int tiles_y, int total_tiles, int splits) {
     using G = WgGeom<STRIDE>;
-    constexpr int TH = G::TH, TW = G::TW, TILE_PIX = TH * TW;
+    constexpr int TH = G::TH, TW = G::TW, TILE_PIX = TH * TW, KS = TILE_PIX / 16;
+    constexpr int P_ITEMS = G::RECS * 4, NP = (P_ITEMS + 255) / 256;   // patch chunks, per thread
+    constexpr int JPN = TILE_PIX / 64, NT_ = NTC * JPN;                // tile chunks per thread: JPN per 32-channel group
+    constexpr int BUF_BYTES = G::RECS * 64 + TILE_PIX * NTC * 64;
+    constexpr int TAB_BYTES = NTC * 32 * 4 * 4;            // the tile side's bn constants: [a_scale | a_shift | b_scale | b_shift][NTC*32]
+    constexpr bool DB = 2 * BUF_BYTES + TAB_BYTES <= 160 * 1024;  // two LDS buffers when they fit: one barrier per pixel tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* lds_p = smem;
-    char* lds_t = smem + G::RECS * 64;
     constexpr int TPW = (9 * NTC + 3) / 4;  // output tiles per wave
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, c16 = tid & 3;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: tile assignment below stays scalar
     const int slab = blockIdx.y, split = blockIdx.x;
     const int cc = slab * 32;
     const int nt_mine = wave % NTC;
+
+    // ---- per-channel bn constants: the patch side's 8 channels of this thread live in registers, the tile side's in LDS ----
+    float psa[8], pta[8], psb[8], ptb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        psa[j] = KP != SRC_RAW ? a.patch.a_scale[cc + c16 * 8 + j] : 0.f;
+        pta[j] = KP != SRC_RAW ? a.patch.a_shift[cc + c16 * 8 + j] : 0.f;
+        psb[j] = KP == SRC_ACT2 ? a.patch.b_scale[cc + c16 * 8 + j] : 0.f;
+        ptb[j] = KP == SRC_ACT2 ? a.patch.b_shift[cc + c16 * 8 + j] : 0.f;
+    }
+    float* tab = reinterpret_cast<float*>(smem + (DB ? 2 : 1) * BUF_BYTES);
+    if (KT != SRC_RAW) {
+        for (int i = tid; i < NTC * 32; i += 256) {
+            tab[i] = a.tile.a_scale[i];
+            tab[NTC * 32 + i] = a.tile.a_shift[i];
+            tab[2 * NTC * 32 + i] = KT == SRC_ACT2 ? a.tile.b_scale[i] : 0.f;
+            tab[3 * NTC * 32 + i] = KT == SRC_ACT2 ? a.tile.b_shift[i] : 0.f;
+        }
+        __syncthreads();
+    }
+
+    // ---- staging geometry, fixed per thread for the whole kernel ----
+    // patch chunk jj = record (tid >> 2) + 64 jj -> (row py, column px); packed as py | px << 8.  Its LDS slot is
+    // swizzled by the column within the row (stride 1) or within the parity plane (stride 2).
+    int pgeo[NP], pdst[NP];
+#pragma unroll
+    for (int jj = 0; jj < NP; ++jj) {
+        const int rec = min((tid >> 2) + 64 * jj, G::RECS - 1);
+        int py, px, key;
+        if (STRIDE == 1) { py = rec / 34; px = rec - py * 34; key = (px >> 2) & 3; }
+        else { py = rec / 66; const int rem = rec - py * 66; const int par = rem >= 33; const int u = rem - 33 * par; px = 2 * u + par; key = (u >> 2) & 3; }
+        pgeo[jj] = py | (px << 8);
+        pdst[jj] = rec * 64 + ((c16 ^ key) << 4);
+    }
+    // tile chunk jj = 32-channel group jj / JPN, row (tid >> 7) + 2 (jj % JPN), column (tid >> 2) & 31
+    const int t_x = (tid >> 2) & 31, t_row0 = tid >> 7;
+    const int tdst0 = G::RECS * 64 + (t_row0 * 32 + t_x) * 64 + ((c16 ^ ((t_x >> 2) & 3)) << 4);
+
+    // ---- this wave's output tiles j = wave + 4i -> (tap, nt_mine); a wave short of tiles repeats its previous one
+    //      (never written), which keeps the MFMA phase free of branches.  pofs / tofs: lane part of the operand addresses ----
+    int pofs[TPW][2], tofs[2];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        const int j = wave + 4 * i, jc = j < 9 * NTC ? j : j - 4;
+        const int tap = jc / NTC, ky = tap / 3, kx = tap - ky * 3;
+        const int first = STRIDE == 1 ? ky * 34 + kx : (ky * 2 + (kx & 1)) * 33 + (kx >> 1);
+        const int x_first = STRIDE == 1 ? kx : (kx >> 1);
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) pofs[i][rr] = first * 64 + tr_lane_offset(lane, rr, x_first);
+    }
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) tofs[rr] = G::RECS * 64 + nt_mine * (TILE_PIX * 64) + tr_lane_offset(lane, rr, 0);
 
     f32x16 acc[TPW];
 #pragma unroll
@@ -362,44 +522,75 @@ __global__ __launch_bounds__(256, (NTC == 4 ? 1 : 2)) void wgrad3x3_mfma_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-    for (int tile = split; tile < total_tiles; tile += splits) {
+    // Software pipeline over this workgroup's pixel tiles: the global loads of tile i+1 are in flight (in registers)
+    // while the MFMAs of tile i run; the prologue + LDS write of tile i+1 follow.  Pixels outside a tensor are zeros.
+    RawChunk<KP> praw[NP];
+    RawChunk<KT> traw[NT_];
+    unsigned pok = 0, tok = 0;
+    const size_t p_plane = (size_t)a.patch.h * a.patch.w * a.patch.c, t_plane = (size_t)a.tile.h * a.tile.w * a.tile.c;  // < 2^31 elements (host check)
+    auto fetch = [&](int tile) {
         const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
         const int x0 = tx * TW, y0 = ty * TH;
-        __syncthreads();
-        // ---- patch slab, then the tile ([nt][pixel][32 channels]); pixels outside a tensor contribute zeros ----
-        stage_side<KP, G::RECS * 4, (NTC == 4 ? 3 : 5)>(lds_p, a.patch, tid, [&](int rec, size_t& pix, int& ch0) {
-            int py, pxx;
-            if (STRIDE == 1) { py = rec / 34; pxx = rec - py * 34; }
-            else { py = rec / 66; const int rem = rec - py * 66; const int par = rem >= 33; pxx = 2 * (rem - 33 * par) + par; }
-            const int iy = STRIDE * y0 + G::ORIGIN + py, ix = STRIDE * x0 + G::ORIGIN + pxx;
-            pix = ((size_t)n * a.patch.h + min(max(iy, 0), a.patch.h - 1)) * a.patch.w + min(max(ix, 0), a.patch.w - 1);
-            ch0 = cc;
-            return iy >= 0 && iy < a.patch.h && ix >= 0 && ix < a.patch.w;
-        });
-        stage_side<KT, TILE_PIX * NTC * 4, 4>(lds_t, a.tile, tid, [&](int rec, size_t& pix, int& ch0) {
-            const int nt = rec / TILE_PIX, pt = rec - nt * TILE_PIX;
-            const int oy = y0 + pt / TW, ox = x0 + (pt % TW);
-            pix = ((size_t)n * a.tile.h + min(oy, a.tile.h - 1)) * a.tile.w + min(ox, a.tile.w - 1);
-            ch0 = nt * 32;
-            return oy < a.tile.h && ox < a.tile.w;
-        });
-        __syncthreads();
-#pragma unroll 2
-        for (int ks = 0; ks < TILE_PIX / 16; ++ks) {
-            const int row = ks >> 1, xh = (ks & 1) << 4;
-            const bf16x8 tf = tr_read8(lds_t + nt_mine * (TILE_PIX * 64), row * TW + xh, lane);
+        const bf16* pa = a.patch.a + (size_t)n * p_plane;
+        const bf16* pb = KP == SRC_ACT2 ? a.patch.b + (size_t)n * p_plane : nullptr;
+        const int yb = STRIDE * y0 + G::ORIGIN, xb = STRIDE * x0 + G::ORIGIN;
+        pok = 0;
 #pragma unroll
-            for (int i = 0; i < TPW; ++i) {
-                const int j = wave + 4 * i;
-                if (j < 9 * NTC) {
-                    const int tap = j / NTC;
-                    const int ky = tap / 3, kx = tap - ky * 3;
-                    const int first = STRIDE == 1 ? (row + ky) * 34 + xh + kx : ((2 * row + ky) * 2 + (kx & 1)) * 33 + xh + (kx >> 1);
-                    const bf16x8 pf = tr_read8(lds_p, first, lane);
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, tf, acc[i], 0, 0, 0);
-                }
-            }
+        for (int jj = 0; jj < NP; ++jj) {
+            const int iy = yb + (pgeo[jj] & 255), ix = xb + (pgeo[jj] >> 8);
+            const int cy = min(max(iy, 0), a.patch.h - 1), cx = min(max(ix, 0), a.patch.w - 1);
+            praw[jj] = side_load_at<KP>(pa, pb, (cy * a.patch.w + cx) * a.patch.c + cc + c16 * 8);
+            pok |= ((iy == cy && ix == cx) ? 1u : 0u) << jj;
         }
+        const bf16* ta = a.tile.a + (size_t)n * t_plane;
+        const bf16* tb = KT == SRC_ACT2 ? a.tile.b + (size_t)n * t_plane : nullptr;
+        const int ox = x0 + t_x, cx = min(ox, a.tile.w - 1);
+        tok = 0;
+#pragma unroll
+        for (int jj = 0; jj < NT_; ++jj) {
+            const int oy = y0 + t_row0 + 2 * (jj % JPN), cy = min(oy, a.tile.h - 1);
+            traw[jj] = side_load_at<KT>(ta, tb, (cy * a.tile.w + cx) * a.tile.c + (jj / JPN) * 32 + c16 * 8);
+            tok |= ((oy == cy && ox == cx) ? 1u : 0u) << jj;
+        }
+    };
+
+    int tile = split;
+    if (tile < total_tiles) fetch(tile);
+    int buf = 0;
+    for (; tile < total_tiles; tile += splits) {
+        char* lbuf = smem + buf * BUF_BYTES;
+        if (!DB) __syncthreads();  // single buffer: every wave is done reading the previous tile
+        // ---- prologue + LDS write of the fetched tile ----
+#pragma unroll
+        for (int jj = 0; jj < NP; ++jj) {
+            uint4 v = chunk_convert<KP>(praw[jj], psa, pta, psb, ptb);
+            if (!((pok >> jj) & 1u)) v = make_uint4(0u, 0u, 0u, 0u);
+            if ((tid >> 2) + 64 * jj < G::RECS) *reinterpret_cast<uint4*>(lbuf + pdst[jj]) = v;
+        }
+#pragma unroll
+        for (int jj = 0; jj < NT_; ++jj) {
+            const float* t0 = tab + (jj / JPN) * 32 + c16 * 8;
+            uint4 v = chunk_convert<KT>(traw[jj], t0, t0 + NTC * 32, t0 + 2 * NTC * 32, t0 + 3 * NTC * 32);
+            if (!((tok >> jj) & 1u)) v = make_uint4(0u, 0u, 0u, 0u);
+            *reinterpret_cast<uint4*>(lbuf + tdst0 + ((jj / JPN) * TILE_PIX + 2 * (jj % JPN) * 32) * 64) = v;
+        }
+        __syncthreads();
+        if (tile + splits < total_tiles) fetch(tile + splits);
+
+        // ---- MFMA phase: the fragments of k-step ks+1 are read from LDS while the MFMAs of k-step ks issue; every
+        //      address is (lane offset computed once) + (compile-time constant) ----
+        const char* pa0[TPW];
+        const char* pa1[TPW];
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) { pa0[i] = lbuf + pofs[i][0]; pa1[i] = lbuf + pofs[i][1]; }
+        const char* ta0 = lbuf + tofs[0];
+        const char* ta1 = lbuf + tofs[1];
+        bf16x8 tf0, tf1, pf0[TPW], pf1[TPW];
+        tf0 = tr_read8_at(ta0, ta1);  // k-step 0
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) pf0[i] = tr_read8_at(pa0[i], pa1[i]);
+        wg_ksteps<0, KS, TPW, STRIDE>(ta0, ta1, pa0, pa1, tf0, pf0, tf1, pf1, acc);
+        if (DB) buf ^= 1;
     }
     // ---- one partial per workgroup, laid out as dw: [tap][ci][co] ----
     const size_t nw = (size_t)9 * a.c_in * a.c_out;
@@ -536,6 +727,8 @@ WgPlan wgrad_plan_mfma(const WgradArgs& a) {
     p.tiles_y = (lr_h + th - 1) / th;
     p.total = p.tiles_x * p.tiles_y * a.n;
     p.lds = (size_t)(a.stride == 1 ? 340 : 594) * 64 + (size_t)p.ntc * th * 32 * 64;
+    const size_t tab = (size_t)p.ntc * 32 * 16;            // the tile side's bn constants
+    p.lds = (2 * p.lds + tab <= 160 * 1024 ? 2 * p.lds : p.lds) + tab;  // double-buffered when it fits (the kernel makes the same decision)
     // one workgroup per CU: these kernels share the chip with the backward-data chain (second stream), and every
     // workgroup writes a full partial, so fewer workgroups also means less partial-sum traffic
     const int target = 256;
@@ -888,6 +1081,8 @@ bool mfma_wgrad_supported(const WgradArgs& a) {
     const bool s2 = a.stride == 2 && a.pad == 0;
     if (!s1 && !s2) return false;
     const int c_tile = a.gather == 1 ? a.c_in : a.c_out, c_patch = a.gather == 1 ? a.c_out : a.c_in;
+    const int64_t plane_in = (int64_t)a.h_in * a.w_in * a.c_in, plane_out = (int64_t)a.h_out * a.w_out * a.c_out;
+    if (plane_in >= (1ll << 31) || plane_out >= (1ll << 31)) return false;  // the kernel indexes within one image with 32-bit offsets
     return c_patch % 32 == 0 && (c_tile == 32 || c_tile == 64 || c_tile == 128);
 }
 
