@@ -624,73 +624,135 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_mfma_kernel(WgParams a, int t
 template <int CIN>
 __global__ __launch_bounds__(256, 2) void wgrad_stem_mfma_kernel(WgradArgs a, WgSide dy_side, int tiles_x, int tiles_y, int total_tiles, int splits) {
     constexpr int ROWS = 25 * CIN, RT = (ROWS + 31) / 32, PLANE = 12 * 5 * 64;  // bytes of one channel plane
+    constexpr int NI = (12 * 36 * CIN + 255) / 256;   // image bytes per thread
+    constexpr int BUF = 256 * 64 + (CIN + 1) * PLANE;  // one buffer: dy tile (256 pixel records) + CIN planes + an all-zero plane
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* lds_g = smem;                       // 256 pixel records of 64 B (dy tile)
-    char* lds_a = smem + 256 * 64;            // (CIN + 1) planes; the last one stays zero
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, col = lane & 31, c16 = tid & 3;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    for (int i = tid; i < PLANE / 4; i += 256) reinterpret_cast<unsigned*>(lds_a + CIN * PLANE)[i] = 0u;
+    for (int i = tid; i < PLANE / 4; i += 256) {  // the zero planes, read by the rows beyond 25*CIN
+        reinterpret_cast<unsigned*>(smem + 256 * 64 + CIN * PLANE)[i] = 0u;
+        reinterpret_cast<unsigned*>(smem + BUF + 256 * 64 + CIN * PLANE)[i] = 0u;
+    }
+
+    // ---- operand addresses: lane part once, k-step part as compile-time constants.  A k-step = 16 pixels of one tile
+    //      row; wave w owns rows 2w, 2w+1 ----
     int a_off[RT];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
         const int r = rt * 32 + col;
         const int tap = r / CIN, ci = r - tap * CIN;
         const int ky = tap / 5, kx = tap - ky * 5;
-        a_off[rt] = r < ROWS ? ci * PLANE + (ky * 5 + kx) * 64 + half * 16 : CIN * PLANE + half * 16;
+        a_off[rt] = 256 * 64 + (r < ROWS ? ci * PLANE + (ky * 5 + kx) * 64 : CIN * PLANE) + half * 16 + wave * 2 * 320;
     }
+    int g_off[2];
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) g_off[rr] = wave * 2 * 32 * 64 + tr_lane_offset(lane, rr, 0);
+
+    // ---- staging geometry, fixed per thread: image byte jj -> (channel, column, row) of the 12 x 36 patch; dy chunk jj ->
+    //      row (tid >> 7) + 2 jj, column (tid >> 2) & 31 ----
+    int igeo[NI];
+#pragma unroll
+    for (int jj = 0; jj < NI; ++jj) {
+        const int i = min(tid + 256 * jj, 12 * 36 * CIN - 1);
+        const int c = i % CIN, px = (i / CIN) % 36, py = i / (CIN * 36);
+        igeo[jj] = c | (px << 4) | (py << 12);
+    }
+    const int t_x = (tid >> 2) & 31, t_row0 = tid >> 7;
+    const int gdst0 = (t_row0 * 32 + t_x) * 64 + ((c16 ^ ((t_x >> 2) & 3)) << 4);
+
     f32x16 acc[RT];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;
 
-    for (int tile = blockIdx.x; tile < total_tiles; tile += splits) {
+    // ---- software pipeline over this workgroup's tiles: loads of tile i+1 fly while the MFMAs of tile i run ----
+    unsigned char ipx[NI];
+    unsigned iok = 0, gok = 0;
+    uint4 graw[4];
+    const bf16* dyp = reinterpret_cast<const bf16*>(a.dy);
+    const size_t dy_plane = (size_t)a.h_out * a.w_out * 32;
+    auto fetch = [&](int tile) {
         const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
         const int x0 = tx * 32, y0 = ty * 8;
-        __syncthreads();
-        // image patch (12 x 36 x CIN) -> five shifted bf16 copies per row
-        for (int i = tid; i < 12 * 36 * CIN; i += 256) {
-            const int c = i % CIN, px = (i / CIN) % 36, py = i / (CIN * 36);
-            const int iy = y0 - 2 + py, ix = x0 - 2 + px;
-            float v = 0.f;
-            if (iy >= 0 && iy < a.h_in && ix >= 0 && ix < a.w_in) {
-                const int sy = min(max(a.src.img_top + iy, 0), a.src.img_h - 1), sx = min(max(a.src.img_left + ix, 0), a.src.img_w - 1);
-                v = (float)a.src.img[(size_t)n * a.src.img_sample_stride + ((size_t)sy * a.src.img_w + sx) * CIN + c] * (1.0f / 256.0f);
-            }
-            const bf16 b = (bf16)v;
+        const uint8_t* img = a.src.img + (size_t)n * a.src.img_sample_stride;
+        iok = 0;
 #pragma unroll
-            for (int kx = 0; kx < 5; ++kx) {
-                const int xx = px - kx;
-                if (xx >= 0 && xx < 32) *reinterpret_cast<bf16*>(lds_a + c * PLANE + (py * 5 + kx) * 64 + xx * 2) = b;
+        for (int jj = 0; jj < NI; ++jj) {
+            const int c = igeo[jj] & 15, px = (igeo[jj] >> 4) & 255, py = igeo[jj] >> 12;
+            const int iy = y0 - 2 + py, ix = x0 - 2 + px;
+            const int sy = min(max(a.src.img_top + iy, 0), a.src.img_h - 1), sx = min(max(a.src.img_left + ix, 0), a.src.img_w - 1);
+            ipx[jj] = img[((size_t)sy * a.src.img_w + sx) * CIN + c];
+            iok |= ((iy >= 0 && iy < a.h_in && ix >= 0 && ix < a.w_in) ? 1u : 0u) << jj;
+        }
+        const bf16* g = dyp + (size_t)n * dy_plane;
+        const int ox = x0 + t_x, cx = min(ox, a.w_out - 1);
+        gok = 0;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int oy = y0 + t_row0 + 2 * jj, cy = min(oy, a.h_out - 1);
+            graw[jj] = *reinterpret_cast<const uint4*>(g + (cy * a.w_out + cx) * 32 + c16 * 8);
+            gok |= ((oy == cy && ox == cx) ? 1u : 0u) << jj;
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile < total_tiles) fetch(tile);
+    int buf = 0;
+    for (; tile < total_tiles; tile += splits) {
+        char* lbuf = smem + buf * BUF;
+        // image patch (12 x 36 x CIN) -> five shifted bf16 copies per row; u8 / 256 is exact in bf16
+#pragma unroll
+        for (int jj = 0; jj < NI; ++jj) {
+            const int c = igeo[jj] & 15, px = (igeo[jj] >> 4) & 255, py = igeo[jj] >> 12;
+            const float v = ((iok >> jj) & 1u) ? (float)ipx[jj] * (1.0f / 256.0f) : 0.f;
+            const bf16 b = (bf16)v;
+            if (tid + 256 * jj < 12 * 36 * CIN) {
+#pragma unroll
+                for (int kx = 0; kx < 5; ++kx) {
+                    const int xx = px - kx;
+                    if (xx >= 0 && xx < 32) *reinterpret_cast<bf16*>(lbuf + 256 * 64 + c * PLANE + (py * 5 + kx) * 64 + xx * 2) = b;
+                }
             }
         }
-        stage_side<SRC_RAW, 256 * 4, 4>(lds_g, dy_side, tid, [&](int rec, size_t& pix, int& ch0) {
-            const int oy = y0 + (rec >> 5), ox = x0 + (rec & 31);
-            pix = ((size_t)n * a.h_out + min(oy, a.h_out - 1)) * a.w_out + min(ox, a.w_out - 1);
-            ch0 = 0;
-            return oy < a.h_out && ox < a.w_out;
-        });
-        __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int ks = wave * 4 + i;
-            const int row = ks >> 1, xh = (ks & 1) << 4;
-            const bf16x8 gf = tr_read8(lds_g, row * 32 + xh, lane);
+        for (int jj = 0; jj < 4; ++jj) {
+            const uint4 v = ((gok >> jj) & 1u) ? graw[jj] : make_uint4(0u, 0u, 0u, 0u);
+            *reinterpret_cast<uint4*>(lbuf + gdst0 + jj * (2 * 32 * 64)) = v;
+        }
+        __syncthreads();  // two buffers: the writes above cannot race with a slower wave still reading the other one
+        if (tile + splits < total_tiles) fetch(tile + splits);
+        const char* g0 = lbuf + g_off[0];
+        const char* g1 = lbuf + g_off[1];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {  // k-steps 4*wave + i: row 2*wave + (i >> 1), columns 16*(i & 1)..
+            const int gimm = ((i >> 1) * 32 + ((i & 1) << 4)) * 64, aimm = (i >> 1) * 320 + ((i & 1) << 4) * 2;
+            const bf16x8 gf = tr_read8_at(g0 + gimm, g1 + gimm);
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
-                const bf16x8 af = *reinterpret_cast<const bf16x8*>(lds_a + a_off[rt] + row * 320 + xh * 2);
+                const bf16x8 af = *reinterpret_cast<const bf16x8*>(lbuf + a_off[rt] + aimm);
                 acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, gf, acc[rt], 0, 0, 0);
             }
         }
+        buf ^= 1;
     }
-    float* out = a.partials + ((size_t)blockIdx.x * 4 + wave) * ROWS * 32;
+
+    // ---- sum the four waves' accumulators through LDS (fixed order) and write ONE partial per workgroup ----
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);  // [wave][rt][r][lane], 4 * RT * 16 * 64 floats <= 2 * BUF
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (row < ROWS) out[row * 32 + col] = acc[rt][r];
-        }
+        for (int r = 0; r < 16; ++r) red[((wave * RT + rt) * 16 + r) * 64 + lane] = acc[rt][r];
+    __syncthreads();
+    float* out = a.partials + (size_t)blockIdx.x * ROWS * 32;
+    for (int e = tid; e < RT * 16 * 64; e += 256) {
+        const int l = e & 63, r = (e >> 6) & 15, rt = e >> 10;
+        const float sum = ((red[e] + red[RT * 1024 + e]) + red[2 * RT * 1024 + e]) + red[3 * RT * 1024 + e];
+        const int row = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        if (row < ROWS) out[row * 32 + (l & 31)] = sum;
+    }
 }
 
 bool stem_wgrad_mfma_ok(const WgradArgs& a) {
@@ -699,17 +761,18 @@ bool stem_wgrad_mfma_ok(const WgradArgs& a) {
 }
 int stem_wgrad_mfma_blocks(const WgradArgs& a) {
     const int tiles = ((a.w_out + 31) / 32) * ((a.h_out + 7) / 8) * a.n;
-    return std::max(1, std::min(tiles, 256));
+    static const int target = getenv("ANH_STEM_WGRAD_BLOCKS") ? atoi(getenv("ANH_STEM_WGRAD_BLOCKS")) : 512;
+    return std::max(1, std::min(tiles, target));
 }
 void launch_wgrad_stem_mfma(const WgradArgs& a, hipStream_t s) {
     const int tiles_x = (a.w_out + 31) / 32, tiles_y = (a.h_out + 7) / 8;
     const int total = tiles_x * tiles_y * a.n, blocks = stem_wgrad_mfma_blocks(a);
     const WgSide dy{reinterpret_cast<const bf16*>(a.dy), nullptr, nullptr, nullptr, nullptr, nullptr, a.h_out, a.w_out, 32};
-    const size_t lds = 256 * 64 + (size_t)(a.c_in + 1) * 12 * 5 * 64;
+    const size_t lds = 2 * (256 * 64 + (size_t)(a.c_in + 1) * 12 * 5 * 64);  // two buffers, each with its zero plane
     if (a.c_in == 3) hipLaunchKernelGGL((wgrad_stem_mfma_kernel<3>), dim3(blocks), dim3(256), lds, s, a, dy, tiles_x, tiles_y, total, blocks);
     else hipLaunchKernelGGL((wgrad_stem_mfma_kernel<1>), dim3(blocks), dim3(256), lds, s, a, dy, tiles_x, tiles_y, total, blocks);
     HIP_CHECK(hipGetLastError());
-    launch_reduce_partials(a.partials, blocks * 4, (int64_t)25 * a.c_in * 32, a.dw, s);
+    launch_reduce_partials(a.partials, blocks, (int64_t)25 * a.c_in * 32, a.dw, s);
 }
 
 struct WgPlan { int stride, ntc, slabs, tiles_x, tiles_y, total, splits; size_t lds; bool cont; };
@@ -1087,7 +1150,7 @@ bool mfma_wgrad_supported(const WgradArgs& a) {
 }
 
 int64_t wgrad_mfma_scratch_floats(const WgradArgs& a) {
-    if (stem_wgrad_mfma_ok(a)) return (int64_t)stem_wgrad_mfma_blocks(a) * 4 * 25 * a.c_in * 32;
+    if (stem_wgrad_mfma_ok(a)) return (int64_t)stem_wgrad_mfma_blocks(a) * 25 * a.c_in * 32;
     return (int64_t)wgrad_plan_mfma(a).splits * 9 * a.c_in * a.c_out;
 }
 
