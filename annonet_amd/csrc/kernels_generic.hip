@@ -55,6 +55,23 @@ template <> __device__ __forceinline__ void load8<bf16>(const bf16* p, float v[8
         v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
     }
 }
+// eight storage elements kept RAW in registers (a prefetched value costs 4 VGPRs in bf16), converted on use
+template <typename T> struct Raw8;
+template <> struct Raw8<float> { float4 a, b; };
+template <> struct Raw8<bf16> { uint4 a; };
+__device__ __forceinline__ Raw8<float> raw_load8(const float* p) { return Raw8<float>{*reinterpret_cast<const float4*>(p), *reinterpret_cast<const float4*>(p + 4)}; }
+__device__ __forceinline__ Raw8<bf16> raw_load8(const bf16* p) { return Raw8<bf16>{*reinterpret_cast<const uint4*>(p)}; }
+__device__ __forceinline__ void raw_to_float(const Raw8<float>& r, float v[8]) {
+    v[0] = r.a.x; v[1] = r.a.y; v[2] = r.a.z; v[3] = r.a.w; v[4] = r.b.x; v[5] = r.b.y; v[6] = r.b.z; v[7] = r.b.w;
+}
+__device__ __forceinline__ void raw_to_float(const Raw8<bf16>& r, float v[8]) {
+    const unsigned w[4] = {r.a.x, r.a.y, r.a.z, r.a.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[2 * i] = __uint_as_float(w[i] << 16);
+        v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+}
 template <typename T> __device__ __forceinline__ void store8(T* p, const float v[8]);
 template <> __device__ __forceinline__ void store8<float>(float* p, const float v[8]) {
     *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
@@ -510,8 +527,8 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* y, int64_t pixel
     for (int ch = tid; ch < c; ch += cx * rows) {
         double s = 0, q = 0;
         for (int r = 0; r < rows; ++r) { s += sh[(r * c + ch) * 2]; q += sh[(r * c + ch) * 2 + 1]; }
-        partials[((size_t)blockIdx.x * c + ch) * 2] = s;
-        partials[((size_t)blockIdx.x * c + ch) * 2 + 1] = q;
+        partials[((size_t)ch * 2) * gridDim.x + blockIdx.x] = s;
+        partials[((size_t)ch * 2 + 1) * gridDim.x + blockIdx.x] = q;
     }
 }
 
@@ -521,7 +538,9 @@ __global__ __launch_bounds__(64) void bn_finalize_kernel(const double* partials,
                                                          float* rmean, float* rvar, double af, double unbias) {
     const int ch = blockIdx.x;
     double s = 0, q = 0;
-    for (int b = threadIdx.x; b < blocks; b += 64) { s += partials[((size_t)b * c + ch) * 2]; q += partials[((size_t)b * c + ch) * 2 + 1]; }
+    const double* ps = partials + (size_t)ch * 2 * blocks;  // [channel][sum | sum of squares][workgroup]: contiguous per channel
+#pragma unroll 8
+    for (int b = threadIdx.x; b < blocks; b += 64) { s += ps[b]; q += ps[blocks + b]; }
     s = wave_sum(s); q = wave_sum(q);
     if (threadIdx.x != 0) return;
     const double m = s / (double)pixels;
@@ -570,8 +589,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* da, const T
     for (int ch = tid; ch < c; ch += cx * rows) {
         double g = 0, b = 0;
         for (int r = 0; r < rows; ++r) { g += sh[(r * c + ch) * 2]; b += sh[(r * c + ch) * 2 + 1]; }
-        partials[((size_t)blockIdx.x * c + ch) * 2] = g;
-        partials[((size_t)blockIdx.x * c + ch) * 2 + 1] = b;
+        partials[((size_t)ch * 2) * gridDim.x + blockIdx.x] = g;
+        partials[((size_t)ch * 2 + 1) * gridDim.x + blockIdx.x] = b;
     }
 }
 
@@ -579,7 +598,9 @@ __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const double* parti
                                                              float* dgamma, float* dbeta, float* coef) {
     const int ch = blockIdx.x;
     double g = 0, b = 0;
-    for (int k = threadIdx.x; k < blocks; k += 64) { g += partials[((size_t)k * c + ch) * 2]; b += partials[((size_t)k * c + ch) * 2 + 1]; }
+    const double* ps = partials + (size_t)ch * 2 * blocks;
+#pragma unroll 8
+    for (int k = threadIdx.x; k < blocks; k += 64) { g += ps[k]; b += ps[blocks + k]; }
     g = wave_sum(g); b = wave_sum(b);
     if (threadIdx.x != 0) return;
     dgamma[ch] = (float)g; dbeta[ch] = (float)b;
@@ -629,7 +650,7 @@ __global__ __launch_bounds__(256) void bn_stats_vec_kernel(const T* y, int64_t p
         const int g = ch >> 3, j = ch & 7;
         double acc = 0;
         for (int r = 0; r < px_step; ++r) acc += sh[r * groups + g][which * 8 + j];
-        partials[((size_t)blockIdx.x * c + ch) * 2 + which] = acc;
+        partials[((size_t)ch * 2 + which) * gridDim.x + blockIdx.x] = acc;
     }
 }
 
@@ -666,7 +687,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_vec_kernel(const T* da, con
         const int g = ch >> 3, j = ch & 7;
         double acc = 0;
         for (int r = 0; r < px_step; ++r) acc += sh[r * groups + g][which * 8 + j];
-        partials[((size_t)blockIdx.x * c + ch) * 2 + which] = acc;
+        partials[((size_t)ch * 2 + which) * gridDim.x + blockIdx.x] = acc;
     }
 }
 
@@ -799,12 +820,13 @@ __global__ __launch_bounds__(256) void head_train_kernel(HeadArgs a) {
     constexpr int C = kHeadC, KM = kHeadKMax;
     const int K = a.k;
     const int sub = threadIdx.x & 3, c0 = sub * 8;
-    float w[8][KM], wt[KM][8], bias[KM], sa[8], ta[8], sb[8], tb[8];
+    // w_tm[ci][k] and w_km[k][ci] are two layouts of the same filter: one register copy serves forward and backward-data
+    float w[8][KM], bias[KM], sa[8], ta[8], sb[8], tb[8];
 #pragma unroll
     for (int k = 0; k < KM; ++k) {
         bias[k] = k < K ? a.bias[k] : 0.f;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) { w[c][k] = k < K ? a.w_tm[(c0 + c) * K + k] : 0.f; wt[k][c] = k < K ? a.w_km[k * C + c0 + c] : 0.f; }
+        for (int c = 0; c < 8; ++c) w[c][k] = k < K ? a.w_tm[(c0 + c) * K + k] : 0.f;
     }
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
@@ -823,14 +845,25 @@ __global__ __launch_bounds__(256) void head_train_kernel(HeadArgs a) {
     const T* xb = reinterpret_cast<const T*>(a.src.b);
     T* da = reinterpret_cast<T*>(a.da);
     const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 2;
-    for (int64_t p = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2; p < a.pixels; p += stride) {
+
+    // Two pixels per iteration, and the loads of the NEXT two are issued (unconditionally, from clamped indices) before
+    // the current two are processed: four pixel records per thread in flight keep HBM busy at 2 waves per SIMD.
+    struct Pre { Raw8<T> xa, xb; uint16_t y; float wgt; };
+    auto issue = [&](int64_t p, Pre& r) {
+        const int64_t pc = min(p, a.pixels - 1);
+        r.xa = raw_load8(xa + (size_t)pc * C + c0);
+        if (KIND == SRC_ACT2) r.xb = raw_load8(xb + (size_t)pc * C + c0);
+        r.y = a.labels[pc];
+        r.wgt = a.weights[pc];
+    };
+    auto process = [&](int64_t p, const Pre& r) {
         float x[8];
-        load8<T>(xa + (size_t)p * C + c0, x);
+        raw_to_float(r.xa, x);
 #pragma unroll
         for (int c = 0; c < 8; ++c) x[c] = relu_affine(x[c], sa[c], ta[c]);
         if (KIND == SRC_ACT2) {
             float u[8];
-            load8<T>(xb + (size_t)p * C + c0, u);
+            raw_to_float(r.xb, u);
 #pragma unroll
             for (int c = 0; c < 8; ++c) x[c] += relu_affine(u[c], sb[c], tb[c]);
         }
@@ -850,7 +883,7 @@ __global__ __launch_bounds__(256) void head_train_kernel(HeadArgs a) {
 #pragma unroll
             for (int k = 0; k < KM; ++k) if (k < K) a.logits[(size_t)p * K + k] = z[k];
         }
-        const uint16_t y = a.labels[p];
+        const uint16_t y = r.y;
         float g[KM];
 #pragma unroll
         for (int k = 0; k < KM; ++k) g[k] = 0.f;
@@ -861,7 +894,7 @@ __global__ __launch_bounds__(256) void head_train_kernel(HeadArgs a) {
             float e[KM], sum = 0.f;
 #pragma unroll
             for (int k = 0; k < KM; ++k) { e[k] = k < K ? expf(z[k] - m) : 0.f; sum += e[k]; }
-            const float sw = (float)a.scale * a.weights[p];
+            const float sw = (float)a.scale * r.wgt;
 #pragma unroll
             for (int k = 0; k < KM; ++k) if (k < K) {
                 const float pk = e[k] / sum;
@@ -874,7 +907,7 @@ __global__ __launch_bounds__(256) void head_train_kernel(HeadArgs a) {
         for (int c = 0; c < 8; ++c) {
             float acc = 0.f;
 #pragma unroll
-            for (int k = 0; k < KM; ++k) acc = fmaf(g[k], wt[k][c], acc);
+            for (int k = 0; k < KM; ++k) acc = fmaf(g[k], w[c][k], acc);
             dx[c] = acc;
 #pragma unroll
             for (int k = 0; k < KM; ++k) dw[c][k] = fmaf(x[c], g[k], dw[c][k]);
@@ -884,6 +917,17 @@ __global__ __launch_bounds__(256) void head_train_kernel(HeadArgs a) {
             for (int k = 0; k < KM; ++k) db[k] += g[k];
         }
         store8<T>(da + (size_t)p * C + c0, dx);
+    };
+    int64_t p = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+    Pre r0, r1;
+    issue(p, r0);
+    issue(p + stride, r1);
+    for (; p < a.pixels; p += 2 * stride) {
+        const Pre q0 = r0, q1 = r1;
+        issue(p + 2 * stride, r0);
+        issue(p + 3 * stride, r1);
+        process(p, q0);
+        if (p + stride < a.pixels) process(p + stride, q1);  // the four lanes of a pixel agree on this branch
     }
     // lanes with equal `sub` hold the same (channel, class) slots: fold them (offsets 4..32 keep `sub`), then across waves
     __shared__ double red[4][1 + KM + C * KM];
@@ -910,7 +954,7 @@ __global__ __launch_bounds__(256) void head_train_kernel(HeadArgs a) {
         int src;
         if (sidx <= K) src = sidx;  // loss, db[k]
         else { const int e = sidx - 1 - K, c = e / K, k = e - c * K; src = 1 + KM + c * KM + k; }
-        a.partials[(size_t)blockIdx.x * slots + sidx] = red[0][src] + red[1][src] + red[2][src] + red[3][src];
+        a.partials[(size_t)sidx * gridDim.x + blockIdx.x] = red[0][src] + red[1][src] + red[2][src] + red[3][src];
     }
 }
 
@@ -919,7 +963,9 @@ __global__ __launch_bounds__(64) void head_finalize_kernel(const double* partial
                                                            float* dbias, float* dw) {
     const int slot = blockIdx.x;
     double s = 0;
-    for (int b = threadIdx.x; b < blocks; b += 64) s += partials[(size_t)b * slots + slot];
+    const double* ps = partials + (size_t)slot * blocks;  // [slot][workgroup]
+#pragma unroll 8
+    for (int b = threadIdx.x; b < blocks; b += 64) s += ps[b];
     s = wave_sum(s);
     if (threadIdx.x != 0) return;
     if (slot == 0) { *loss_out = s; if (loss_out_f32) *loss_out_f32 = (float)s; }
