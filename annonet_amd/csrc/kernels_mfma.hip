@@ -26,6 +26,7 @@ typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 constexpr int TH = 8, TW = 32;            // output tile (rows x cols); one wave = 2 rows = 2 MFMA pixel groups
 constexpr int PH = TH + 2, PW = TW + 2;   // input patch
@@ -613,6 +614,193 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_mfma_kernel(WgParams a, int t
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// conv3x3s1_pipe: the stride-1 3x3 layer (forward con, or its backward-data with the taps mirrored) as a PERSISTENT,
+// software-pipelined kernel.  A workgroup walks (pixel tile, 32-channel slab) items; while the MFMAs of one item run,
+// the global loads of the next item (input patch chunks and, for multi-slab layers, the slab's filter block) are in
+// flight in registers; the prologue (producer's bn + relu, skip add) and the LDS write follow after the next barrier.
+// LDS records are swizzled by the patch COLUMN, so every operand address in the MFMA phase is
+// (lane offset computed once per kernel) + (compile-time constant carried by the ds_read's immediate): no address
+// arithmetic between MFMAs.  Mirrored taps are handled by staging the filter taps in reverse order.
+// Single-slab layers stage their filter block once per workgroup.
+// ---------------------------------------------------------------------------------------------------------------
+template <int NT, int KIND>
+__global__ __launch_bounds__(256, 2) void conv3x3s1_pipe_kernel(ConvArgs a, int tiles_x, int tiles_y, int flip) {
+    constexpr int C_OUT = NT * 32, NP = (PATCH_PIX * 4 + 255) / 256, W_ITEMS = 9 * C_OUT * 4, NW = (W_ITEMS + 255) / 256;
+    constexpr int W_BYTES = 9 * C_OUT * 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* lds_x = smem;
+    char* lds_w = smem + X_BYTES;
+    float* tab = reinterpret_cast<float*>(smem + X_BYTES + W_BYTES);  // [a_scale | a_shift | b_scale | b_shift][c_red]
+
+    const int tid = threadIdx.x, lane = tid & 63, c16 = tid & 3;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, col = lane & 31;
+    const int co_base = blockIdx.y * C_OUT;
+    const int H = a.h_out, W = a.w_out, c_red = a.c_red;
+    const int n_slabs = c_red >> 5, n_tiles = tiles_x * tiles_y * a.n;
+    const bf16* wsrc = reinterpret_cast<const bf16*>(a.w_bf16);
+    const bf16* xa = reinterpret_cast<const bf16*>(a.src.a);
+    const bf16* xb = reinterpret_cast<const bf16*>(a.src.b);
+    const size_t plane = (size_t)H * W * c_red;  // < 2^31 elements (host check)
+
+    if (KIND != SRC_RAW) {
+        for (int i = tid; i < c_red; i += 256) {
+            tab[i] = a.src.a_scale[i];
+            tab[c_red + i] = a.src.a_shift[i];
+            tab[2 * c_red + i] = KIND == SRC_ACT2 ? a.src.b_scale[i] : 0.f;
+            tab[3 * c_red + i] = KIND == SRC_ACT2 ? a.src.b_shift[i] : 0.f;
+        }
+    }
+
+    // ---- staging geometry, fixed per thread ----
+    int pgeo[NP], pdst[NP];
+#pragma unroll
+    for (int jj = 0; jj < NP; ++jj) {
+        const int rec = min((tid >> 2) + 64 * jj, PATCH_PIX - 1);
+        const int py = rec / PW, px = rec - py * PW;
+        pgeo[jj] = py | (px << 8);
+        pdst[jj] = rec * 64 + ((c16 ^ ((px >> 2) & 3)) << 4);
+    }
+    // filter chunk j = record (tid >> 2) + 64 j = (tap slot, co); slot t holds tap t, or 8 - t for mirrored taps
+    int wsrc_off[NW], wdst[NW];
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+        const int rec = min((tid >> 2) + 64 * j, 9 * C_OUT - 1);
+        const int tl = rec / C_OUT, co = rec - tl * C_OUT;
+        const int tap = flip ? 8 - tl : tl;
+        wsrc_off[j] = (tap * a.c_out + co_base + co) * c_red + c16 * 8;
+        wdst[j] = rec * 64 + ((c16 ^ ((co >> 2) & 3)) << 4);
+    }
+    // ---- MFMA operand addresses: lane parts ----
+    const char* xbase[3][2];
+    const char* wbase[2];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            xbase[kx][ks] = lds_x + (wave * 2 * PW + col + kx) * 64 + ((((ks << 1) | half) ^ (((col + kx) >> 2) & 3)) << 4);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) wbase[ks] = lds_w + col * 64 + ((((ks << 1) | half) ^ ((col >> 2) & 3)) << 4);
+
+    f32x16 acc[2][NT];
+    RawChunk<KIND> praw[NP];
+    u32x4 wraw[NW];  // a native vector type: hipcc keeps a HIP uint4 that is only copied (never unpacked) in scratch
+    unsigned pok = 0;
+    auto fetch = [&](int tile, int slab, bool with_w) __attribute__((always_inline)) {
+        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+        const int x0 = tx * TW - 1, y0 = ty * TH - 1;
+        const bf16* pa = xa + (size_t)n * plane;
+        const bf16* pb = KIND == SRC_ACT2 ? xb + (size_t)n * plane : nullptr;
+        const int cc = slab * 32;
+        pok = 0;
+#pragma unroll
+        for (int jj = 0; jj < NP; ++jj) {
+            const int iy = y0 + (pgeo[jj] & 255), ix = x0 + (pgeo[jj] >> 8);
+            const int cy = min(max(iy, 0), H - 1), cx = min(max(ix, 0), W - 1);
+            praw[jj] = side_load_at<KIND>(pa, pb, (cy * W + cx) * c_red + cc + c16 * 8);
+            pok |= ((iy == cy && ix == cx) ? 1u : 0u) << jj;
+        }
+        if (with_w) {
+#pragma unroll
+            for (int j = 0; j < NW; ++j) wraw[j] = *reinterpret_cast<const u32x4*>(wsrc + wsrc_off[j] + cc);
+        }
+    };
+
+    int tile = blockIdx.x, slab = 0;
+    bool first = true;
+    if (tile < n_tiles) fetch(tile, 0, true);
+    while (tile < n_tiles) {
+        int ntile = tile, nslab = slab + 1;
+        if (nslab == n_slabs) { nslab = 0; ntile += gridDim.x; }
+        const bool stage_w = first || n_slabs > 1;
+        __syncthreads();  // every wave is done with the previous item's LDS contents (and the bn table is written)
+        // ---- prologue + LDS write of the fetched item ----
+        {
+            float sa[8], ta[8], sb[8], tb[8];
+            if (KIND != SRC_RAW) {
+                const float* t0 = tab + slab * 32 + c16 * 8;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    sa[j] = t0[j]; ta[j] = t0[c_red + j];
+                    sb[j] = KIND == SRC_ACT2 ? t0[2 * c_red + j] : 0.f; tb[j] = KIND == SRC_ACT2 ? t0[3 * c_red + j] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int jj = 0; jj < NP; ++jj) {
+                uint4 v = chunk_convert<KIND>(praw[jj], sa, ta, sb, tb);
+                if (!((pok >> jj) & 1u)) v = make_uint4(0u, 0u, 0u, 0u);
+                if ((tid >> 2) + 64 * jj < PATCH_PIX) *reinterpret_cast<uint4*>(lds_x + pdst[jj]) = v;
+            }
+            if (stage_w) {
+#pragma unroll
+                for (int j = 0; j < NW; ++j)
+                    if ((tid >> 2) + 64 * j < 9 * C_OUT) *reinterpret_cast<u32x4*>(lds_w + wdst[j]) = wraw[j];
+            }
+        }
+        __syncthreads();
+        if (ntile < n_tiles) fetch(ntile, nslab, n_slabs > 1);
+        first = false;
+
+        if (slab == 0) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[g][nt][r] = 0.f;
+        }
+        // ---- MFMA phase: 9 taps x 2 k-steps, operands at (lane base) + (compile-time offset) ----
+#pragma unroll
+        for (int tl = 0; tl < 9; ++tl) {
+            const int ky = tl / 3, kx = tl - ky * 3;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 xf[2];
+#pragma unroll
+                for (int g = 0; g < 2; ++g) xf[g] = *reinterpret_cast<const bf16x8*>(xbase[kx][ks] + (g + ky) * (PW * 64));
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wbase[ks] + (tl * C_OUT + nt * 32) * 64);
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) acc[g][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf[g], acc[g][nt], 0, 0, 0);
+                }
+            }
+        }
+        if (slab == n_slabs - 1) {
+            const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int oy = ty * TH + wave * 2 + g, ox = tx * TW + col;
+                const bool valid = oy < H && ox < W;
+                const size_t pix = ((size_t)n * H + (valid ? oy : 0)) * W + (valid ? ox : 0);
+                store_pixel_tiles<NT>(acc[g], a, pix, valid, half, co_base);
+            }
+        }
+        tile = ntile; slab = nslab;
+    }
+}
+
+template <int NT>
+void launch_s1_pipe(const ConvArgs& a, hipStream_t s) {
+    const int tiles_x = (a.w_out + TW - 1) / TW, tiles_y = (a.h_out + TH - 1) / TH;
+    const int n_tiles = tiles_x * tiles_y * a.n, groups = a.c_out / (NT * 32);
+    static const int target = getenv("ANH_S1_PIPE_WGS") ? atoi(getenv("ANH_S1_PIPE_WGS")) : 512;  // 2 per CU
+    const dim3 grid((unsigned)std::max(1, std::min(n_tiles, target / groups)), (unsigned)groups), block(256);
+    const size_t lds = X_BYTES + (size_t)9 * NT * 32 * 64 + (size_t)a.c_red * 16;
+    const int flip = a.gather;
+    auto launch = [&](auto kernel) {
+        if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kernel, grid, block, lds, s, a, tiles_x, tiles_y, flip);
+    };
+    switch (a.src.kind) {
+        case SRC_RAW: launch(conv3x3s1_pipe_kernel<NT, SRC_RAW>); break;
+        case SRC_ACT: launch(conv3x3s1_pipe_kernel<NT, SRC_ACT>); break;
+        default: launch(conv3x3s1_pipe_kernel<NT, SRC_ACT2>); break;
+    }
+    HIP_CHECK(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // wgrad_stem_mfma: filter gradient of the 5x5 stem on the u8 image, bf16 dy.
 //   dW[(tap,ci)][co] = sum_p img(p + tap - 2)[ci]/256 * dy[p][co]      -> a (25*CIN -> 96 or 32) x 32 MFMA output, K = pixels.
 // dy is fetched with the transposing LDS read as in wgrad3x3_mfma.  The image operand needs, per lane, 8 consecutive
@@ -1125,7 +1313,12 @@ void launch_conv_mfma(const ConvArgs& a, hipStream_t s) {
     if ((int64_t)a.n * a.h_out * a.w_out == 0) return;
     if (stem_mfma_ok(a)) { launch_stem_mfma(a, s); return; }
     if (a.stride == 1) {
-        if (a.c_out == 32) launch_s1<1, 9>(a, s);
+        static const int pipe = getenv("ANH_S1_PIPE") ? atoi(getenv("ANH_S1_PIPE")) : 1;
+        const bool small_plane = (int64_t)a.h_out * a.w_out * a.c_red < (1ll << 31);  // the pipelined kernel uses 32-bit in-image offsets
+        if (pipe && small_plane) {
+            if (a.c_out == 32) launch_s1_pipe<1>(a, s);
+            else launch_s1_pipe<2>(a, s);
+        } else if (a.c_out == 32) launch_s1<1, 9>(a, s);
         else launch_s1<2, 9>(a, s);   // 64, or 128 as two workgroups of 64 output channels
     } else if (a.gather == 0) {
         if (a.c_out == 32) launch_down<1, 9>(a, s);
