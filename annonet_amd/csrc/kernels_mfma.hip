@@ -614,29 +614,178 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_mfma_kernel(WgParams a, int t
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// conv3x3s1_pipe: the stride-1 3x3 layer (forward con, or its backward-data with the taps mirrored) as a PERSISTENT,
-// software-pipelined kernel.  A workgroup walks (pixel tile, 32-channel slab) items; while the MFMAs of one item run,
-// the global loads of the next item (input patch chunks and, for multi-slab layers, the slab's filter block) are in
-// flight in registers; the prologue (producer's bn + relu, skip add) and the LDS write follow after the next barrier.
-// LDS records are swizzled by the patch COLUMN, so every operand address in the MFMA phase is
-// (lane offset computed once per kernel) + (compile-time constant carried by the ds_read's immediate): no address
-// arithmetic between MFMAs.  Mirrored taps are handled by staging the filter taps in reverse order.
-// Single-slab layers stage their filter block once per workgroup.
+// conv3x3_pipe: the 3x3 layers (stride-1 con and its mirrored backward-data; stride-2 con / cont backward-data;
+// cont / stride-2 con backward-data) as ONE persistent, software-pipelined kernel with a geometry policy.
+// A workgroup walks (pixel tile, 32-channel slab) items; while the MFMAs of one item run, the global loads of the next
+// item (input patch chunks and, for multi-slab layers, the slab's filter block) are in flight in registers; the
+// prologue (producer's bn + relu, skip add) and the LDS write follow after the next barrier.
+// LDS pixel records are swizzled by the patch COLUMN (column within the parity plane for stride 2), so every operand
+// address in the MFMA phase is (lane offset computed once per kernel) + (compile-time constant carried by the ds_read's
+// immediate): no address arithmetic between MFMAs.  Mirrored taps are handled by staging the filter taps in reverse
+// order.  Single-slab layers stage their filter block once per workgroup.
+//   GeoS1   8x32 output tile, 10x34 patch; wave = 2 output rows.
+//   GeoDown 4x32 output tile, 9x65 patch stored split by column parity (a tap reads consecutive records); wave = 1 row.
+//   GeoUp   4x32 tile of LOW-RES positions, 5x33 patch; the four output parity classes take 4 / 2 / 2 / 1 taps and
+//           each owns an accumulator, so no MFMA multiplies by a structural zero; wave = 1 low-res row.
 // ---------------------------------------------------------------------------------------------------------------
-template <int NT, int KIND>
-__global__ __launch_bounds__(256, 2) void conv3x3s1_pipe_kernel(ConvArgs a, int tiles_x, int tiles_y, int flip) {
-    constexpr int C_OUT = NT * 32, NP = (PATCH_PIX * 4 + 255) / 256, W_ITEMS = 9 * C_OUT * 4, NW = (W_ITEMS + 255) / 256;
-    constexpr int W_BYTES = 9 * C_OUT * 64;
+__device__ __forceinline__ const char* swz_addr(const char* base, int rec, int key, int ks, int half) {
+    return base + rec * 64 + ((((ks << 1) | half) ^ (key & 3)) << 4);
+}
+__device__ __forceinline__ bf16x8 lds_frag(const char* p) { return *reinterpret_cast<const bf16x8*>(p); }
+
+struct GeoS1 {
+    static constexpr int RECS = PATCH_PIX, ACC = 2, TILE_H = TH, TILE_W = TW;
+    __device__ static void decode(int rec, int& py, int& px, int& key) { py = rec / PW; px = rec - py * PW; key = (px >> 2) & 3; }
+    __device__ static int in_y0(int ty) { return ty * TH - 1; }
+    __device__ static int in_x0(int tx) { return tx * TW - 1; }
+    struct Bases { const char* x[3][2]; };
+    __device__ static void init(Bases& b, const char* lds_x, int wave, int col, int half) {
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) b.x[kx][ks] = swz_addr(lds_x, wave * 2 * PW + col + kx, (col + kx) >> 2, ks, half);
+    }
+    template <int NT>
+    __device__ static void mfma(f32x16 (&acc)[ACC][NT], const Bases& b, const char* (&wb)[2]) {
+        constexpr int C_OUT = NT * 32;
+#pragma unroll
+        for (int tl = 0; tl < 9; ++tl) {
+            const int ky = tl / 3, kx = tl - ky * 3;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 xf[2];
+#pragma unroll
+                for (int g = 0; g < 2; ++g) xf[g] = lds_frag(b.x[kx][ks] + (g + ky) * (PW * 64));
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const bf16x8 wf = lds_frag(wb[ks] + (tl * C_OUT + nt * 32) * 64);
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) acc[g][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf[g], acc[g][nt], 0, 0, 0);
+                }
+            }
+        }
+    }
+    template <int NT>
+    __device__ static void store(const f32x16 (&acc)[ACC][NT], const ConvArgs& a, int n, int ty, int tx, int wave, int col, int half, int co_base) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int oy = ty * TH + wave * 2 + g, ox = tx * TW + col;
+            const bool valid = oy < a.h_out && ox < a.w_out;
+            const size_t pix = ((size_t)n * a.h_out + (valid ? oy : 0)) * a.w_out + (valid ? ox : 0);
+            store_pixel_tiles<NT>(acc[g], a, pix, valid, half, co_base);
+        }
+    }
+};
+
+struct GeoDown {
+    static constexpr int RECS = 9 * 66, ACC = 1, TILE_H = 4, TILE_W = 32;
+    __device__ static void decode(int rec, int& py, int& px, int& key) {
+        py = rec / 66;
+        const int rem = rec - py * 66, par = rem >= 33, u = rem - 33 * par;
+        px = 2 * u + par; key = (u >> 2) & 3;
+    }
+    __device__ static int in_y0(int ty) { return ty * 8; }
+    __device__ static int in_x0(int tx) { return tx * 64; }
+    struct Bases { const char* x[2][2]; };  // [kx >> 1][ks]
+    __device__ static void init(Bases& b, const char* lds_x, int wave, int col, int half) {
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) b.x[kh][ks] = swz_addr(lds_x, wave * 4 * 33 + col + kh, (col + kh) >> 2, ks, half);
+    }
+    template <int NT>
+    __device__ static void mfma(f32x16 (&acc)[ACC][NT], const Bases& b, const char* (&wb)[2]) {
+        constexpr int C_OUT = NT * 32;
+#pragma unroll
+        for (int tl = 0; tl < 9; ++tl) {
+            const int ky = tl / 3, kx = tl - ky * 3;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16x8 xf = lds_frag(b.x[kx >> 1][ks] + (ky * 2 + (kx & 1)) * (33 * 64));
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const bf16x8 wf = lds_frag(wb[ks] + (tl * C_OUT + nt * 32) * 64);
+                    acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc[0][nt], 0, 0, 0);
+                }
+            }
+        }
+    }
+    template <int NT>
+    __device__ static void store(const f32x16 (&acc)[ACC][NT], const ConvArgs& a, int n, int ty, int tx, int wave, int col, int half, int co_base) {
+        const int oy = ty * 4 + wave, ox = tx * 32 + col;
+        const bool valid = oy < a.h_out && ox < a.w_out;
+        const size_t pix = ((size_t)n * a.h_out + (valid ? oy : 0)) * a.w_out + (valid ? ox : 0);
+        store_pixel_tiles<NT>(acc[0], a, pix, valid, half, co_base);
+    }
+};
+
+struct GeoUp {
+    static constexpr int RECS = 5 * 33, ACC = 4, TILE_H = 4, TILE_W = 32;
+    __device__ static void decode(int rec, int& py, int& px, int& key) { py = rec / 33; px = rec - py * 33; key = (px >> 2) & 3; }
+    __device__ static int in_y0(int ty) { return ty * 4 - 1; }
+    __device__ static int in_x0(int tx) { return tx * 32 - 1; }
+    struct Bases { const char* x[2][2]; };  // [ib][ks]: input column j - ib, row i - 1 (the immediate adds a row for ia = 0)
+    __device__ static void init(Bases& b, const char* lds_x, int wave, int col, int half) {
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) b.x[ib][ks] = swz_addr(lds_x, wave * 33 + col + 1 - ib, (col + 1 - ib) >> 2, ks, half);
+    }
+    template <int NT>
+    __device__ static void mfma(f32x16 (&acc)[ACC][NT], const Bases& b, const char* (&wb)[2]) {
+        constexpr int C_OUT = NT * 32;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 xf[2][2];  // [ia][ib]: input (i - ia, j - ib)
+#pragma unroll
+            for (int ia = 0; ia < 2; ++ia)
+#pragma unroll
+                for (int ib = 0; ib < 2; ++ib) xf[ia][ib] = lds_frag(b.x[ib][ks] + (1 - ia) * (33 * 64));
+#pragma unroll
+            for (int py = 0; py < 2; ++py)
+#pragma unroll
+                for (int px = 0; px < 2; ++px)
+#pragma unroll
+                    for (int ia = 0; ia < 2 - py; ++ia)
+#pragma unroll
+                        for (int ib = 0; ib < 2 - px; ++ib) {
+                            const int tap = (py + 2 * ia) * 3 + px + 2 * ib;
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt) {
+                                const bf16x8 wf = lds_frag(wb[ks] + (tap * C_OUT + nt * 32) * 64);
+                                acc[py * 2 + px][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf[ia][ib], acc[py * 2 + px][nt], 0, 0, 0);
+                            }
+                        }
+        }
+    }
+    template <int NT>
+    __device__ static void store(const f32x16 (&acc)[ACC][NT], const ConvArgs& a, int n, int ty, int tx, int wave, int col, int half, int co_base) {
+#pragma unroll
+        for (int py = 0; py < 2; ++py)
+#pragma unroll
+            for (int px = 0; px < 2; ++px) {
+                const int oy = 2 * (ty * 4 + wave) + py, ox = 2 * (tx * 32 + col) + px;
+                const bool valid = oy < a.h_out && ox < a.w_out;
+                const size_t pix = ((size_t)n * a.h_out + (valid ? oy : 0)) * a.w_out + (valid ? ox : 0);
+                store_pixel_tiles<NT>(acc[py * 2 + px], a, pix, valid, half, co_base);
+            }
+    }
+};
+
+template <class G, int NT, int KIND>
+__global__ __launch_bounds__(256, 2) void conv3x3_pipe_kernel(ConvArgs a, int tiles_x, int tiles_y, int flip) {
+    constexpr int C_OUT = NT * 32, NP = (G::RECS * 4 + 255) / 256, W_ITEMS = 9 * C_OUT * 4, NW = (W_ITEMS + 255) / 256;
+    constexpr int X_BYTES_ = G::RECS * 64, W_BYTES = 9 * C_OUT * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* lds_x = smem;
-    char* lds_w = smem + X_BYTES;
-    float* tab = reinterpret_cast<float*>(smem + X_BYTES + W_BYTES);  // [a_scale | a_shift | b_scale | b_shift][c_red]
+    char* lds_w = smem + X_BYTES_;
+    float* tab = reinterpret_cast<float*>(smem + X_BYTES_ + W_BYTES);  // [a_scale | a_shift | b_scale | b_shift][c_red]
 
     const int tid = threadIdx.x, lane = tid & 63, c16 = tid & 3;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, col = lane & 31;
     const int co_base = blockIdx.y * C_OUT;
-    const int H = a.h_out, W = a.w_out, c_red = a.c_red;
+    const int H = a.h_in, W = a.w_in, c_red = a.c_red;
     const int n_slabs = c_red >> 5, n_tiles = tiles_x * tiles_y * a.n;
     const bf16* wsrc = reinterpret_cast<const bf16*>(a.w_bf16);
     const bf16* xa = reinterpret_cast<const bf16*>(a.src.a);
@@ -652,14 +801,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3s1_pipe_kernel(ConvArgs a, int 
         }
     }
 
-    // ---- staging geometry, fixed per thread ----
+    // ---- staging geometry, fixed per thread: patch chunk jj = record (tid >> 2) + 64 jj ----
     int pgeo[NP], pdst[NP];
 #pragma unroll
     for (int jj = 0; jj < NP; ++jj) {
-        const int rec = min((tid >> 2) + 64 * jj, PATCH_PIX - 1);
-        const int py = rec / PW, px = rec - py * PW;
+        const int rec = min((tid >> 2) + 64 * jj, G::RECS - 1);
+        int py, px, key;
+        G::decode(rec, py, px, key);
         pgeo[jj] = py | (px << 8);
-        pdst[jj] = rec * 64 + ((c16 ^ ((px >> 2) & 3)) << 4);
+        pdst[jj] = rec * 64 + ((c16 ^ key) << 4);
     }
     // filter chunk j = record (tid >> 2) + 64 j = (tap slot, co); slot t holds tap t, or 8 - t for mirrored taps
     int wsrc_off[NW], wdst[NW];
@@ -672,23 +822,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3s1_pipe_kernel(ConvArgs a, int 
         wdst[j] = rec * 64 + ((c16 ^ ((co >> 2) & 3)) << 4);
     }
     // ---- MFMA operand addresses: lane parts ----
-    const char* xbase[3][2];
+    typename G::Bases xbases;
+    G::init(xbases, lds_x, wave, col, half);
     const char* wbase[2];
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-            xbase[kx][ks] = lds_x + (wave * 2 * PW + col + kx) * 64 + ((((ks << 1) | half) ^ (((col + kx) >> 2) & 3)) << 4);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) wbase[ks] = lds_w + col * 64 + ((((ks << 1) | half) ^ ((col >> 2) & 3)) << 4);
+    for (int ks = 0; ks < 2; ++ks) wbase[ks] = swz_addr(lds_w, col, col >> 2, ks, half);
 
-    f32x16 acc[2][NT];
+    f32x16 acc[G::ACC][NT];
     RawChunk<KIND> praw[NP];
     u32x4 wraw[NW];  // a native vector type: hipcc keeps a HIP uint4 that is only copied (never unpacked) in scratch
     unsigned pok = 0;
     auto fetch = [&](int tile, int slab, bool with_w) __attribute__((always_inline)) {
         const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
-        const int x0 = tx * TW - 1, y0 = ty * TH - 1;
+        const int x0 = G::in_x0(tx), y0 = G::in_y0(ty);
         const bf16* pa = xa + (size_t)n * plane;
         const bf16* pb = KIND == SRC_ACT2 ? xb + (size_t)n * plane : nullptr;
         const int cc = slab * 32;
@@ -729,7 +875,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3s1_pipe_kernel(ConvArgs a, int 
             for (int jj = 0; jj < NP; ++jj) {
                 uint4 v = chunk_convert<KIND>(praw[jj], sa, ta, sb, tb);
                 if (!((pok >> jj) & 1u)) v = make_uint4(0u, 0u, 0u, 0u);
-                if ((tid >> 2) + 64 * jj < PATCH_PIX) *reinterpret_cast<uint4*>(lds_x + pdst[jj]) = v;
+                if ((tid >> 2) + 64 * jj < G::RECS) *reinterpret_cast<uint4*>(lds_x + pdst[jj]) = v;
             }
             if (stage_w) {
 #pragma unroll
@@ -743,59 +889,35 @@ __global__ __launch_bounds__(256, 2) void conv3x3s1_pipe_kernel(ConvArgs a, int 
 
         if (slab == 0) {
 #pragma unroll
-            for (int g = 0; g < 2; ++g)
+            for (int g = 0; g < G::ACC; ++g)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[g][nt][r] = 0.f;
         }
-        // ---- MFMA phase: 9 taps x 2 k-steps, operands at (lane base) + (compile-time offset) ----
-#pragma unroll
-        for (int tl = 0; tl < 9; ++tl) {
-            const int ky = tl / 3, kx = tl - ky * 3;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 xf[2];
-#pragma unroll
-                for (int g = 0; g < 2; ++g) xf[g] = *reinterpret_cast<const bf16x8*>(xbase[kx][ks] + (g + ky) * (PW * 64));
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wbase[ks] + (tl * C_OUT + nt * 32) * 64);
-#pragma unroll
-                    for (int g = 0; g < 2; ++g) acc[g][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf[g], acc[g][nt], 0, 0, 0);
-                }
-            }
-        }
+        G::template mfma<NT>(acc, xbases, wbase);
         if (slab == n_slabs - 1) {
             const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
-#pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                const int oy = ty * TH + wave * 2 + g, ox = tx * TW + col;
-                const bool valid = oy < H && ox < W;
-                const size_t pix = ((size_t)n * H + (valid ? oy : 0)) * W + (valid ? ox : 0);
-                store_pixel_tiles<NT>(acc[g], a, pix, valid, half, co_base);
-            }
+            G::template store<NT>(acc, a, n, ty, tx, wave, col, half, co_base);
         }
         tile = ntile; slab = nslab;
     }
 }
 
-template <int NT>
-void launch_s1_pipe(const ConvArgs& a, hipStream_t s) {
-    const int tiles_x = (a.w_out + TW - 1) / TW, tiles_y = (a.h_out + TH - 1) / TH;
+template <class G, int NT>
+void launch_pipe(const ConvArgs& a, int tiles_x, int tiles_y, int flip, hipStream_t s) {
     const int n_tiles = tiles_x * tiles_y * a.n, groups = a.c_out / (NT * 32);
-    static const int target = getenv("ANH_S1_PIPE_WGS") ? atoi(getenv("ANH_S1_PIPE_WGS")) : 512;  // 2 per CU
+    static const int target = getenv("ANH_PIPE_WGS") ? atoi(getenv("ANH_PIPE_WGS")) : 512;  // 2 per CU
     const dim3 grid((unsigned)std::max(1, std::min(n_tiles, target / groups)), (unsigned)groups), block(256);
-    const size_t lds = X_BYTES + (size_t)9 * NT * 32 * 64 + (size_t)a.c_red * 16;
-    const int flip = a.gather;
+    const size_t lds = (size_t)G::RECS * 64 + (size_t)9 * NT * 32 * 64 + (size_t)a.c_red * 16;
     auto launch = [&](auto kernel) {
         if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kernel, grid, block, lds, s, a, tiles_x, tiles_y, flip);
     };
     switch (a.src.kind) {
-        case SRC_RAW: launch(conv3x3s1_pipe_kernel<NT, SRC_RAW>); break;
-        case SRC_ACT: launch(conv3x3s1_pipe_kernel<NT, SRC_ACT>); break;
-        default: launch(conv3x3s1_pipe_kernel<NT, SRC_ACT2>); break;
+        case SRC_RAW: launch(conv3x3_pipe_kernel<G, NT, SRC_RAW>); break;
+        case SRC_ACT: launch(conv3x3_pipe_kernel<G, NT, SRC_ACT>); break;
+        default: launch(conv3x3_pipe_kernel<G, NT, SRC_ACT2>); break;
     }
     HIP_CHECK(hipGetLastError());
 }
@@ -1312,20 +1434,30 @@ void launch_conv_mfma(const ConvArgs& a, hipStream_t s) {
     if (!mfma_conv_supported(a)) fail(ANH_ERR_INTERNAL, "conv_mfma: unsupported shape");
     if ((int64_t)a.n * a.h_out * a.w_out == 0) return;
     if (stem_mfma_ok(a)) { launch_stem_mfma(a, s); return; }
+    // the persistent pipelined kernels index within one image with 32-bit element offsets
+    static const int pipe = getenv("ANH_CONV_PIPE") ? atoi(getenv("ANH_CONV_PIPE")) : 7;  // bit 0: stride 1, bit 1: down, bit 2: up
+    const bool small_plane = (int64_t)a.h_in * a.w_in * a.c_red < (1ll << 31);
     if (a.stride == 1) {
-        static const int pipe = getenv("ANH_S1_PIPE") ? atoi(getenv("ANH_S1_PIPE")) : 1;
-        const bool small_plane = (int64_t)a.h_out * a.w_out * a.c_red < (1ll << 31);  // the pipelined kernel uses 32-bit in-image offsets
-        if (pipe && small_plane) {
-            if (a.c_out == 32) launch_s1_pipe<1>(a, s);
-            else launch_s1_pipe<2>(a, s);
+        const int tiles_x = (a.w_out + TW - 1) / TW, tiles_y = (a.h_out + TH - 1) / TH;
+        if ((pipe & 1) && small_plane) {
+            if (a.c_out == 32) launch_pipe<GeoS1, 1>(a, tiles_x, tiles_y, a.gather, s);
+            else launch_pipe<GeoS1, 2>(a, tiles_x, tiles_y, a.gather, s);   // 64, or 128 as two workgroups of 64 output channels
         } else if (a.c_out == 32) launch_s1<1, 9>(a, s);
-        else launch_s1<2, 9>(a, s);   // 64, or 128 as two workgroups of 64 output channels
+        else launch_s1<2, 9>(a, s);
     } else if (a.gather == 0) {
-        if (a.c_out == 32) launch_down<1, 9>(a, s);
+        const int tiles_x = (a.w_out + 31) / 32, tiles_y = (a.h_out + 3) / 4;
+        if ((pipe & 2) && small_plane) {
+            if (a.c_out == 32) launch_pipe<GeoDown, 1>(a, tiles_x, tiles_y, 0, s);
+            else launch_pipe<GeoDown, 2>(a, tiles_x, tiles_y, 0, s);
+        } else if (a.c_out == 32) launch_down<1, 9>(a, s);
         else if (a.c_out == 64) launch_down<2, 9>(a, s);
-        else launch_down<4, 3>(a, s);   // measured: the unsplit 128-channel form is the faster one here
+        else launch_down<4, 3>(a, s);
     } else {
-        if (a.c_out == 32) launch_up<1>(a, s);
+        const int tiles_x = (a.w_in + 1 + 31) / 32, tiles_y = (a.h_in + 1 + 3) / 4;
+        if ((pipe & 4) && small_plane) {
+            if (a.c_out == 32) launch_pipe<GeoUp, 1>(a, tiles_x, tiles_y, 0, s);
+            else launch_pipe<GeoUp, 2>(a, tiles_x, tiles_y, 0, s);
+        } else if (a.c_out == 32) launch_up<1>(a, s);
         else launch_up<2>(a, s);
     }
 }
