@@ -15,6 +15,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdio>
+#include <vector>
 
 #include "common.h"
 #include "kernels.h"
@@ -67,7 +69,8 @@ __device__ __forceinline__ uint4 add_bf16x8(const uint4& p, const uint4& q) {
 // every lane.  With "accumulate" the old values are fetched by one batch of unconditional loads (pix is clamped by the
 // caller) before any add/store, instead of a load -> wait -> store chain per 16 bytes.
 template <int NT>
-__device__ __forceinline__ void store_pixel_tiles(const f32x16 (&acc)[NT], const ConvArgs& a, size_t pix, bool valid, int half, int co_base = 0) {
+__device__ __forceinline__ void store_pixel_tiles_rmw(const f32x16 (&acc)[NT], const ConvArgs& a, size_t pix, bool valid, int half, int co_base,
+                                                      const u32x4 (&prefetched)[NT][2], bool use_prefetched) {
     const int C_OUT = a.c_out;  // a workgroup may own only NT*32 of the layer's output channels, starting at co_base
     uint4 q[NT][2];
 #pragma unroll
@@ -93,7 +96,10 @@ __device__ __forceinline__ void store_pixel_tiles(const f32x16 (&acc)[NT], const
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int s = 0; s < 2; ++s) old[nt][s] = *reinterpret_cast<const uint4*>(out + base + nt * 32 + 16 * s);
+                for (int s = 0; s < 2; ++s) {
+                    if (d == 0 && use_prefetched) { const u32x4 v = prefetched[nt][s]; old[nt][s] = make_uint4(v[0], v[1], v[2], v[3]); }
+                    else old[nt][s] = *reinterpret_cast<const uint4*>(out + base + nt * 32 + 16 * s);
+                }
             if (valid) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
@@ -109,6 +115,16 @@ __device__ __forceinline__ void store_pixel_tiles(const f32x16 (&acc)[NT], const
     }
 }
 
+
+template <int NT>
+__device__ __forceinline__ void store_pixel_tiles(const f32x16 (&acc)[NT], const ConvArgs& a, size_t pix, bool valid, int half, int co_base = 0) {
+    u32x4 none[NT][2];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) none[nt][s] = u32x4{0u, 0u, 0u, 0u};
+    store_pixel_tiles_rmw<NT>(acc, a, pix, valid, half, co_base, none, false);
+}
 
 // ---- staging helpers shared by every MFMA kernel --------------------------------------------------------------------
 // A "side" is a tensor read through its producer's bn+relu (+ skip add).  Staging a batch of 16-byte chunks is done in
@@ -638,6 +654,7 @@ struct GeoS1 {
     __device__ static void decode(int rec, int& py, int& px, int& key) { py = rec / PW; px = rec - py * PW; key = (px >> 2) & 3; }
     __device__ static int in_y0(int ty) { return ty * TH - 1; }
     __device__ static int in_x0(int tx) { return tx * TW - 1; }
+    static constexpr int NB = 3;  // one lane base per kx
     struct Bases { const char* x[3][2]; };
     __device__ static void init(Bases& b, const char* lds_x, int wave, int col, int half) {
 #pragma unroll
@@ -665,15 +682,11 @@ struct GeoS1 {
             }
         }
     }
-    template <int NT>
-    __device__ static void store(const f32x16 (&acc)[ACC][NT], const ConvArgs& a, int n, int ty, int tx, int wave, int col, int half, int co_base) {
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            const int oy = ty * TH + wave * 2 + g, ox = tx * TW + col;
-            const bool valid = oy < a.h_out && ox < a.w_out;
-            const size_t pix = ((size_t)n * a.h_out + (valid ? oy : 0)) * a.w_out + (valid ? ox : 0);
-            store_pixel_tiles<NT>(acc[g], a, pix, valid, half, co_base);
-        }
+    // output pixel of accumulator group g (one lane = one pixel): row 2*wave + g of the tile
+    __device__ static void out_pixel(int g, const ConvArgs& a, int n, int ty, int tx, int wave, int col, size_t& pix, bool& valid) {
+        const int oy = ty * TH + wave * 2 + g, ox = tx * TW + col;
+        valid = oy < a.h_out && ox < a.w_out;
+        pix = ((size_t)n * a.h_out + (valid ? oy : 0)) * a.w_out + (valid ? ox : 0);
     }
 };
 
@@ -686,6 +699,7 @@ struct GeoDown {
     }
     __device__ static int in_y0(int ty) { return ty * 8; }
     __device__ static int in_x0(int tx) { return tx * 64; }
+    static constexpr int NB = 2;
     struct Bases { const char* x[2][2]; };  // [kx >> 1][ks]
     __device__ static void init(Bases& b, const char* lds_x, int wave, int col, int half) {
 #pragma unroll
@@ -710,12 +724,10 @@ struct GeoDown {
             }
         }
     }
-    template <int NT>
-    __device__ static void store(const f32x16 (&acc)[ACC][NT], const ConvArgs& a, int n, int ty, int tx, int wave, int col, int half, int co_base) {
+    __device__ static void out_pixel(int, const ConvArgs& a, int n, int ty, int tx, int wave, int col, size_t& pix, bool& valid) {
         const int oy = ty * 4 + wave, ox = tx * 32 + col;
-        const bool valid = oy < a.h_out && ox < a.w_out;
-        const size_t pix = ((size_t)n * a.h_out + (valid ? oy : 0)) * a.w_out + (valid ? ox : 0);
-        store_pixel_tiles<NT>(acc[0], a, pix, valid, half, co_base);
+        valid = oy < a.h_out && ox < a.w_out;
+        pix = ((size_t)n * a.h_out + (valid ? oy : 0)) * a.w_out + (valid ? ox : 0);
     }
 };
 
@@ -724,6 +736,7 @@ struct GeoUp {
     __device__ static void decode(int rec, int& py, int& px, int& key) { py = rec / 33; px = rec - py * 33; key = (px >> 2) & 3; }
     __device__ static int in_y0(int ty) { return ty * 4 - 1; }
     __device__ static int in_x0(int tx) { return tx * 32 - 1; }
+    static constexpr int NB = 2;
     struct Bases { const char* x[2][2]; };  // [ib][ks]: input column j - ib, row i - 1 (the immediate adds a row for ia = 0)
     __device__ static void init(Bases& b, const char* lds_x, int wave, int col, int half) {
 #pragma unroll
@@ -758,17 +771,11 @@ struct GeoUp {
                         }
         }
     }
-    template <int NT>
-    __device__ static void store(const f32x16 (&acc)[ACC][NT], const ConvArgs& a, int n, int ty, int tx, int wave, int col, int half, int co_base) {
-#pragma unroll
-        for (int py = 0; py < 2; ++py)
-#pragma unroll
-            for (int px = 0; px < 2; ++px) {
-                const int oy = 2 * (ty * 4 + wave) + py, ox = 2 * (tx * 32 + col) + px;
-                const bool valid = oy < a.h_out && ox < a.w_out;
-                const size_t pix = ((size_t)n * a.h_out + (valid ? oy : 0)) * a.w_out + (valid ? ox : 0);
-                store_pixel_tiles<NT>(acc[py * 2 + px], a, pix, valid, half, co_base);
-            }
+    // accumulator group g = output parity class (py, px) = (g >> 1, g & 1) of low-res position (i, j)
+    __device__ static void out_pixel(int g, const ConvArgs& a, int n, int ty, int tx, int wave, int col, size_t& pix, bool& valid) {
+        const int oy = 2 * (ty * 4 + wave) + (g >> 1), ox = 2 * (tx * 32 + col) + (g & 1);
+        valid = oy < a.h_out && ox < a.w_out;
+        pix = ((size_t)n * a.h_out + (valid ? oy : 0)) * a.w_out + (valid ? ox : 0);
     }
 };
 
@@ -898,10 +905,257 @@ __global__ __launch_bounds__(256, 2) void conv3x3_pipe_kernel(ConvArgs a, int ti
         G::template mfma<NT>(acc, xbases, wbase);
         if (slab == n_slabs - 1) {
             const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
-            G::template store<NT>(acc, a, n, ty, tx, wave, col, half, co_base);
+#pragma unroll
+            for (int g = 0; g < G::ACC; ++g) {
+                size_t pix; bool valid;
+                G::out_pixel(g, a, n, ty, tx, wave, col, pix, valid);
+                store_pixel_tiles<NT>(acc[g], a, pix, valid, half, co_base);
+            }
         }
         tile = ntile; slab = nslab;
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// conv3x3_ws: the same layers, geometry policies and LDS layout as conv3x3_pipe, with the two halves of the work on
+// different waves of one 512-thread workgroup (1 workgroup per CU, 2 waves per SIMD):
+//   waves 4..7 (producers): global loads of item i+1 into registers, prologue (bn + relu, skip add), LDS write into
+//                           buffer (i+1) & 1;
+//   waves 0..3 (consumers): MFMAs of item i from buffer i & 1, epilogue stores.
+// One workgroup barrier per item hands a filled buffer over and releases the other one, so the staging VALU work, the
+// global-load latency and the MFMA/LDS-read work of a CU overlap instead of adding up.
+// ---------------------------------------------------------------------------------------------------------------
+template <class G, int NT, int KIND>
+__global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tiles_x, int tiles_y, int flip, long long* prof) {
+    // per-phase wall-clock accounting, compiled in with -DANH_WS_PROFILE (ANH_WS_PROF=1 then prints one line per launch)
+#ifdef ANH_WS_PROFILE
+    long long t_a = 0, t_b = 0, t_c = 0, t0_;
+#define TICK() (t0_ = wall_clock64())
+#define TOCK(acc_) (acc_ += wall_clock64() - t0_)
+#else
+#define TICK()
+#define TOCK(acc_)
+#endif
+    constexpr int C_OUT = NT * 32, NP = (G::RECS * 4 + 255) / 256, W_ITEMS = 9 * C_OUT * 4, NW = (W_ITEMS + 255) / 256;
+    constexpr int X_BYTES_ = G::RECS * 64, W_BYTES = 9 * C_OUT * 64, BUF = X_BYTES_ + W_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* tab = reinterpret_cast<float*>(smem + 2 * BUF);  // [a_scale | a_shift | b_scale | b_shift][c_red]
+
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const bool producer = wave >= 4;
+    const int tid = threadIdx.x & 255, lane = tid & 63, c16 = tid & 3;
+    const int half = lane >> 5, col = lane & 31;
+    const int co_base = blockIdx.y * C_OUT;
+    const int H = a.h_in, W = a.w_in, c_red = a.c_red;
+    const int n_slabs = c_red >> 5, n_tiles = tiles_x * tiles_y * a.n;
+
+    if (KIND != SRC_RAW) {
+        for (int i = threadIdx.x; i < c_red; i += 512) {
+            tab[i] = a.src.a_scale[i];
+            tab[c_red + i] = a.src.a_shift[i];
+            tab[2 * c_red + i] = KIND == SRC_ACT2 ? a.src.b_scale[i] : 0.f;
+            tab[3 * c_red + i] = KIND == SRC_ACT2 ? a.src.b_shift[i] : 0.f;
+        }
+    }
+    __syncthreads();
+
+    int tile = blockIdx.x, slab = 0, it = 0;
+    if (producer) {
+        const bf16* wsrc = reinterpret_cast<const bf16*>(a.w_bf16);
+        const bf16* xa = reinterpret_cast<const bf16*>(a.src.a);
+        const bf16* xb = reinterpret_cast<const bf16*>(a.src.b);
+        const size_t plane = (size_t)H * W * c_red;  // < 2^31 elements (host check)
+        // ---- staging geometry, fixed per thread: patch chunk jj = record (tid >> 2) + 64 jj ----
+        int pgeo[NP], pdst[NP];
+#pragma unroll
+        for (int jj = 0; jj < NP; ++jj) {
+            const int rec = min((tid >> 2) + 64 * jj, G::RECS - 1);
+            int py, px, key;
+            G::decode(rec, py, px, key);
+            pgeo[jj] = py | (px << 8);
+            pdst[jj] = rec * 64 + ((c16 ^ key) << 4);
+        }
+        // filter chunk j = record (tid >> 2) + 64 j = (tap slot, co); slot t holds tap t, or 8 - t for mirrored taps
+        int wsrc_off[NW], wdst[NW];
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            const int rec = min((tid >> 2) + 64 * j, 9 * C_OUT - 1);
+            const int tl = rec / C_OUT, co = rec - tl * C_OUT;
+            const int tap = flip ? 8 - tl : tl;
+            wsrc_off[j] = (tap * a.c_out + co_base + co) * c_red + c16 * 8;
+            wdst[j] = X_BYTES_ + rec * 64 + ((c16 ^ ((co >> 2) & 3)) << 4);
+        }
+        RawChunk<KIND> praw[NP];
+        u32x4 wraw[NW];  // a native vector type: hipcc keeps a HIP uint4 that is only copied (never unpacked) in scratch
+        unsigned pok = 0;
+        auto fetch = [&](int tile_, int slab_, bool with_w) __attribute__((always_inline)) {
+            const int tx = tile_ % tiles_x, ty = (tile_ / tiles_x) % tiles_y, n = tile_ / (tiles_x * tiles_y);
+            const int x0 = G::in_x0(tx), y0 = G::in_y0(ty);
+            const bf16* pa = xa + (size_t)n * plane;
+            const bf16* pb = KIND == SRC_ACT2 ? xb + (size_t)n * plane : nullptr;
+            const int cc = slab_ * 32;
+            pok = 0;
+#pragma unroll
+            for (int jj = 0; jj < NP; ++jj) {
+                const int iy = y0 + (pgeo[jj] & 255), ix = x0 + (pgeo[jj] >> 8);
+                const int cy = min(max(iy, 0), H - 1), cx = min(max(ix, 0), W - 1);
+                praw[jj] = side_load_at<KIND>(pa, pb, (cy * W + cx) * c_red + cc + c16 * 8);
+                pok |= ((iy == cy && ix == cx) ? 1u : 0u) << jj;
+            }
+            if (with_w) {
+#pragma unroll
+                for (int j = 0; j < NW; ++j) wraw[j] = *reinterpret_cast<const u32x4*>(wsrc + wsrc_off[j] + cc);
+            }
+        };
+        if (tile < n_tiles) fetch(tile, 0, true);
+        while (tile < n_tiles) {
+            int ntile = tile, nslab = slab + 1;
+            if (nslab == n_slabs) { nslab = 0; ntile += gridDim.x; }
+            char* lbuf = smem + (it & 1) * BUF;
+            TICK();
+            // a single-slab layer's filter block goes into both buffers once (its registers are not refetched)
+            const bool stage_w = it < 2 || n_slabs > 1;
+            {
+                float sa[8], ta[8], sb[8], tb[8];
+                if (KIND != SRC_RAW) {
+                    const float* t0 = tab + slab * 32 + c16 * 8;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        sa[j] = t0[j]; ta[j] = t0[c_red + j];
+                        sb[j] = KIND == SRC_ACT2 ? t0[2 * c_red + j] : 0.f; tb[j] = KIND == SRC_ACT2 ? t0[3 * c_red + j] : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int jj = 0; jj < NP; ++jj) {
+                    uint4 v = chunk_convert<KIND>(praw[jj], sa, ta, sb, tb);
+                    if (!((pok >> jj) & 1u)) v = make_uint4(0u, 0u, 0u, 0u);
+                    if ((tid >> 2) + 64 * jj < G::RECS) *reinterpret_cast<uint4*>(lbuf + pdst[jj]) = v;
+                }
+                if (stage_w) {
+#pragma unroll
+                    for (int j = 0; j < NW; ++j)
+                        if ((tid >> 2) + 64 * j < 9 * C_OUT) *reinterpret_cast<u32x4*>(lbuf + wdst[j]) = wraw[j];
+                }
+            }
+#ifdef ANH_WS_PROFILE
+            __builtin_amdgcn_s_waitcnt(0xc07f);  // the commit figure includes the load wait and the LDS write drain
+#endif
+            TOCK(t_a);
+            TICK();
+            if (ntile < n_tiles) fetch(ntile, nslab, n_slabs > 1);
+            TOCK(t_b);
+            TICK();
+            __syncthreads();  // buffer it & 1 is full; the consumers are done with buffer (it + 1) & 1
+            TOCK(t_c);
+            tile = ntile; slab = nslab; ++it;
+        }
+    } else {
+        typename G::Bases b0;
+        G::init(b0, smem, wave, col, half);
+        const char* wb0[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) wb0[ks] = swz_addr(smem + X_BYTES_, col, col >> 2, ks, half);
+        f32x16 acc[G::ACC][NT];
+        u32x4 old[G::ACC][NT][2];
+        while (tile < n_tiles) {
+            int ntile = tile, nslab = slab + 1;
+            if (nslab == n_slabs) { nslab = 0; ntile += gridDim.x; }
+            const int boff = (it & 1) * BUF;
+            typename G::Bases b;
+#pragma unroll
+            for (int i = 0; i < G::NB; ++i)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) b.x[i][ks] = b0.x[i][ks] + boff;
+            const char* wb[2] = {wb0[0] + boff, wb0[1] + boff};
+            if (slab == 0) {
+#pragma unroll
+                for (int g = 0; g < G::ACC; ++g)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[g][nt][r] = 0.f;
+            }
+            TICK();
+            __syncthreads();  // buffer it & 1 is full
+            TOCK(t_c);
+            TICK();
+            const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+            const bool rmw = a.out_accumulate && slab == n_slabs - 1;
+            if (rmw) {  // the old values of a read-modify-write destination travel while the MFMAs run
+                const bf16* out = reinterpret_cast<const bf16*>(a.out);
+#pragma unroll
+                for (int g = 0; g < G::ACC; ++g) {
+                    size_t pix; bool valid;
+                    G::out_pixel(g, a, n, ty, tx, wave, col, pix, valid);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; ++s2) old[g][nt][s2] = *reinterpret_cast<const u32x4*>(out + pix * a.c_out + co_base + 8 * half + nt * 32 + 16 * s2);
+                }
+            }
+            G::template mfma<NT>(acc, b, wb);
+#ifdef ANH_WS_PROFILE
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+            TOCK(t_a);
+            TICK();
+            if (slab == n_slabs - 1) {
+#pragma unroll
+                for (int g = 0; g < G::ACC; ++g) {
+                    size_t pix; bool valid;
+                    G::out_pixel(g, a, n, ty, tx, wave, col, pix, valid);
+                    store_pixel_tiles_rmw<NT>(acc[g], a, pix, valid, half, co_base, old[g], rmw);
+                }
+            }
+            TOCK(t_b);
+            tile = ntile; slab = nslab; ++it;
+        }
+    }
+#ifdef ANH_WS_PROFILE
+    if (prof && lane == 0) { long long* o = prof + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * 4; o[0] = t_a; o[1] = t_b; o[2] = t_c; o[3] = it; }
+#endif
+#undef TICK
+#undef TOCK
+}
+
+template <class G, int NT>
+void launch_ws(const ConvArgs& a, int tiles_x, int tiles_y, int flip, hipStream_t s) {
+    const int n_tiles = tiles_x * tiles_y * a.n, groups = a.c_out / (NT * 32);
+    static const int target = getenv("ANH_WS_WGS") ? atoi(getenv("ANH_WS_WGS")) : 256;  // 1 per CU
+    const dim3 grid((unsigned)std::max(1, std::min(n_tiles, target / groups)), (unsigned)groups), block(512);
+    const size_t lds = 2 * ((size_t)G::RECS * 64 + (size_t)9 * NT * 32 * 64) + (size_t)a.c_red * 16;
+    auto launch = [&](auto kernel) {
+        if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+#ifndef ANH_WS_PROFILE
+        hipLaunchKernelGGL(kernel, grid, block, lds, s, a, tiles_x, tiles_y, flip, (long long*)nullptr);
+#else
+        static const int prof_on = getenv("ANH_WS_PROF") ? atoi(getenv("ANH_WS_PROF")) : 0;
+        static long long* prof = nullptr;
+        if (prof_on && !prof) HIP_CHECK(hipMalloc(&prof, 1024 * 8 * 4 * sizeof(long long)));
+        hipLaunchKernelGGL(kernel, grid, block, lds, s, a, tiles_x, tiles_y, flip, prof_on ? prof : nullptr);
+        if (prof_on) {
+            HIP_CHECK(hipStreamSynchronize(s));
+            const int nwg = grid.x * grid.y;
+            std::vector<long long> h((size_t)nwg * 32);
+            HIP_CHECK(hipMemcpy(h.data(), prof, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+            double pa = 0, pb = 0, pc = 0, ca = 0, cb = 0, cc = 0, items = 0;
+            for (int w = 0; w < nwg; ++w) {
+                for (int v = 0; v < 4; ++v) { ca += h[(w * 8 + v) * 4]; cb += h[(w * 8 + v) * 4 + 1]; cc += h[(w * 8 + v) * 4 + 2]; }
+                for (int v = 4; v < 8; ++v) { pa += h[(w * 8 + v) * 4]; pb += h[(w * 8 + v) * 4 + 1]; pc += h[(w * 8 + v) * 4 + 2]; }
+                items += h[(w * 8) * 4 + 3];
+            }
+            const double k = 1.0 / (4.0 * nwg) / 100.0;  // wall clock = 100 MHz -> us per wave
+            fprintf(stderr, "[ws prof] geo_recs=%d NT=%d kind=%d c_red=%d wgs=%d items/wg=%.1f | producer us: commit %.1f fetch %.1f barrier %.1f | consumer us: mfma %.1f store %.1f barrier %.1f\n",
+                    G::RECS, NT, a.src.kind, a.c_red, nwg, items / nwg, pa * k, pb * k, pc * k, ca * k, cb * k, cc * k);
+        }
+#endif
+    };
+    switch (a.src.kind) {
+        case SRC_RAW: launch(conv3x3_ws_kernel<G, NT, SRC_RAW>); break;
+        case SRC_ACT: launch(conv3x3_ws_kernel<G, NT, SRC_ACT>); break;
+        default: launch(conv3x3_ws_kernel<G, NT, SRC_ACT2>); break;
+    }
+    HIP_CHECK(hipGetLastError());
 }
 
 template <class G, int NT>
@@ -1436,17 +1690,24 @@ void launch_conv_mfma(const ConvArgs& a, hipStream_t s) {
     if (stem_mfma_ok(a)) { launch_stem_mfma(a, s); return; }
     // the persistent pipelined kernels index within one image with 32-bit element offsets
     static const int pipe = getenv("ANH_CONV_PIPE") ? atoi(getenv("ANH_CONV_PIPE")) : 7;  // bit 0: stride 1, bit 1: down, bit 2: up
+    static const int wsm = getenv("ANH_CONV_WS") ? atoi(getenv("ANH_CONV_WS")) : 7;      // same bits: warp-specialised form
     const bool small_plane = (int64_t)a.h_in * a.w_in * a.c_red < (1ll << 31);
     if (a.stride == 1) {
         const int tiles_x = (a.w_out + TW - 1) / TW, tiles_y = (a.h_out + TH - 1) / TH;
-        if ((pipe & 1) && small_plane) {
+        if ((wsm & 1) && small_plane) {
+            if (a.c_out == 32) launch_ws<GeoS1, 1>(a, tiles_x, tiles_y, a.gather, s);
+            else launch_ws<GeoS1, 2>(a, tiles_x, tiles_y, a.gather, s);
+        } else if ((pipe & 1) && small_plane) {
             if (a.c_out == 32) launch_pipe<GeoS1, 1>(a, tiles_x, tiles_y, a.gather, s);
             else launch_pipe<GeoS1, 2>(a, tiles_x, tiles_y, a.gather, s);   // 64, or 128 as two workgroups of 64 output channels
         } else if (a.c_out == 32) launch_s1<1, 9>(a, s);
         else launch_s1<2, 9>(a, s);
     } else if (a.gather == 0) {
         const int tiles_x = (a.w_out + 31) / 32, tiles_y = (a.h_out + 3) / 4;
-        if ((pipe & 2) && small_plane) {
+        if ((wsm & 2) && small_plane) {
+            if (a.c_out == 32) launch_ws<GeoDown, 1>(a, tiles_x, tiles_y, 0, s);
+            else launch_ws<GeoDown, 2>(a, tiles_x, tiles_y, 0, s);
+        } else if ((pipe & 2) && small_plane) {
             if (a.c_out == 32) launch_pipe<GeoDown, 1>(a, tiles_x, tiles_y, 0, s);
             else launch_pipe<GeoDown, 2>(a, tiles_x, tiles_y, 0, s);
         } else if (a.c_out == 32) launch_down<1, 9>(a, s);
@@ -1454,7 +1715,10 @@ void launch_conv_mfma(const ConvArgs& a, hipStream_t s) {
         else launch_down<4, 3>(a, s);
     } else {
         const int tiles_x = (a.w_in + 1 + 31) / 32, tiles_y = (a.h_in + 1 + 3) / 4;
-        if ((pipe & 4) && small_plane) {
+        if ((wsm & 4) && small_plane) {
+            if (a.c_out == 32) launch_ws<GeoUp, 1>(a, tiles_x, tiles_y, 0, s);
+            else launch_ws<GeoUp, 2>(a, tiles_x, tiles_y, 0, s);
+        } else if ((pipe & 4) && small_plane) {
             if (a.c_out == 32) launch_pipe<GeoUp, 1>(a, tiles_x, tiles_y, 0, s);
             else launch_pipe<GeoUp, 2>(a, tiles_x, tiles_y, 0, s);
         } else if (a.c_out == 32) launch_up<1>(a, s);
