@@ -258,7 +258,8 @@ void Engine::plan_dims(int n, int h, int w) {
         if (L.has_bn) {
             s.raw.reserve(elems * es);
             if (training) s.dact.reserve(elems * es);
-            bn_need = std::max(bn_need, (size_t)bn_partial_blocks((int64_t)n * s.h * s.w) * 2 * L.cout * sizeof(double));
+            // the conv kernels that fuse the statistics write one partial per workgroup (at most 1024 workgroups)
+            bn_need = std::max(bn_need, (size_t)std::max(bn_partial_blocks((int64_t)n * s.h * s.w), 1024) * 2 * L.cout * sizeof(double));
         }
     }
     const anh_layer_desc& head = spec.layers.back();
@@ -334,6 +335,15 @@ void Engine::run_conv_forward(int li, const Src& image, bool training_pass, floa
     const double es = (double)elem_size(dtype);
     const double bytes = (double)p_in * L.cin * (L.in_a < 0 ? 1.0 : es) * (L.in_b >= 0 ? 2 : 1) + (double)p_out * L.cout * (L.has_bn ? es : 4.0) +
                          (double)spec.filter_count(li) * es;
+    // training forward of a bn layer: the MFMA kernels that can keep per-lane running sums also write the statistic partials
+    int fused_stat_blocks = 0;
+    if (L.has_bn && training_pass && conv_takes_mfma(a, dtype)) {
+        fused_stat_blocks = conv_fused_stat_blocks(a);
+        if (fused_stat_blocks > 0) {
+            bn_partials.reserve((size_t)fused_stat_blocks * 2 * L.cout * sizeof(double));
+            a.stat_partials = bn_partials.as<double>();
+        }
+    }
     conv_dispatch(a, (std::string("fwd_") + layer_tag(L)).c_str(), flops, bytes);
     if (L.has_bn && training_pass) {
         BnFwdArgs b;
@@ -348,9 +358,15 @@ void Engine::run_conv_forward(int li, const Src& image, bool training_pass, floa
             b.unbias = P > 1 ? P / (P - 1.0) : 1.0;
             b.running_mean = running.as<float>() + L.rs_off; b.running_var = running.as<float>() + L.rs_off + L.cout;
         }
-        const int tok = prof.begin(stream, "bn_forward_stats", 0, (double)p_out * L.cout * es);
-        launch_bn_forward_stats(b, stream);
-        prof.end(stream, tok);
+        if (fused_stat_blocks > 0) {
+            const int tok = prof.begin(stream, "bn_forward_finalize", 0, (double)fused_stat_blocks * L.cout * 16.0);
+            launch_bn_forward_finalize(b, fused_stat_blocks, stream);
+            prof.end(stream, tok);
+        } else {
+            const int tok = prof.begin(stream, "bn_forward_stats", 0, (double)p_out * L.cout * es);
+            launch_bn_forward_stats(b, stream);
+            prof.end(stream, tok);
+        }
     }
 }
 

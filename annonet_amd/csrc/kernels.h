@@ -77,6 +77,8 @@ struct BnFwdArgs {
 };
 int bn_partial_blocks(int64_t pixels);
 void launch_bn_forward_stats(const BnFwdArgs& a, hipStream_t s);
+// statistics already written by the conv kernel (ConvArgs::stat_partials, `blocks` partials per channel): finalize only
+void launch_bn_forward_finalize(const BnFwdArgs& a, int blocks, hipStream_t s);
 
 // running_mean/var update (dlib bn_: averaging factor 1/(updates+1) up to the window; unbiased variance)
 void launch_bn_running_update(const float* mean, const double* var, float* running_mean, float* running_var,
@@ -165,6 +167,9 @@ void launch_head_train(const HeadTrainArgs& a, hipStream_t s);
 // kernels_mfma.hip: bf16 MFMA implicit-GEMM kernels; *_supported() says whether a shape is covered
 bool mfma_conv_supported(const ConvArgs& a);
 void launch_conv_mfma(const ConvArgs& a, hipStream_t s);
+// > 0: the MFMA kernel of this layer can also write the bn statistic partials (set ConvArgs::stat_partials; the
+// value is the number of partials per channel to pass to launch_bn_forward_finalize)
+int conv_fused_stat_blocks(const ConvArgs& a);
 bool mfma_wgrad_supported(const WgradArgs& a);
 void launch_wgrad_mfma(const WgradArgs& a, hipStream_t s);
 int64_t wgrad_mfma_scratch_floats(const WgradArgs& a);

@@ -1216,6 +1216,10 @@ void launch_bn_forward_stats(const BnFwdArgs& a, hipStream_t s) {
             hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(blocks), block, shmem, s, reinterpret_cast<const float*>(a.y), a.pixels, a.c, a.partials, bn_pixels_per_block(a.pixels));
     }
     HIP_CHECK(hipGetLastError());
+    launch_bn_forward_finalize(a, blocks, s);
+}
+
+void launch_bn_forward_finalize(const BnFwdArgs& a, int blocks, hipStream_t s) {
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(a.c), dim3(64), 0, s, a.partials, blocks, a.pixels, a.c, a.gamma, a.beta, a.eps,
                        a.mean, a.invstd, a.scale, a.shift, a.var, a.running_mean, a.running_var, a.averaging_factor, a.unbias);
     HIP_CHECK(hipGetLastError());

@@ -70,7 +70,8 @@ __device__ __forceinline__ uint4 add_bf16x8(const uint4& p, const uint4& q) {
 // caller) before any add/store, instead of a load -> wait -> store chain per 16 bytes.
 template <int NT>
 __device__ __forceinline__ void store_pixel_tiles_rmw(const f32x16 (&acc)[NT], const ConvArgs& a, size_t pix, bool valid, int half, int co_base,
-                                                      const u32x4 (&prefetched)[NT][2], bool use_prefetched) {
+                                                      const u32x4 (&prefetched)[NT][2], bool use_prefetched,
+                                                      float (*stat)[2][16] = nullptr, bool do_stat = false) {
     const int C_OUT = a.c_out;  // a workgroup may own only NT*32 of the layer's output channels, starting at co_base
     uint4 q[NT][2];
 #pragma unroll
@@ -84,6 +85,20 @@ __device__ __forceinline__ void store_pixel_tiles_rmw(const f32x16 (&acc)[NT], c
             auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
             q[nt][s] = make_uint4(r0[0], r1[0], r0[1], r1[1]);
         }
+    if (do_stat && valid) {  // batch-norm statistics of the STORED (bf16-rounded) values: per-lane running sum and sum of squares
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const unsigned w[4] = {q[nt][s].x, q[nt][s].y, q[nt][s].z, q[nt][s].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float lo = lo_f(w[i]), hi = hi_f(w[i]);
+                    stat[nt][s][2 * i] += lo; stat[nt][s][8 + 2 * i] = fmaf(lo, lo, stat[nt][s][8 + 2 * i]);
+                    stat[nt][s][2 * i + 1] += hi; stat[nt][s][8 + 2 * i + 1] = fmaf(hi, hi, stat[nt][s][8 + 2 * i + 1]);
+                }
+            }
+    }
     bf16* outs[2] = {reinterpret_cast<bf16*>(a.out), reinterpret_cast<bf16*>(a.out2)};
     const int accumulate[2] = {a.out_accumulate, a.out2_accumulate};
 #pragma unroll
@@ -948,6 +963,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
     const int co_base = blockIdx.y * C_OUT;
     const int H = a.h_in, W = a.w_in, c_red = a.c_red;
     const int n_slabs = c_red >> 5, n_tiles = tiles_x * tiles_y * a.n;
+    constexpr bool CAN_STATS = G::ACC * NT <= 4;  // register budget of the consumer waves
+    const bool fuse_stats = CAN_STATS && a.stat_partials != nullptr;
 
     if (KIND != SRC_RAW) {
         for (int i = threadIdx.x; i < c_red; i += 512) {
@@ -1057,6 +1074,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
         for (int ks = 0; ks < 2; ++ks) wb0[ks] = swz_addr(smem + X_BYTES_, col, col >> 2, ks, half);
         f32x16 acc[G::ACC][NT];
         u32x4 old[G::ACC][NT][2];
+        float stat[NT][2][16];  // [..][0..7] sum, [8..15] sum of squares of this lane's 8 channels per (nt, s)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) stat[nt][s2][e] = 0.f;
         while (tile < n_tiles) {
             int ntile = tile, nslab = slab + 1;
             if (nslab == n_slabs) { nslab = 0; ntile += gridDim.x; }
@@ -1104,11 +1128,36 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
                 for (int g = 0; g < G::ACC; ++g) {
                     size_t pix; bool valid;
                     G::out_pixel(g, a, n, ty, tx, wave, col, pix, valid);
-                    store_pixel_tiles_rmw<NT>(acc[g], a, pix, valid, half, co_base, old[g], rmw);
+                    store_pixel_tiles_rmw<NT>(acc[g], a, pix, valid, half, co_base, old[g], rmw, stat, fuse_stats);
                 }
             }
             TOCK(t_b);
             tile = ntile; slab = nslab; ++it;
+        }
+        if (fuse_stats) {
+            __syncthreads();  // (matched by the producers) every wave is done with the staging buffers
+            float* red = reinterpret_cast<float*>(smem) + (size_t)(wave * 64 + lane) * (32 * NT);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) red[(nt * 2 + s2) * 16 + e] = stat[nt][s2][e];
+        }
+    }
+    if (fuse_stats) {
+        if (producer) __syncthreads();
+        __syncthreads();
+        // thread t < 64 NT sums (channel, which) over the 4 consumer waves x 32 pixel columns, in a fixed order, in double
+        const int t = threadIdx.x;
+        if (t < 64 * NT) {
+            const int ch = t >> 1, which = t & 1;
+            const int nt = ch >> 5, s2 = (ch >> 4) & 1, hf = (ch >> 3) & 1, j = ch & 7;
+            const float* red = reinterpret_cast<const float*>(smem);
+            double sum = 0.0;
+            for (int w = 0; w < 4; ++w)
+                for (int c = 0; c < 32; ++c) sum += (double)red[(size_t)(w * 64 + hf * 32 + c) * (32 * NT) + (nt * 2 + s2) * 16 + which * 8 + j];
+            a.stat_partials[((size_t)(co_base + ch) * 2 + which) * gridDim.x + blockIdx.x] = sum;
         }
     }
 #ifdef ANH_WS_PROFILE
@@ -1118,11 +1167,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
 #undef TOCK
 }
 
+int ws_target_wgs();
+
 template <class G, int NT>
 void launch_ws(const ConvArgs& a, int tiles_x, int tiles_y, int flip, hipStream_t s) {
     const int n_tiles = tiles_x * tiles_y * a.n, groups = a.c_out / (NT * 32);
-    static const int target = getenv("ANH_WS_WGS") ? atoi(getenv("ANH_WS_WGS")) : 256;  // 1 per CU
-    const dim3 grid((unsigned)std::max(1, std::min(n_tiles, target / groups)), (unsigned)groups), block(512);
+    const dim3 grid((unsigned)std::max(1, std::min(n_tiles, ws_target_wgs() / groups)), (unsigned)groups), block(512);
     const size_t lds = 2 * ((size_t)G::RECS * 64 + (size_t)9 * NT * 32 * 64) + (size_t)a.c_red * 16;
     auto launch = [&](auto kernel) {
         if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1684,44 +1734,65 @@ bool mfma_conv_supported(const ConvArgs& a) {
     return false;
 }
 
+namespace {
+// which kernel a supported 3x3 layer takes, and its launch geometry
+struct ConvPlan { int geo /*0 s1, 1 down, 2 up*/, nt, tiles_x, tiles_y, flip, form /*0 classic, 1 pipelined, 2 warp-specialised*/, grid_x, groups; };
+
+int ws_target_wgs() { static const int t = getenv("ANH_WS_WGS") ? atoi(getenv("ANH_WS_WGS")) : 256; return t; }  // 1 per CU
+
+ConvPlan conv_plan(const ConvArgs& a) {
+    static const int pipe = getenv("ANH_CONV_PIPE") ? atoi(getenv("ANH_CONV_PIPE")) : 7;  // bit 0: stride 1, bit 1: down, bit 2: up
+    static const int wsm = getenv("ANH_CONV_WS") ? atoi(getenv("ANH_CONV_WS")) : 7;      // same bits: warp-specialised form
+    // the persistent kernels index within one image with 32-bit element offsets
+    const bool small_plane = (int64_t)a.h_in * a.w_in * a.c_red < (1ll << 31);
+    ConvPlan p{};
+    p.geo = a.stride == 1 ? 0 : (a.gather == 0 ? 1 : 2);
+    p.nt = a.c_out == 32 ? 1 : 2;  // 64, or 128 as two workgroup groups of 64 output channels
+    p.flip = p.geo == 0 ? a.gather : 0;
+    if (p.geo == 0) { p.tiles_x = (a.w_out + TW - 1) / TW; p.tiles_y = (a.h_out + TH - 1) / TH; }
+    else if (p.geo == 1) { p.tiles_x = (a.w_out + 31) / 32; p.tiles_y = (a.h_out + 3) / 4; }
+    else { p.tiles_x = (a.w_in + 1 + 31) / 32; p.tiles_y = (a.h_in + 1 + 3) / 4; }
+    const int bit = 1 << p.geo;
+    p.form = small_plane ? ((wsm & bit) ? 2 : (pipe & bit) ? 1 : 0) : 0;
+    p.groups = a.c_out / (p.nt * 32);
+    const int n_tiles = p.tiles_x * p.tiles_y * a.n;
+    p.grid_x = std::max(1, std::min(n_tiles, ws_target_wgs() / p.groups));
+    return p;
+}
+}  // namespace
+
+// Number of per-workgroup statistic partials the conv kernel will write when ConvArgs::stat_partials is set
+// (layout [channel][sum | sum of squares][workgroup]); 0 when this layer's kernel does not fuse the statistics.
+int conv_fused_stat_blocks(const ConvArgs& a) {
+    if (!mfma_conv_supported(a) || stem_mfma_ok(a) || (int64_t)a.n * a.h_out * a.w_out == 0) return 0;
+    static const int on = getenv("ANH_FUSE_BN_STATS") ? atoi(getenv("ANH_FUSE_BN_STATS")) : 1;
+    const ConvPlan p = conv_plan(a);
+    const int acc = p.geo == 0 ? 2 : p.geo == 1 ? 1 : 4;
+    if (!on || p.form != 2 || acc * p.nt > 4 || a.out_accumulate || a.out2) return 0;
+    return p.grid_x;
+}
+
 void launch_conv_mfma(const ConvArgs& a, hipStream_t s) {
     if (!mfma_conv_supported(a)) fail(ANH_ERR_INTERNAL, "conv_mfma: unsupported shape");
     if ((int64_t)a.n * a.h_out * a.w_out == 0) return;
     if (stem_mfma_ok(a)) { launch_stem_mfma(a, s); return; }
-    // the persistent pipelined kernels index within one image with 32-bit element offsets
-    static const int pipe = getenv("ANH_CONV_PIPE") ? atoi(getenv("ANH_CONV_PIPE")) : 7;  // bit 0: stride 1, bit 1: down, bit 2: up
-    static const int wsm = getenv("ANH_CONV_WS") ? atoi(getenv("ANH_CONV_WS")) : 7;      // same bits: warp-specialised form
-    const bool small_plane = (int64_t)a.h_in * a.w_in * a.c_red < (1ll << 31);
-    if (a.stride == 1) {
-        const int tiles_x = (a.w_out + TW - 1) / TW, tiles_y = (a.h_out + TH - 1) / TH;
-        if ((wsm & 1) && small_plane) {
-            if (a.c_out == 32) launch_ws<GeoS1, 1>(a, tiles_x, tiles_y, a.gather, s);
-            else launch_ws<GeoS1, 2>(a, tiles_x, tiles_y, a.gather, s);
-        } else if ((pipe & 1) && small_plane) {
-            if (a.c_out == 32) launch_pipe<GeoS1, 1>(a, tiles_x, tiles_y, a.gather, s);
-            else launch_pipe<GeoS1, 2>(a, tiles_x, tiles_y, a.gather, s);   // 64, or 128 as two workgroups of 64 output channels
-        } else if (a.c_out == 32) launch_s1<1, 9>(a, s);
+    const ConvPlan p = conv_plan(a);
+    ANH_REQUIRE(!a.stat_partials || conv_fused_stat_blocks(a) > 0, "conv_mfma: this layer's kernel does not fuse bn statistics");
+    if (p.geo == 0) {
+        if (p.form == 2) { if (p.nt == 1) launch_ws<GeoS1, 1>(a, p.tiles_x, p.tiles_y, p.flip, s); else launch_ws<GeoS1, 2>(a, p.tiles_x, p.tiles_y, p.flip, s); }
+        else if (p.form == 1) { if (p.nt == 1) launch_pipe<GeoS1, 1>(a, p.tiles_x, p.tiles_y, p.flip, s); else launch_pipe<GeoS1, 2>(a, p.tiles_x, p.tiles_y, p.flip, s); }
+        else if (a.c_out == 32) launch_s1<1, 9>(a, s);
         else launch_s1<2, 9>(a, s);
-    } else if (a.gather == 0) {
-        const int tiles_x = (a.w_out + 31) / 32, tiles_y = (a.h_out + 3) / 4;
-        if ((wsm & 2) && small_plane) {
-            if (a.c_out == 32) launch_ws<GeoDown, 1>(a, tiles_x, tiles_y, 0, s);
-            else launch_ws<GeoDown, 2>(a, tiles_x, tiles_y, 0, s);
-        } else if ((pipe & 2) && small_plane) {
-            if (a.c_out == 32) launch_pipe<GeoDown, 1>(a, tiles_x, tiles_y, 0, s);
-            else launch_pipe<GeoDown, 2>(a, tiles_x, tiles_y, 0, s);
-        } else if (a.c_out == 32) launch_down<1, 9>(a, s);
+    } else if (p.geo == 1) {
+        if (p.form == 2) { if (p.nt == 1) launch_ws<GeoDown, 1>(a, p.tiles_x, p.tiles_y, 0, s); else launch_ws<GeoDown, 2>(a, p.tiles_x, p.tiles_y, 0, s); }
+        else if (p.form == 1) { if (p.nt == 1) launch_pipe<GeoDown, 1>(a, p.tiles_x, p.tiles_y, 0, s); else launch_pipe<GeoDown, 2>(a, p.tiles_x, p.tiles_y, 0, s); }
+        else if (a.c_out == 32) launch_down<1, 9>(a, s);
         else if (a.c_out == 64) launch_down<2, 9>(a, s);
         else launch_down<4, 3>(a, s);
     } else {
-        const int tiles_x = (a.w_in + 1 + 31) / 32, tiles_y = (a.h_in + 1 + 3) / 4;
-        if ((wsm & 4) && small_plane) {
-            if (a.c_out == 32) launch_ws<GeoUp, 1>(a, tiles_x, tiles_y, 0, s);
-            else launch_ws<GeoUp, 2>(a, tiles_x, tiles_y, 0, s);
-        } else if ((pipe & 4) && small_plane) {
-            if (a.c_out == 32) launch_pipe<GeoUp, 1>(a, tiles_x, tiles_y, 0, s);
-            else launch_pipe<GeoUp, 2>(a, tiles_x, tiles_y, 0, s);
-        } else if (a.c_out == 32) launch_up<1>(a, s);
+        if (p.form == 2) { if (p.nt == 1) launch_ws<GeoUp, 1>(a, p.tiles_x, p.tiles_y, 0, s); else launch_ws<GeoUp, 2>(a, p.tiles_x, p.tiles_y, 0, s); }
+        else if (p.form == 1) { if (p.nt == 1) launch_pipe<GeoUp, 1>(a, p.tiles_x, p.tiles_y, 0, s); else launch_pipe<GeoUp, 2>(a, p.tiles_x, p.tiles_y, 0, s); }
+        else if (a.c_out == 32) launch_up<1>(a, s);
         else launch_up<2>(a, s);
     }
 }
