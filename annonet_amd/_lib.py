@@ -127,6 +127,7 @@ _SIGNATURES = {  # ConvDesc / OpInput are defined above
     "anh_trainer_layer_tensor": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int64, C.POINTER(C.c_int)]),
     "anh_profile_enable": (C.c_int, [_P, C.c_int, C.c_int]),
     "anh_profile_set_filter": (C.c_int, [_P, C.c_int, C.c_char_p]),
+    "anh_profile_set_sampling": (C.c_int, [_P, C.c_int, C.c_int]),
     "anh_profile_reset": (C.c_int, [_P, C.c_int]),
     "anh_profile_count": (C.c_int, [_P, C.c_int]),
     "anh_profile_entry": (C.c_int, [_P, C.c_int, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),

@@ -608,6 +608,9 @@ int anh_profile_enable(void* handle, int is_trainer, int enable) {
 int anh_profile_set_filter(void* handle, int is_trainer, const char* substring) {
     return guarded([&] { Engine* e = engine_of(handle, is_trainer); e->synchronize(); e->prof.filter = substring ? substring : ""; });
 }
+int anh_profile_set_sampling(void* handle, int is_trainer, int every) {
+    return guarded([&] { ANH_REQUIRE(every >= 1, "sampling interval must be >= 1"); Engine* e = engine_of(handle, is_trainer); e->synchronize(); e->prof.sample_every = every; e->prof.pass_index = 0; });
+}
 int anh_profile_reset(void* handle, int is_trainer) {
     return guarded([&] { Engine* e = engine_of(handle, is_trainer); e->synchronize(); e->prof.reset(); });
 }

@@ -20,6 +20,8 @@ class Profiler {
     struct Entry { std::string name; double total_ms = 0; int64_t launches = 0; double flops = 0, bytes = 0; };
     bool enabled = false;
     std::string filter;  // when non-empty only kernels whose name contains it are timed
+    int sample_every = 1;  // time the kernels of every n-th pass only (an event pair costs ~6 us of stream time per launch)
+    int64_t pass_index = 0; // advanced by the engine at the start of every forward pass
     ~Profiler();
     int begin(hipStream_t s, const char* name, double flops, double bytes);  // returns a token (or -1 when disabled)
     void end(hipStream_t s, int token);

@@ -29,6 +29,7 @@ hipEvent_t Profiler::get_event() {
 }
 int Profiler::begin(hipStream_t s, const char* name, double flops, double bytes) {
     if (!enabled) return -1;
+    if (sample_every > 1 && (pass_index % sample_every) != 0) return -1;
     if (!filter.empty() && std::string(name).find(filter) == std::string::npos) return -1;
     int idx = -1;
     for (size_t i = 0; i < entries.size(); ++i) if (entries[i].name == name) { idx = (int)i; break; }
@@ -363,8 +364,11 @@ void Engine::run_conv_forward(int li, const Src& image, bool training_pass, floa
             launch_bn_forward_finalize(b, fused_stat_blocks, stream);
             prof.end(stream, tok);
         } else {
-            const int tok = prof.begin(stream, "bn_forward_stats", 0, (double)p_out * L.cout * es);
-            launch_bn_forward_stats(b, stream);
+            int tok = prof.begin(stream, "bn_forward_stats", 0, (double)p_out * L.cout * es);
+            const int blocks = launch_bn_forward_partials(b, stream);
+            prof.end(stream, tok);
+            tok = prof.begin(stream, "bn_forward_finalize", 0, (double)blocks * L.cout * 16.0);
+            launch_bn_forward_finalize(b, blocks, stream);
             prof.end(stream, tok);
         }
     }
@@ -380,12 +384,14 @@ bool Engine::head_is_fused() const {
 }
 
 void Engine::forward_inference(const Src& image, int n, int h, int w, float* d_out_nchw) {
+    ++prof.pass_index;
     ANH_REQUIRE(!training, "forward_inference on a training net: take a runtime snapshot first");
     plan_dims(n, h, w);
     for (size_t li = 0; li < spec.layers.size(); ++li) run_conv_forward((int)li, image, false, d_out_nchw);
 }
 
 void Engine::forward_training(const Src& image, int n, int h, int w) {
+    ++prof.pass_index;
     ANH_REQUIRE(training, "not a training net");
     plan_dims(n, h, w);
     const size_t n_run = head_is_fused() ? spec.layers.size() - 1 : spec.layers.size();  // the fused tail computes the logits itself
@@ -447,8 +453,15 @@ void Engine::backward(const uint16_t* d_labels, const float* d_weights, double l
             b.gamma = master.as<float>() + L.g_off; b.mean = s.mean; b.invstd = s.invstd; b.scale = s.scale; b.shift = s.shift;
             b.dgamma = grad.as<float>() + L.g_off; b.dbeta = grad.as<float>() + L.beta_off;
             b.partials = bn_partials.as<double>(); b.coef = coef.as<float>();
-            const int tok = prof.begin(stream, "bn_relu_backward", 0, (double)p_out * L.cout * es * 5);
-            launch_bn_backward(b, stream);
+            // one profiler entry per kernel: reduce reads da and y; apply reads both and rewrites da
+            int tok = prof.begin(stream, "bn_bwd_reduce", 0, (double)p_out * L.cout * es * 2);
+            launch_bn_bwd_reduce(b, stream);
+            prof.end(stream, tok);
+            tok = prof.begin(stream, "bn_bwd_finalize", 0, (double)bn_partial_blocks(p_out) * L.cout * 16.0);
+            launch_bn_bwd_finalize(b, stream);
+            prof.end(stream, tok);
+            tok = prof.begin(stream, "bn_bwd_apply", 0, (double)p_out * L.cout * es * 3);
+            launch_bn_bwd_apply(b, stream);
             prof.end(stream, tok);
             dy = s.dact.p; dy_dt = dtype;
         } else { dy = dlogits.p; dy_dt = DT_F32; }

@@ -76,7 +76,8 @@ struct BnFwdArgs {
     float* running_mean = nullptr; float* running_var = nullptr; double averaging_factor = 1.0, unbias = 1.0;
 };
 int bn_partial_blocks(int64_t pixels);
-void launch_bn_forward_stats(const BnFwdArgs& a, hipStream_t s);
+void launch_bn_forward_stats(const BnFwdArgs& a, hipStream_t s);   // = partials, finalize
+int launch_bn_forward_partials(const BnFwdArgs& a, hipStream_t s);
 // statistics already written by the conv kernel (ConvArgs::stat_partials, `blocks` partials per channel): finalize only
 void launch_bn_forward_finalize(const BnFwdArgs& a, int blocks, hipStream_t s);
 
@@ -96,7 +97,10 @@ struct BnBwdArgs {
     double* partials = nullptr;
     float* coef = nullptr;  // scratch 3*c floats
 };
-void launch_bn_backward(const BnBwdArgs& a, hipStream_t s);
+void launch_bn_backward(const BnBwdArgs& a, hipStream_t s);   // = reduce, finalize, apply
+void launch_bn_bwd_reduce(const BnBwdArgs& a, hipStream_t s);
+void launch_bn_bwd_finalize(const BnBwdArgs& a, hipStream_t s);
+void launch_bn_bwd_apply(const BnBwdArgs& a, hipStream_t s);
 
 // loss_multiclass_log_per_pixel_weighted on fp32 NHWC logits [P][K]; writes dlogits in place of nothing (separate buffer),
 // the summed loss (double) and the bias gradient.

@@ -1202,7 +1202,9 @@ static dim3 bn_block(int c) {
     return dim3(cx, 256 / cx);
 }
 
-void launch_bn_forward_stats(const BnFwdArgs& a, hipStream_t s) {
+void launch_bn_forward_finalize(const BnFwdArgs& a, int blocks, hipStream_t s);
+// statistics pass alone (partials only); returns the number of partials per channel for launch_bn_forward_finalize
+int launch_bn_forward_partials(const BnFwdArgs& a, hipStream_t s) {
     const int blocks = bn_partial_blocks(a.pixels);
     if (bn_vec_ok(a.c)) {
         if (a.dtype == DT_BF16) hipLaunchKernelGGL(bn_stats_vec_kernel<bf16>, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const bf16*>(a.y), a.pixels, a.c, a.partials, bn_pixels_per_block(a.pixels));
@@ -1216,8 +1218,10 @@ void launch_bn_forward_stats(const BnFwdArgs& a, hipStream_t s) {
             hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(blocks), block, shmem, s, reinterpret_cast<const float*>(a.y), a.pixels, a.c, a.partials, bn_pixels_per_block(a.pixels));
     }
     HIP_CHECK(hipGetLastError());
-    launch_bn_forward_finalize(a, blocks, s);
+    return blocks;
 }
+
+void launch_bn_forward_stats(const BnFwdArgs& a, hipStream_t s) { launch_bn_forward_finalize(a, launch_bn_forward_partials(a, s), s); }
 
 void launch_bn_forward_finalize(const BnFwdArgs& a, int blocks, hipStream_t s) {
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(a.c), dim3(64), 0, s, a.partials, blocks, a.pixels, a.c, a.gamma, a.beta, a.eps,
@@ -1231,12 +1235,11 @@ void launch_bn_running_update(const float* mean, const double* var, float* runni
     HIP_CHECK(hipGetLastError());
 }
 
-void launch_bn_backward(const BnBwdArgs& a, hipStream_t s) {
+// The three passes of batch-norm + relu backward; launch_bn_backward runs them in order.
+void launch_bn_bwd_reduce(const BnBwdArgs& a, hipStream_t s) {
     const int blocks = bn_partial_blocks(a.pixels);
-    const int64_t total = a.pixels * a.c;
-    const bool vec = bn_vec_ok(a.c);
     const bool bf = a.dtype == DT_BF16;
-    if (vec) {
+    if (bn_vec_ok(a.c)) {
         if (bf) hipLaunchKernelGGL(bn_bwd_reduce_vec_kernel<bf16>, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const bf16*>(a.da), reinterpret_cast<const bf16*>(a.y),
                                    a.pixels, a.c, a.mean, a.invstd, a.scale, a.shift, a.partials, bn_pixels_per_block(a.pixels));
         else hipLaunchKernelGGL(bn_bwd_reduce_vec_kernel<float>, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const float*>(a.da), reinterpret_cast<const float*>(a.y),
@@ -1250,10 +1253,18 @@ void launch_bn_backward(const BnBwdArgs& a, hipStream_t s) {
                                 a.pixels, a.c, a.mean, a.invstd, a.scale, a.shift, a.partials, bn_pixels_per_block(a.pixels));
     }
     HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(a.c), dim3(64), 0, s, a.partials, blocks, a.pixels, a.c, a.gamma, a.invstd,
+}
+
+void launch_bn_bwd_finalize(const BnBwdArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(a.c), dim3(64), 0, s, a.partials, bn_partial_blocks(a.pixels), a.pixels, a.c, a.gamma, a.invstd,
                        a.dgamma, a.dbeta, a.coef);
     HIP_CHECK(hipGetLastError());
-    if (vec) {
+}
+
+void launch_bn_bwd_apply(const BnBwdArgs& a, hipStream_t s) {
+    const int64_t total = a.pixels * a.c;
+    const bool bf = a.dtype == DT_BF16;
+    if (bn_vec_ok(a.c)) {
         const int64_t chunks = total / 8;
         const int apply_blocks = (int)std::min<int64_t>((chunks + 255) / 256, 256 * 8);  // 256 threads: a multiple of every group count
         if (bf) hipLaunchKernelGGL(bn_bwd_apply_vec_kernel<bf16>, dim3(apply_blocks), dim3(256), 0, s, reinterpret_cast<bf16*>(a.da), reinterpret_cast<const bf16*>(a.y),
@@ -1268,6 +1279,12 @@ void launch_bn_backward(const BnBwdArgs& a, hipStream_t s) {
                                 total, a.c, a.mean, a.invstd, a.scale, a.shift, a.coef);
     }
     HIP_CHECK(hipGetLastError());
+}
+
+void launch_bn_backward(const BnBwdArgs& a, hipStream_t s) {
+    launch_bn_bwd_reduce(a, s);
+    launch_bn_bwd_finalize(a, s);
+    launch_bn_bwd_apply(a, s);
 }
 
 int loss_partial_blocks(int64_t pixels) { return (int)((pixels + kLossPixelsPerBlock - 1) / kLossPixelsPerBlock); }

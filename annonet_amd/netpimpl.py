@@ -97,6 +97,9 @@ class _Profiled:
     def profile_set_filter(self, substring=""):
         check(self.L.anh_profile_set_filter(self.h, self._is_trainer, (substring or "").encode()))
 
+    def profile_set_sampling(self, every=1):
+        check(self.L.anh_profile_set_sampling(self.h, self._is_trainer, int(every)))
+
     def profile_reset(self):
         check(self.L.anh_profile_reset(self.h, self._is_trainer))
 

@@ -170,6 +170,7 @@ int anh_trainer_layer_tensor(anh_trainer* h, int layer, int which, float* out, i
 /* ---- per-kernel timing (HIP events on the handle's stream), for bench.py's roofline line ---- */
 int anh_profile_enable(void* handle, int is_trainer, int enable);
 int anh_profile_set_filter(void* handle, int is_trainer, const char* substring); /* NULL or "" = time every kernel */
+int anh_profile_set_sampling(void* handle, int is_trainer, int every);         /* time every n-th forward(+backward) pass only */
 int anh_profile_reset(void* handle, int is_trainer);
 int anh_profile_count(void* handle, int is_trainer);
 int anh_profile_entry(void* handle, int is_trainer, int index, char* name, size_t name_cap,
