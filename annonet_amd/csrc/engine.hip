@@ -304,10 +304,19 @@ void Engine::wgrad_dispatch(WgradArgs& a, const char* tag, double flops, double 
     a.partials = wgrad_partials.as<float>();
     a.partials_capacity = (int64_t)(wgrad_partials.bytes / 4);
     std::string name = std::string(fast ? "wgrad_mfma_bf16:" : (dtype == DT_BF16 ? "wgrad_generic_bf16:" : "wgrad_generic_f32:")) + tag;
-    const int tok = prof.begin(on, name.c_str(), flops, bytes);
+    int splits = 0;
+    a.splits_out = &splits;
+    int tok = prof.begin(on, name.c_str(), flops, bytes);
     if (fast) launch_wgrad_mfma(a, on);
     else launch_wgrad_generic(a, on);
     prof.end(on, tok);
+    a.splits_out = nullptr;
+    if (splits > 0) {  // fixed-order sum of the per-workgroup partials
+        const int64_t nw = (int64_t)a.k * a.k * a.c_in * a.c_out;
+        tok = prof.begin(on, "wgrad_reduce_partials", 0, (double)splits * nw * 4.0);
+        launch_reduce_partials(a.partials, splits, nw, a.dw, on);
+        prof.end(on, tok);
+    }
 }
 
 static const char* layer_tag(const anh_layer_desc& L) {

@@ -57,6 +57,7 @@ struct WgradArgs {
     float* dw = nullptr;        // [tap][c_in][c_out] fp32
     float* partials = nullptr;  // scratch, >= splits * k*k*c_in*c_out floats
     int64_t partials_capacity = 0;
+    int* splits_out = nullptr;  // when set: the partial-sum pass is left to the caller (launch_reduce_partials with *splits_out)
 };
 
 void launch_conv_generic(const ConvArgs& a, hipStream_t s);

@@ -1140,7 +1140,7 @@ void launch_wgrad_generic(const WgradArgs& a, hipStream_t s) {
             else hipLaunchKernelGGL((wgrad_stem_kernel<1, float>), dim3(splits), dim3(128), 0, s, a, tiles_x, tiles_y, total, splits);
         }
         HIP_CHECK(hipGetLastError());
-        launch_reduce_partials(a.partials, splits, nw, a.dw, s);
+        if (a.splits_out) *a.splits_out = splits; else launch_reduce_partials(a.partials, splits, nw, a.dw, s);
         HIP_CHECK(hipGetLastError());
         return;
     }
@@ -1159,7 +1159,7 @@ void launch_wgrad_generic(const WgradArgs& a, hipStream_t s) {
         else wgrad_generic_dispatch<float, float>(a, grid, pps, nco, s);
     }
     HIP_CHECK(hipGetLastError());
-    launch_reduce_partials(a.partials, splits, nw, a.dw, s);
+    if (a.splits_out) *a.splits_out = splits; else launch_reduce_partials(a.partials, splits, nw, a.dw, s);
     HIP_CHECK(hipGetLastError());
 }
 

@@ -1386,7 +1386,7 @@ void launch_wgrad_stem_mfma(const WgradArgs& a, hipStream_t s) {
     if (a.c_in == 3) hipLaunchKernelGGL((wgrad_stem_mfma_kernel<3>), dim3(blocks), dim3(256), lds, s, a, dy, tiles_x, tiles_y, total, blocks);
     else hipLaunchKernelGGL((wgrad_stem_mfma_kernel<1>), dim3(blocks), dim3(256), lds, s, a, dy, tiles_x, tiles_y, total, blocks);
     HIP_CHECK(hipGetLastError());
-    launch_reduce_partials(a.partials, blocks, (int64_t)25 * a.c_in * 32, a.dw, s);
+    if (a.splits_out) *a.splits_out = blocks; else launch_reduce_partials(a.partials, blocks, (int64_t)25 * a.c_in * 32, a.dw, s);
 }
 
 struct WgPlan { int stride, ntc, slabs, tiles_x, tiles_y, total, splits; size_t lds; bool cont; };
@@ -1454,7 +1454,7 @@ void launch_wgrad_any(const WgradArgs& a, hipStream_t s) {
     }
     HIP_CHECK(hipGetLastError());
     const int64_t nw = (int64_t)9 * a.c_in * a.c_out;
-    launch_reduce_partials(a.partials, p.splits, nw, a.dw, s);
+    if (a.splits_out) *a.splits_out = p.splits; else launch_reduce_partials(a.partials, p.splits, nw, a.dw, s);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -31,6 +31,17 @@ PEAK_BF16_TFLOPS = 2500.0
 RIDGE = PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
 
 
+def pmc_traffic(entry):
+    """HBM-side bytes per launch of a profiler entry, from the committed rocprofv3 --pmc passes (tools/pmc_traffic.py)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json")
+    try:
+        with open(path) as f:
+            e = json.load(f)["entries"].get(entry)
+        return e["traffic_bytes_per_launch"] if e else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def synthetic_batch(rank):
     import annonet_amd as aa
     rng_img = np.random.default_rng(1000 * rank + 0)
@@ -215,7 +226,8 @@ def main():
             else:                          # below it: HBM traffic bounds it
                 roof = {"bound": "hbm", "achieved": byts / avg_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s"}
             roof["frac"] = roof["achieved"] / roof["peak"]
-            roof["traffic"] = None
+            roof["traffic"] = pmc_traffic(dominant)
+            roof["algorithmic_bytes_per_launch"] = byts
             roof["kernel"] = dominant
             roof["avg_launch_us"] = avg_s * 1e6
             roof["launches"] = e["launches"]
