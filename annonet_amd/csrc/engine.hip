@@ -110,9 +110,10 @@ Engine::Engine(const anh_net_config& cfg, bool training_) : spec(Spec::build(cfg
         const int C = spec.layers[li].cout;
         max_c = std::max(max_c, C);
         LayerState& s = ls[li];
-        s.bn.reserve((size_t)C * (4 * sizeof(float) + sizeof(double)));
+        s.bn.reserve((size_t)C * (8 * sizeof(float) + sizeof(double)));
         s.mean = s.bn.as<float>(); s.invstd = s.mean + C; s.scale = s.invstd + C; s.shift = s.scale + C;
         s.var = reinterpret_cast<double*>(s.shift + C);
+        s.coef = reinterpret_cast<float*>(s.var + C);  // [3][C] (+ C of padding)
     }
     coef.reserve((size_t)max_c * 3 * sizeof(float));
     HIP_CHECK(hipStreamSynchronize(stream));
@@ -258,7 +259,7 @@ void Engine::plan_dims(int n, int h, int w) {
         const size_t elems = (size_t)n * s.h * s.w * L.cout;
         if (L.has_bn) {
             s.raw.reserve(elems * es);
-            if (training) s.dact.reserve(elems * es);
+            if (training) { s.dact.reserve(elems * es); if (bn_bwd_apply_fusion_enabled()) s.dyp.reserve(elems * es); }
             // the conv kernels that fuse the statistics write one partial per workgroup (at most 1024 workgroups)
             bn_need = std::max(bn_need, (size_t)std::max(bn_partial_blocks((int64_t)n * s.h * s.w), 1024) * 2 * L.cout * sizeof(double));
         }
@@ -319,11 +320,10 @@ void Engine::wgrad_dispatch(WgradArgs& a, const char* tag, double flops, double 
     }
 }
 
-static const char* layer_tag(const anh_layer_desc& L) {
-    if (L.in_a < 0) return "stem";
-    if (!L.has_bn) return "head";
-    if (L.type == 1) return "cont3x3s2";
-    return L.stride == 2 ? "con3x3s2" : "con3x3s1";
+// profiler entry of a layer's kernel: layer kind + channel shape, so that an entry is ONE kernel instantiation at one shape
+static std::string layer_tag(const anh_layer_desc& L) {
+    const char* kind = L.in_a < 0 ? "stem" : !L.has_bn ? "head" : L.type == 1 ? "cont3x3s2" : L.stride == 2 ? "con3x3s2" : "con3x3s1";
+    return std::string(kind) + "_" + std::to_string(L.cin) + "x" + std::to_string(L.cout);
 }
 
 void Engine::run_conv_forward(int li, const Src& image, bool training_pass, float* d_out_nchw) {
@@ -455,27 +455,62 @@ void Engine::backward(const uint16_t* d_labels, const float* d_weights, double l
         const int64_t p_out = (int64_t)s.n * s.h * s.w, p_in = (int64_t)s.n * s.h_in * s.w_in;
         const void* dy;
         DType dy_dt;
+        const double flops = 2.0 * L.k * L.k * L.cin * L.cout * (double)(L.type == 0 ? p_out : p_in);
+        const bool two_streams = concurrent_wgrad && aux_stream;
+
+        // backward-data conv of this layer (arguments first: whether it can take the bn backward in its prologue decides the schedule)
+        ConvArgs dg;
+        const bool has_dgrad = L.in_a >= 0;
+        if (has_dgrad) {
+            dg.src.kind = SRC_RAW; dg.src.dtype = L.has_bn ? dtype : DT_F32;
+            dg.n = s.n; dg.h_in = s.h; dg.w_in = s.w; dg.c_red = L.cout;
+            dg.h_out = s.h_in; dg.w_out = s.w_in; dg.c_out = L.cin;
+            dg.k = L.k; dg.stride = L.stride; dg.pad = L.pad; dg.gather = 1 - L.type;
+            dg.w_f32 = w_km_f32.as<float>() + L.w_off;
+            dg.w_bf16 = dtype == DT_BF16 ? (const void*)(w_tm_bf16.as<uint16_t>() + L.w_off) : nullptr;
+            dg.out = ls[L.in_a].dact.p; dg.out_dtype = dtype; dg.out_accumulate = ls[L.in_a].dact_written ? 1 : 0;
+            if (L.in_b >= 0) { dg.out2 = ls[L.in_b].dact.p; dg.out2_accumulate = ls[L.in_b].dact_written ? 1 : 0; }
+        }
+        // Fused schedule (two streams, MFMA path): the main stream runs reduce -> finalize -> backward-data conv, the conv
+        // applying bn + relu backward to (da, y) while staging; the elementwise apply pass — needed by the filter gradient
+        // only — runs out of place on the second stream ahead of that layer's wgrad.
+        bool fused_apply = false;
         if (L.has_bn) {
             ANH_REQUIRE(s.dact_written, "internal: layer output has no consumer");
             BnBwdArgs b;
             b.da = s.dact.p; b.y = s.raw.p; b.dtype = dtype; b.pixels = p_out; b.c = L.cout;
             b.gamma = master.as<float>() + L.g_off; b.mean = s.mean; b.invstd = s.invstd; b.scale = s.scale; b.shift = s.shift;
             b.dgamma = grad.as<float>() + L.g_off; b.dbeta = grad.as<float>() + L.beta_off;
-            b.partials = bn_partials.as<double>(); b.coef = coef.as<float>();
-            // one profiler entry per kernel: reduce reads da and y; apply reads both and rewrites da
+            b.partials = bn_partials.as<double>(); b.coef = s.coef;
+            // one profiler entry per kernel: reduce reads da and y; apply reads both and writes dy
             int tok = prof.begin(stream, "bn_bwd_reduce", 0, (double)p_out * L.cout * es * 2);
             launch_bn_bwd_reduce(b, stream);
             prof.end(stream, tok);
             tok = prof.begin(stream, "bn_bwd_finalize", 0, (double)bn_partial_blocks(p_out) * L.cout * 16.0);
             launch_bn_bwd_finalize(b, stream);
             prof.end(stream, tok);
-            tok = prof.begin(stream, "bn_bwd_apply", 0, (double)p_out * L.cout * es * 3);
-            launch_bn_bwd_apply(b, stream);
-            prof.end(stream, tok);
-            dy = s.dact.p; dy_dt = dtype;
-        } else { dy = dlogits.p; dy_dt = DT_F32; }
+            const bool dgrad_fuses = has_dgrad && dtype == DT_BF16 && conv_takes_mfma(dg, dtype) && conv_accepts_bnbwd(dg);
+            static const bool force_fused = getenv("ANH_FORCE_FUSED_APPLY") != nullptr;  // experiment: fused schedule on one stream
+            fused_apply = (two_streams && dgrad_fuses) || (force_fused && dgrad_fuses);
+            hipStream_t apply_on = stream;
+            if (fused_apply && !two_streams) b.dy_out = s.dyp.p;
+            if (fused_apply && two_streams) {
+                HIP_CHECK(hipEventRecord(ev_dy_ready, stream));   // coefficients final: the second stream may produce dy
+                HIP_CHECK(hipStreamWaitEvent(aux_stream, ev_dy_ready, 0));
+                apply_on = aux_stream;
+                if (has_dgrad) b.dy_out = s.dyp.p;               // da stays intact for the conv on the main stream
+            }
+            tok = prof.begin(apply_on, "bn_bwd_apply", 0, (double)p_out * L.cout * es * 3);
+            launch_bn_bwd_apply(b, apply_on);
+            prof.end(apply_on, tok);
+            dy = b.dy_out ? b.dy_out : s.dact.p; dy_dt = dtype;
+            if (fused_apply && has_dgrad) {
+                dg.src.kind = SRC_BNBWD; dg.src.a = s.dact.p; dg.src.b = s.raw.p;
+                dg.src.a_scale = s.scale; dg.src.a_shift = s.shift;
+                dg.src.bn_mean = s.mean; dg.src.bn_invstd = s.invstd; dg.src.bn_coef = s.coef;
+            } else if (has_dgrad) dg.src.a = dy;
+        } else { dy = dlogits.p; dy_dt = DT_F32; if (has_dgrad) dg.src.a = dy; }
 
-        const double flops = 2.0 * L.k * L.k * L.cin * L.cout * (double)(L.type == 0 ? p_out : p_in);
         {   // filter gradient
             WgradArgs g;
             g.src = layer_source(li, last_image);
@@ -486,29 +521,21 @@ void Engine::backward(const uint16_t* d_labels, const float* d_weights, double l
             g.dw = grad.as<float>() + L.w_off;
             const double bytes = (double)p_in * L.cin * (L.in_a < 0 ? 1.0 : es) * (L.in_b >= 0 ? 2 : 1) + (double)p_out * L.cout * (L.has_bn ? es : 4.0);
             hipStream_t on = stream;
-            if (concurrent_wgrad && aux_stream) {   // dy of this layer is final on the main stream: let the aux stream pick it up
-                HIP_CHECK(hipEventRecord(ev_dy_ready, stream));
-                HIP_CHECK(hipStreamWaitEvent(aux_stream, ev_dy_ready, 0));
+            if (two_streams) {
+                if (!fused_apply) {   // dy of this layer is final on the main stream: let the second stream pick it up
+                    HIP_CHECK(hipEventRecord(ev_dy_ready, stream));
+                    HIP_CHECK(hipStreamWaitEvent(aux_stream, ev_dy_ready, 0));
+                }
                 on = aux_stream;
             }
             wgrad_dispatch(g, (std::string("wgrad_") + layer_tag(L)).c_str(), flops, bytes, on);
         }
-        if (L.in_a >= 0) {   // data gradient -> d(activation of the producing layers)
-            ConvArgs a;
-            a.src.kind = SRC_RAW; a.src.dtype = dy_dt; a.src.a = dy;
-            a.n = s.n; a.h_in = s.h; a.w_in = s.w; a.c_red = L.cout;
-            a.h_out = s.h_in; a.w_out = s.w_in; a.c_out = L.cin;
-            a.k = L.k; a.stride = L.stride; a.pad = L.pad; a.gather = 1 - L.type;
-            a.w_f32 = w_km_f32.as<float>() + L.w_off;
-            a.w_bf16 = dtype == DT_BF16 ? (const void*)(w_tm_bf16.as<uint16_t>() + L.w_off) : nullptr;
-            a.out = ls[L.in_a].dact.p; a.out_dtype = dtype; a.out_accumulate = ls[L.in_a].dact_written ? 1 : 0;
+        if (has_dgrad) {   // data gradient -> d(activation of the producing layers)
             ls[L.in_a].dact_written = true;
-            if (L.in_b >= 0) {
-                a.out2 = ls[L.in_b].dact.p; a.out2_accumulate = ls[L.in_b].dact_written ? 1 : 0;
-                ls[L.in_b].dact_written = true;
-            }
-            const double bytes = (double)p_out * L.cout * (L.has_bn ? es : 4.0) + (double)p_in * L.cin * es * (L.in_b >= 0 ? 2 : 1) * (a.out_accumulate ? 2 : 1);
-            conv_dispatch(a, (std::string("dgrad_") + layer_tag(L)).c_str(), flops, bytes);
+            if (L.in_b >= 0) ls[L.in_b].dact_written = true;
+            const double bytes = (double)p_out * L.cout * (L.has_bn ? es : 4.0) * (dg.src.kind == SRC_BNBWD ? 2 : 1) +
+                                 (double)p_in * L.cin * es * (L.in_b >= 0 ? 2 : 1) * (dg.out_accumulate ? 2 : 1);
+            conv_dispatch(dg, (std::string("dgrad_") + layer_tag(L)).c_str(), flops, bytes);
         }
     }
     if (concurrent_wgrad && aux_stream) {  // gradients are complete on the main stream only after the aux stream drains

@@ -15,7 +15,13 @@ enum SrcKind {
     SRC_RAW = 0,    // value = a[i]
     SRC_ACT = 1,    // value = relu(a[i]*scale_a[c] + shift_a[c])
     SRC_ACT2 = 2,   // value = relu(a[i]*scale_a[c]+shift_a[c]) + relu(b[i]*scale_b[c]+shift_b[c])   (skip add)
-    SRC_IMAGE = 3   // value = u8 image / 256, read through a clamp-to-edge window (annonet_infer.cpp:68-75)
+    SRC_IMAGE = 3,  // value = u8 image / 256, read through a clamp-to-edge window (annonet_infer.cpp:68-75)
+    // value = the batch-norm + relu BACKWARD of a layer, applied on the fly (backward-data convs on the MFMA path):
+    //   a = da (gradient w.r.t. the layer's post-activation output), b = y (its raw conv output),
+    //   dz = (y*scale + shift > 0) ? da : 0,  value = coef0 * (dz - coef1 - (y - mean)*invstd * coef2)
+    // with a_scale/a_shift = the layer's folded (scale, shift) and bn_mean / bn_invstd / bn_coef ([3][C], from the
+    // bn backward finalize kernel) — the same expression, in the same order, as the bn_bwd_apply kernels.
+    SRC_BNBWD = 4
 };
 
 struct Src {
@@ -23,6 +29,7 @@ struct Src {
     int dtype = DT_F32;
     const void* a = nullptr; const float* a_scale = nullptr; const float* a_shift = nullptr;
     const void* b = nullptr; const float* b_scale = nullptr; const float* b_shift = nullptr;
+    const float* bn_mean = nullptr; const float* bn_invstd = nullptr; const float* bn_coef = nullptr;  // SRC_BNBWD
     // SRC_IMAGE: sample n lives at img + n*img_sample_stride; the net input window starts at (img_left, img_top)
     const uint8_t* img = nullptr;
     int img_h = 0, img_w = 0, img_left = 0, img_top = 0;
@@ -97,11 +104,12 @@ struct BnBwdArgs {
     float* dgamma = nullptr; float* dbeta = nullptr;  // destinations in the gradient blob
     double* partials = nullptr;
     float* coef = nullptr;  // scratch 3*c floats
+    void* dy_out = nullptr; // apply: destination (default: in place over da)
 };
 void launch_bn_backward(const BnBwdArgs& a, hipStream_t s);   // = reduce, finalize, apply
 void launch_bn_bwd_reduce(const BnBwdArgs& a, hipStream_t s);
 void launch_bn_bwd_finalize(const BnBwdArgs& a, hipStream_t s);
-void launch_bn_bwd_apply(const BnBwdArgs& a, hipStream_t s);
+void launch_bn_bwd_apply(const BnBwdArgs& a, hipStream_t s);   // writes BnBwdArgs::dy_out when set, else over da
 
 // loss_multiclass_log_per_pixel_weighted on fp32 NHWC logits [P][K]; writes dlogits in place of nothing (separate buffer),
 // the summed loss (double) and the bias gradient.
@@ -175,6 +183,9 @@ void launch_conv_mfma(const ConvArgs& a, hipStream_t s);
 // > 0: the MFMA kernel of this layer can also write the bn statistic partials (set ConvArgs::stat_partials; the
 // value is the number of partials per channel to pass to launch_bn_forward_finalize)
 int conv_fused_stat_blocks(const ConvArgs& a);
+// the layer's MFMA kernel can read its input through SRC_BNBWD (decided on the args with src.kind = SRC_RAW)
+bool conv_accepts_bnbwd(const ConvArgs& a);
+bool bn_bwd_apply_fusion_enabled();  // ANH_FUSE_BN_BWD_APPLY=1 (off by default: measured slower)
 bool mfma_wgrad_supported(const WgradArgs& a);
 void launch_wgrad_mfma(const WgradArgs& a, hipStream_t s);
 int64_t wgrad_mfma_scratch_floats(const WgradArgs& a);

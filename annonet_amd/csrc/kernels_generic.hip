@@ -610,7 +610,7 @@ __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const double* parti
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(T* da, const T* y, int64_t total, int c, const float* mean, const float* invstd,
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* da, T* out, const T* y, int64_t total, int c, const float* mean, const float* invstd,
                                                            const float* scale, const float* shift, const float* coef) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
@@ -618,7 +618,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(T* da, const T* y, in
         const float yv = to_f<T>(y[i]);
         const float dz = fmaf(yv, scale[ch], shift[ch]) > 0.f ? to_f<T>(da[i]) : 0.f;
         const float xhat = (yv - mean[ch]) * invstd[ch];
-        da[i] = from_f<T>(coef[ch] * (dz - coef[c + ch] - xhat * coef[2 * c + ch]));
+        out[i] = from_f<T>(coef[ch] * (dz - coef[c + ch] - xhat * coef[2 * c + ch]));
     }
 }
 
@@ -692,7 +692,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_vec_kernel(const T* da, con
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(T* da, const T* y, int64_t chunks, int c, const float* mean, const float* invstd,
+__global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(const T* da, T* out, const T* y, int64_t chunks, int c, const float* mean, const float* invstd,
                                                                const float* scale, const float* shift, const float* coef) {
     const int groups = c >> 3;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;  // a multiple of `groups`: a thread keeps its channel group
@@ -715,7 +715,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(T* da, const T* y
             const float xhat = (yv[j] - m[j]) * is[j];
             r[j] = k0[j] * (dz - k1[j] - xhat * k2[j]);
         }
-        store8<T>(da + (size_t)i * 8, r);
+        store8<T>(out + (size_t)i * 8, r);
     }
 }
 
@@ -1264,19 +1264,20 @@ void launch_bn_bwd_finalize(const BnBwdArgs& a, hipStream_t s) {
 void launch_bn_bwd_apply(const BnBwdArgs& a, hipStream_t s) {
     const int64_t total = a.pixels * a.c;
     const bool bf = a.dtype == DT_BF16;
+    void* out = a.dy_out ? a.dy_out : a.da;
     if (bn_vec_ok(a.c)) {
         const int64_t chunks = total / 8;
         const int apply_blocks = (int)std::min<int64_t>((chunks + 255) / 256, 256 * 8);  // 256 threads: a multiple of every group count
-        if (bf) hipLaunchKernelGGL(bn_bwd_apply_vec_kernel<bf16>, dim3(apply_blocks), dim3(256), 0, s, reinterpret_cast<bf16*>(a.da), reinterpret_cast<const bf16*>(a.y),
-                                   chunks, a.c, a.mean, a.invstd, a.scale, a.shift, a.coef);
-        else hipLaunchKernelGGL(bn_bwd_apply_vec_kernel<float>, dim3(apply_blocks), dim3(256), 0, s, reinterpret_cast<float*>(a.da), reinterpret_cast<const float*>(a.y),
-                                chunks, a.c, a.mean, a.invstd, a.scale, a.shift, a.coef);
+        if (bf) hipLaunchKernelGGL(bn_bwd_apply_vec_kernel<bf16>, dim3(apply_blocks), dim3(256), 0, s, reinterpret_cast<const bf16*>(a.da), reinterpret_cast<bf16*>(out),
+                                   reinterpret_cast<const bf16*>(a.y), chunks, a.c, a.mean, a.invstd, a.scale, a.shift, a.coef);
+        else hipLaunchKernelGGL(bn_bwd_apply_vec_kernel<float>, dim3(apply_blocks), dim3(256), 0, s, reinterpret_cast<const float*>(a.da), reinterpret_cast<float*>(out),
+                                reinterpret_cast<const float*>(a.y), chunks, a.c, a.mean, a.invstd, a.scale, a.shift, a.coef);
     } else {
         const int apply_blocks = (int)std::min<int64_t>((total + 255) / 256, 256 * 16);
-        if (bf) hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16>, dim3(apply_blocks), dim3(256), 0, s, reinterpret_cast<bf16*>(a.da), reinterpret_cast<const bf16*>(a.y),
-                                   total, a.c, a.mean, a.invstd, a.scale, a.shift, a.coef);
-        else hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(apply_blocks), dim3(256), 0, s, reinterpret_cast<float*>(a.da), reinterpret_cast<const float*>(a.y),
-                                total, a.c, a.mean, a.invstd, a.scale, a.shift, a.coef);
+        if (bf) hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16>, dim3(apply_blocks), dim3(256), 0, s, reinterpret_cast<const bf16*>(a.da), reinterpret_cast<bf16*>(out),
+                                   reinterpret_cast<const bf16*>(a.y), total, a.c, a.mean, a.invstd, a.scale, a.shift, a.coef);
+        else hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(apply_blocks), dim3(256), 0, s, reinterpret_cast<const float*>(a.da), reinterpret_cast<float*>(out),
+                                reinterpret_cast<const float*>(a.y), total, a.c, a.mean, a.invstd, a.scale, a.shift, a.coef);
     }
     HIP_CHECK(hipGetLastError());
 }

@@ -251,7 +251,7 @@ __device__ __forceinline__ void side_commit(const SideRegs<KIND, ITEMS>& R, char
 // prologue of one 16-byte chunk with the per-channel constants given as pointers (registers or an LDS table)
 template <int KIND>
 __device__ __forceinline__ uint4 chunk_convert(const RawChunk<KIND>& r, const float* sa, const float* ta, const float* sb, const float* tb) {
-    if (KIND == SRC_RAW) return r.a;
+    if (KIND == SRC_RAW || KIND == SRC_BNBWD) return r.a;  // (SRC_BNBWD goes through chunk_bnbwd)
     float v[8];
     affine8(r.a, sa, ta, v);
     if (KIND == SRC_ACT2) {
@@ -261,6 +261,25 @@ __device__ __forceinline__ uint4 chunk_convert(const RawChunk<KIND>& r, const fl
         for (int j = 0; j < 8; ++j) v[j] += u[j];
     }
     return make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
+}
+
+// SRC_BNBWD prologue of one 16-byte chunk: a = da, b = y; the expression and its order are those of bn_bwd_apply_vec_kernel
+__device__ __forceinline__ uint4 chunk_bnbwd(const uint4& da, const uint4& y, const float* sc, const float* sf, const float* m, const float* is,
+                                             const float* k0, const float* k1, const float* k2) {
+    const unsigned wd[4] = {da.x, da.y, da.z, da.w}, wy[4] = {y.x, y.y, y.z, y.w};
+    float r[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int j = 2 * i + h;
+            const float yv = h ? hi_f(wy[i]) : lo_f(wy[i]), dv = h ? hi_f(wd[i]) : lo_f(wd[i]);
+            const float dz = fmaf(yv, sc[j], sf[j]) > 0.f ? dv : 0.f;
+            const float xhat = (yv - m[j]) * is[j];
+            r[j] = k0[j] * (dz - k1[j] - xhat * k2[j]);
+        }
+    }
+    return make_uint4(pack2(r[0], r[1]), pack2(r[2], r[3]), pack2(r[4], r[5]), pack2(r[6], r[7]));
 }
 
 // weights of NTAPS taps for one 32-channel slab -> LDS records [tap][co][32 ci]; loads first, then writes
@@ -474,7 +493,7 @@ template <int KIND>
 __device__ __forceinline__ RawChunk<KIND> side_load_at(const bf16* a, const bf16* b, int off) {
     RawChunk<KIND> r;
     r.a = *reinterpret_cast<const uint4*>(a + off);
-    if (KIND == SRC_ACT2) r.b = *reinterpret_cast<const uint4*>(b + off);
+    if (KIND == SRC_ACT2 || KIND == SRC_BNBWD) r.b = *reinterpret_cast<const uint4*>(b + off);
     return r;
 }
 
@@ -645,11 +664,8 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_mfma_kernel(WgParams a, int t
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// conv3x3_pipe: the 3x3 layers (stride-1 con and its mirrored backward-data; stride-2 con / cont backward-data;
-// cont / stride-2 con backward-data) as ONE persistent, software-pipelined kernel with a geometry policy.
-// A workgroup walks (pixel tile, 32-channel slab) items; while the MFMAs of one item run, the global loads of the next
-// item (input patch chunks and, for multi-slab layers, the slab's filter block) are in flight in registers; the
-// prologue (producer's bn + relu, skip add) and the LDS write follow after the next barrier.
+// Geometry policies of the persistent 3x3 conv kernel (conv3x3_ws below): stride-1 con and its mirrored backward-data;
+// stride-2 con / cont backward-data; cont / stride-2 con backward-data.
 // LDS pixel records are swizzled by the patch COLUMN (column within the parity plane for stride 2), so every operand
 // address in the MFMA phase is (lane offset computed once per kernel) + (compile-time constant carried by the ds_read's
 // immediate): no address arithmetic between MFMAs.  Mirrored taps are handled by staging the filter taps in reverse
@@ -665,7 +681,7 @@ __device__ __forceinline__ const char* swz_addr(const char* base, int rec, int k
 __device__ __forceinline__ bf16x8 lds_frag(const char* p) { return *reinterpret_cast<const bf16x8*>(p); }
 
 struct GeoS1 {
-    static constexpr int RECS = PATCH_PIX, ACC = 2, TILE_H = TH, TILE_W = TW;
+    static constexpr int RECS = PATCH_PIX, ACC = 2;
     __device__ static void decode(int rec, int& py, int& px, int& key) { py = rec / PW; px = rec - py * PW; key = (px >> 2) & 3; }
     __device__ static int in_y0(int ty) { return ty * TH - 1; }
     __device__ static int in_x0(int tx) { return tx * TW - 1; }
@@ -706,7 +722,7 @@ struct GeoS1 {
 };
 
 struct GeoDown {
-    static constexpr int RECS = 9 * 66, ACC = 1, TILE_H = 4, TILE_W = 32;
+    static constexpr int RECS = 9 * 66, ACC = 1;
     __device__ static void decode(int rec, int& py, int& px, int& key) {
         py = rec / 66;
         const int rem = rec - py * 66, par = rem >= 33, u = rem - 33 * par;
@@ -747,7 +763,7 @@ struct GeoDown {
 };
 
 struct GeoUp {
-    static constexpr int RECS = 5 * 33, ACC = 4, TILE_H = 4, TILE_W = 32;
+    static constexpr int RECS = 5 * 33, ACC = 4;
     __device__ static void decode(int rec, int& py, int& px, int& key) { py = rec / 33; px = rec - py * 33; key = (px >> 2) & 3; }
     __device__ static int in_y0(int ty) { return ty * 4 - 1; }
     __device__ static int in_x0(int tx) { return tx * 32 - 1; }
@@ -794,146 +810,9 @@ struct GeoUp {
     }
 };
 
-template <class G, int NT, int KIND>
-__global__ __launch_bounds__(256, 2) void conv3x3_pipe_kernel(ConvArgs a, int tiles_x, int tiles_y, int flip) {
-    constexpr int C_OUT = NT * 32, NP = (G::RECS * 4 + 255) / 256, W_ITEMS = 9 * C_OUT * 4, NW = (W_ITEMS + 255) / 256;
-    constexpr int X_BYTES_ = G::RECS * 64, W_BYTES = 9 * C_OUT * 64;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* lds_x = smem;
-    char* lds_w = smem + X_BYTES_;
-    float* tab = reinterpret_cast<float*>(smem + X_BYTES_ + W_BYTES);  // [a_scale | a_shift | b_scale | b_shift][c_red]
-
-    const int tid = threadIdx.x, lane = tid & 63, c16 = tid & 3;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int half = lane >> 5, col = lane & 31;
-    const int co_base = blockIdx.y * C_OUT;
-    const int H = a.h_in, W = a.w_in, c_red = a.c_red;
-    const int n_slabs = c_red >> 5, n_tiles = tiles_x * tiles_y * a.n;
-    const bf16* wsrc = reinterpret_cast<const bf16*>(a.w_bf16);
-    const bf16* xa = reinterpret_cast<const bf16*>(a.src.a);
-    const bf16* xb = reinterpret_cast<const bf16*>(a.src.b);
-    const size_t plane = (size_t)H * W * c_red;  // < 2^31 elements (host check)
-
-    if (KIND != SRC_RAW) {
-        for (int i = tid; i < c_red; i += 256) {
-            tab[i] = a.src.a_scale[i];
-            tab[c_red + i] = a.src.a_shift[i];
-            tab[2 * c_red + i] = KIND == SRC_ACT2 ? a.src.b_scale[i] : 0.f;
-            tab[3 * c_red + i] = KIND == SRC_ACT2 ? a.src.b_shift[i] : 0.f;
-        }
-    }
-
-    // ---- staging geometry, fixed per thread: patch chunk jj = record (tid >> 2) + 64 jj ----
-    int pgeo[NP], pdst[NP];
-#pragma unroll
-    for (int jj = 0; jj < NP; ++jj) {
-        const int rec = min((tid >> 2) + 64 * jj, G::RECS - 1);
-        int py, px, key;
-        G::decode(rec, py, px, key);
-        pgeo[jj] = py | (px << 8);
-        pdst[jj] = rec * 64 + ((c16 ^ key) << 4);
-    }
-    // filter chunk j = record (tid >> 2) + 64 j = (tap slot, co); slot t holds tap t, or 8 - t for mirrored taps
-    int wsrc_off[NW], wdst[NW];
-#pragma unroll
-    for (int j = 0; j < NW; ++j) {
-        const int rec = min((tid >> 2) + 64 * j, 9 * C_OUT - 1);
-        const int tl = rec / C_OUT, co = rec - tl * C_OUT;
-        const int tap = flip ? 8 - tl : tl;
-        wsrc_off[j] = (tap * a.c_out + co_base + co) * c_red + c16 * 8;
-        wdst[j] = rec * 64 + ((c16 ^ ((co >> 2) & 3)) << 4);
-    }
-    // ---- MFMA operand addresses: lane parts ----
-    typename G::Bases xbases;
-    G::init(xbases, lds_x, wave, col, half);
-    const char* wbase[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) wbase[ks] = swz_addr(lds_w, col, col >> 2, ks, half);
-
-    f32x16 acc[G::ACC][NT];
-    RawChunk<KIND> praw[NP];
-    u32x4 wraw[NW];  // a native vector type: hipcc keeps a HIP uint4 that is only copied (never unpacked) in scratch
-    unsigned pok = 0;
-    auto fetch = [&](int tile, int slab, bool with_w) __attribute__((always_inline)) {
-        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
-        const int x0 = G::in_x0(tx), y0 = G::in_y0(ty);
-        const bf16* pa = xa + (size_t)n * plane;
-        const bf16* pb = KIND == SRC_ACT2 ? xb + (size_t)n * plane : nullptr;
-        const int cc = slab * 32;
-        pok = 0;
-#pragma unroll
-        for (int jj = 0; jj < NP; ++jj) {
-            const int iy = y0 + (pgeo[jj] & 255), ix = x0 + (pgeo[jj] >> 8);
-            const int cy = min(max(iy, 0), H - 1), cx = min(max(ix, 0), W - 1);
-            praw[jj] = side_load_at<KIND>(pa, pb, (cy * W + cx) * c_red + cc + c16 * 8);
-            pok |= ((iy == cy && ix == cx) ? 1u : 0u) << jj;
-        }
-        if (with_w) {
-#pragma unroll
-            for (int j = 0; j < NW; ++j) wraw[j] = *reinterpret_cast<const u32x4*>(wsrc + wsrc_off[j] + cc);
-        }
-    };
-
-    int tile = blockIdx.x, slab = 0;
-    bool first = true;
-    if (tile < n_tiles) fetch(tile, 0, true);
-    while (tile < n_tiles) {
-        int ntile = tile, nslab = slab + 1;
-        if (nslab == n_slabs) { nslab = 0; ntile += gridDim.x; }
-        const bool stage_w = first || n_slabs > 1;
-        __syncthreads();  // every wave is done with the previous item's LDS contents (and the bn table is written)
-        // ---- prologue + LDS write of the fetched item ----
-        {
-            float sa[8], ta[8], sb[8], tb[8];
-            if (KIND != SRC_RAW) {
-                const float* t0 = tab + slab * 32 + c16 * 8;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    sa[j] = t0[j]; ta[j] = t0[c_red + j];
-                    sb[j] = KIND == SRC_ACT2 ? t0[2 * c_red + j] : 0.f; tb[j] = KIND == SRC_ACT2 ? t0[3 * c_red + j] : 0.f;
-                }
-            }
-#pragma unroll
-            for (int jj = 0; jj < NP; ++jj) {
-                uint4 v = chunk_convert<KIND>(praw[jj], sa, ta, sb, tb);
-                if (!((pok >> jj) & 1u)) v = make_uint4(0u, 0u, 0u, 0u);
-                if ((tid >> 2) + 64 * jj < G::RECS) *reinterpret_cast<uint4*>(lds_x + pdst[jj]) = v;
-            }
-            if (stage_w) {
-#pragma unroll
-                for (int j = 0; j < NW; ++j)
-                    if ((tid >> 2) + 64 * j < 9 * C_OUT) *reinterpret_cast<u32x4*>(lds_w + wdst[j]) = wraw[j];
-            }
-        }
-        __syncthreads();
-        if (ntile < n_tiles) fetch(ntile, nslab, n_slabs > 1);
-        first = false;
-
-        if (slab == 0) {
-#pragma unroll
-            for (int g = 0; g < G::ACC; ++g)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[g][nt][r] = 0.f;
-        }
-        G::template mfma<NT>(acc, xbases, wbase);
-        if (slab == n_slabs - 1) {
-            const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
-#pragma unroll
-            for (int g = 0; g < G::ACC; ++g) {
-                size_t pix; bool valid;
-                G::out_pixel(g, a, n, ty, tx, wave, col, pix, valid);
-                store_pixel_tiles<NT>(acc[g], a, pix, valid, half, co_base);
-            }
-        }
-        tile = ntile; slab = nslab;
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------------------
-// conv3x3_ws: the same layers, geometry policies and LDS layout as conv3x3_pipe, with the two halves of the work on
-// different waves of one 512-thread workgroup (1 workgroup per CU, 2 waves per SIMD):
+// conv3x3_ws: the 3x3 layers as ONE persistent, warp-specialised kernel.  A workgroup walks (pixel tile, 32-channel slab)
+// items with the two halves of the work on different waves of a 512-thread workgroup (1 workgroup per CU, 2 waves per SIMD):
 //   waves 4..7 (producers): global loads of item i+1 into registers, prologue (bn + relu, skip add), LDS write into
 //                           buffer (i+1) & 1;
 //   waves 0..3 (consumers): MFMAs of item i from buffer i & 1, epilogue stores.
@@ -966,12 +845,20 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
     constexpr bool CAN_STATS = G::ACC * NT <= 4;  // register budget of the consumer waves
     const bool fuse_stats = CAN_STATS && a.stat_partials != nullptr;
 
-    if (KIND != SRC_RAW) {
+    if (KIND != SRC_RAW) {  // SRC_BNBWD: [scale | shift | mean | invstd | coef0 | coef1 | coef2][c_red]
         for (int i = threadIdx.x; i < c_red; i += 512) {
             tab[i] = a.src.a_scale[i];
             tab[c_red + i] = a.src.a_shift[i];
-            tab[2 * c_red + i] = KIND == SRC_ACT2 ? a.src.b_scale[i] : 0.f;
-            tab[3 * c_red + i] = KIND == SRC_ACT2 ? a.src.b_shift[i] : 0.f;
+            if (KIND == SRC_BNBWD) {
+                tab[2 * c_red + i] = a.src.bn_mean[i];
+                tab[3 * c_red + i] = a.src.bn_invstd[i];
+                tab[4 * c_red + i] = a.src.bn_coef[i];
+                tab[5 * c_red + i] = a.src.bn_coef[c_red + i];
+                tab[6 * c_red + i] = a.src.bn_coef[2 * c_red + i];
+            } else {
+                tab[2 * c_red + i] = KIND == SRC_ACT2 ? a.src.b_scale[i] : 0.f;
+                tab[3 * c_red + i] = KIND == SRC_ACT2 ? a.src.b_shift[i] : 0.f;
+            }
         }
     }
     __syncthreads();
@@ -1009,7 +896,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
             const int tx = tile_ % tiles_x, ty = (tile_ / tiles_x) % tiles_y, n = tile_ / (tiles_x * tiles_y);
             const int x0 = G::in_x0(tx), y0 = G::in_y0(ty);
             const bf16* pa = xa + (size_t)n * plane;
-            const bf16* pb = KIND == SRC_ACT2 ? xb + (size_t)n * plane : nullptr;
+            const bf16* pb = (KIND == SRC_ACT2 || KIND == SRC_BNBWD) ? xb + (size_t)n * plane : nullptr;
             const int cc = slab_ * 32;
             pok = 0;
 #pragma unroll
@@ -1033,18 +920,22 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
             // a single-slab layer's filter block goes into both buffers once (its registers are not refetched)
             const bool stage_w = it < 2 || n_slabs > 1;
             {
-                float sa[8], ta[8], sb[8], tb[8];
+                float sa[8], ta[8], sb[8], tb[8], q0[8], q1[8], q2[8];
                 if (KIND != SRC_RAW) {
                     const float* t0 = tab + slab * 32 + c16 * 8;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         sa[j] = t0[j]; ta[j] = t0[c_red + j];
-                        sb[j] = KIND == SRC_ACT2 ? t0[2 * c_red + j] : 0.f; tb[j] = KIND == SRC_ACT2 ? t0[3 * c_red + j] : 0.f;
+                        sb[j] = (KIND == SRC_ACT2 || KIND == SRC_BNBWD) ? t0[2 * c_red + j] : 0.f;
+                        tb[j] = (KIND == SRC_ACT2 || KIND == SRC_BNBWD) ? t0[3 * c_red + j] : 0.f;
+                        q0[j] = KIND == SRC_BNBWD ? t0[4 * c_red + j] : 0.f;
+                        q1[j] = KIND == SRC_BNBWD ? t0[5 * c_red + j] : 0.f;
+                        q2[j] = KIND == SRC_BNBWD ? t0[6 * c_red + j] : 0.f;
                     }
                 }
 #pragma unroll
                 for (int jj = 0; jj < NP; ++jj) {
-                    uint4 v = chunk_convert<KIND>(praw[jj], sa, ta, sb, tb);
+                    uint4 v = KIND == SRC_BNBWD ? chunk_bnbwd(praw[jj].a, praw[jj].b, sa, ta, sb, tb, q0, q1, q2) : chunk_convert<KIND>(praw[jj], sa, ta, sb, tb);
                     if (!((pok >> jj) & 1u)) v = make_uint4(0u, 0u, 0u, 0u);
                     if ((tid >> 2) + 64 * jj < G::RECS) *reinterpret_cast<uint4*>(lbuf + pdst[jj]) = v;
                 }
@@ -1173,7 +1064,7 @@ template <class G, int NT>
 void launch_ws(const ConvArgs& a, int tiles_x, int tiles_y, int flip, hipStream_t s) {
     const int n_tiles = tiles_x * tiles_y * a.n, groups = a.c_out / (NT * 32);
     const dim3 grid((unsigned)std::max(1, std::min(n_tiles, ws_target_wgs() / groups)), (unsigned)groups), block(512);
-    const size_t lds = 2 * ((size_t)G::RECS * 64 + (size_t)9 * NT * 32 * 64) + (size_t)a.c_red * 16;
+    const size_t lds = 2 * ((size_t)G::RECS * 64 + (size_t)9 * NT * 32 * 64) + (size_t)a.c_red * (a.src.kind == SRC_BNBWD ? 28 : 16);
     auto launch = [&](auto kernel) {
         if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 #ifndef ANH_WS_PROFILE
@@ -1203,25 +1094,8 @@ void launch_ws(const ConvArgs& a, int tiles_x, int tiles_y, int flip, hipStream_
     switch (a.src.kind) {
         case SRC_RAW: launch(conv3x3_ws_kernel<G, NT, SRC_RAW>); break;
         case SRC_ACT: launch(conv3x3_ws_kernel<G, NT, SRC_ACT>); break;
+        case SRC_BNBWD: launch(conv3x3_ws_kernel<G, NT, SRC_BNBWD>); break;
         default: launch(conv3x3_ws_kernel<G, NT, SRC_ACT2>); break;
-    }
-    HIP_CHECK(hipGetLastError());
-}
-
-template <class G, int NT>
-void launch_pipe(const ConvArgs& a, int tiles_x, int tiles_y, int flip, hipStream_t s) {
-    const int n_tiles = tiles_x * tiles_y * a.n, groups = a.c_out / (NT * 32);
-    static const int target = getenv("ANH_PIPE_WGS") ? atoi(getenv("ANH_PIPE_WGS")) : 512;  // 2 per CU
-    const dim3 grid((unsigned)std::max(1, std::min(n_tiles, target / groups)), (unsigned)groups), block(256);
-    const size_t lds = (size_t)G::RECS * 64 + (size_t)9 * NT * 32 * 64 + (size_t)a.c_red * 16;
-    auto launch = [&](auto kernel) {
-        if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kernel, grid, block, lds, s, a, tiles_x, tiles_y, flip);
-    };
-    switch (a.src.kind) {
-        case SRC_RAW: launch(conv3x3_pipe_kernel<G, NT, SRC_RAW>); break;
-        case SRC_ACT: launch(conv3x3_pipe_kernel<G, NT, SRC_ACT>); break;
-        default: launch(conv3x3_pipe_kernel<G, NT, SRC_ACT2>); break;
     }
     HIP_CHECK(hipGetLastError());
 }
@@ -1719,11 +1593,14 @@ void launch_up(const ConvArgs& a, hipStream_t s) {
 
 }  // namespace
 
+namespace { bool bnbwd_form_ok(const ConvArgs& a); }
+
 bool mfma_conv_supported(const ConvArgs& a) {
     if (stem_mfma_ok(a)) return true;
     if (a.k != 3 || !a.w_bf16) return false;
     if (a.src.kind == SRC_IMAGE || a.src.dtype != DT_BF16 || a.out_dtype != DT_BF16 || a.out_nchw || a.bias) return false;
     if (a.c_red % 32 != 0) return false;
+    if (a.src.kind == SRC_BNBWD && !bnbwd_form_ok(a)) return false;  // only the warp-specialised kernels carry that prologue
     if (a.stride == 1 && a.pad == 1)
         return (a.c_out == 32 || a.c_out == 64 || a.c_out == 128) && a.h_in == a.h_out && a.w_in == a.w_out;
     if (a.stride == 2 && a.pad == 0 && a.gather == 0)
@@ -1736,13 +1613,12 @@ bool mfma_conv_supported(const ConvArgs& a) {
 
 namespace {
 // which kernel a supported 3x3 layer takes, and its launch geometry
-struct ConvPlan { int geo /*0 s1, 1 down, 2 up*/, nt, tiles_x, tiles_y, flip, form /*0 classic, 1 pipelined, 2 warp-specialised*/, grid_x, groups; };
+struct ConvPlan { int geo /*0 s1, 1 down, 2 up*/, nt, tiles_x, tiles_y, flip, form /*0 classic one-tile kernels, 2 warp-specialised*/, grid_x, groups; };
 
 int ws_target_wgs() { static const int t = getenv("ANH_WS_WGS") ? atoi(getenv("ANH_WS_WGS")) : 256; return t; }  // 1 per CU
 
 ConvPlan conv_plan(const ConvArgs& a) {
-    static const int pipe = getenv("ANH_CONV_PIPE") ? atoi(getenv("ANH_CONV_PIPE")) : 7;  // bit 0: stride 1, bit 1: down, bit 2: up
-    static const int wsm = getenv("ANH_CONV_WS") ? atoi(getenv("ANH_CONV_WS")) : 7;      // same bits: warp-specialised form
+    static const int wsm = getenv("ANH_CONV_WS") ? atoi(getenv("ANH_CONV_WS")) : 7;  // bit 0: stride 1, bit 1: down, bit 2: up (0 = the classic one-tile kernels)
     // the persistent kernels index within one image with 32-bit element offsets
     const bool small_plane = (int64_t)a.h_in * a.w_in * a.c_red < (1ll << 31);
     ConvPlan p{};
@@ -1753,13 +1629,32 @@ ConvPlan conv_plan(const ConvArgs& a) {
     else if (p.geo == 1) { p.tiles_x = (a.w_out + 31) / 32; p.tiles_y = (a.h_out + 3) / 4; }
     else { p.tiles_x = (a.w_in + 1 + 31) / 32; p.tiles_y = (a.h_in + 1 + 3) / 4; }
     const int bit = 1 << p.geo;
-    p.form = small_plane ? ((wsm & bit) ? 2 : (pipe & bit) ? 1 : 0) : 0;
+    p.form = (small_plane && (wsm & bit)) ? 2 : 0;
     p.groups = a.c_out / (p.nt * 32);
     const int n_tiles = p.tiles_x * p.tiles_y * a.n;
     p.grid_x = std::max(1, std::min(n_tiles, ws_target_wgs() / p.groups));
     return p;
 }
 }  // namespace
+
+namespace {
+bool bnbwd_form_ok(const ConvArgs& a) {
+    // Off by default.  Measured: with the apply pass moved to the second stream the backward step gets
+    // SLOWER (2.34 vs 2.01 ms) — the backward pass is HBM-bound as a whole, and this schedule adds a read of y per layer.
+    return bn_bwd_apply_fusion_enabled() && a.k == 3 && conv_plan(a).form == 2;
+}
+}  // namespace
+
+bool bn_bwd_apply_fusion_enabled() {
+    static const int on = getenv("ANH_FUSE_BN_BWD_APPLY") ? atoi(getenv("ANH_FUSE_BN_BWD_APPLY")) : 0;
+    return on != 0;
+}
+
+bool conv_accepts_bnbwd(const ConvArgs& a) {
+    ConvArgs b = a;
+    b.src.kind = SRC_BNBWD;
+    return mfma_conv_supported(b) && !stem_mfma_ok(b);
+}
 
 // Number of per-workgroup statistic partials the conv kernel will write when ConvArgs::stat_partials is set
 // (layout [channel][sum | sum of squares][workgroup]); 0 when this layer's kernel does not fuse the statistics.
@@ -1780,18 +1675,15 @@ void launch_conv_mfma(const ConvArgs& a, hipStream_t s) {
     ANH_REQUIRE(!a.stat_partials || conv_fused_stat_blocks(a) > 0, "conv_mfma: this layer's kernel does not fuse bn statistics");
     if (p.geo == 0) {
         if (p.form == 2) { if (p.nt == 1) launch_ws<GeoS1, 1>(a, p.tiles_x, p.tiles_y, p.flip, s); else launch_ws<GeoS1, 2>(a, p.tiles_x, p.tiles_y, p.flip, s); }
-        else if (p.form == 1) { if (p.nt == 1) launch_pipe<GeoS1, 1>(a, p.tiles_x, p.tiles_y, p.flip, s); else launch_pipe<GeoS1, 2>(a, p.tiles_x, p.tiles_y, p.flip, s); }
         else if (a.c_out == 32) launch_s1<1, 9>(a, s);
         else launch_s1<2, 9>(a, s);
     } else if (p.geo == 1) {
         if (p.form == 2) { if (p.nt == 1) launch_ws<GeoDown, 1>(a, p.tiles_x, p.tiles_y, 0, s); else launch_ws<GeoDown, 2>(a, p.tiles_x, p.tiles_y, 0, s); }
-        else if (p.form == 1) { if (p.nt == 1) launch_pipe<GeoDown, 1>(a, p.tiles_x, p.tiles_y, 0, s); else launch_pipe<GeoDown, 2>(a, p.tiles_x, p.tiles_y, 0, s); }
         else if (a.c_out == 32) launch_down<1, 9>(a, s);
         else if (a.c_out == 64) launch_down<2, 9>(a, s);
         else launch_down<4, 3>(a, s);
     } else {
         if (p.form == 2) { if (p.nt == 1) launch_ws<GeoUp, 1>(a, p.tiles_x, p.tiles_y, 0, s); else launch_ws<GeoUp, 2>(a, p.tiles_x, p.tiles_y, 0, s); }
-        else if (p.form == 1) { if (p.nt == 1) launch_pipe<GeoUp, 1>(a, p.tiles_x, p.tiles_y, 0, s); else launch_pipe<GeoUp, 2>(a, p.tiles_x, p.tiles_y, 0, s); }
         else if (a.c_out == 32) launch_up<1>(a, s);
         else launch_up<2>(a, s);
     }

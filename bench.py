@@ -13,6 +13,7 @@ bucket.  Inputs are resident in HBM before the timed region.  Prints ONE JSON li
 """
 import argparse
 import json
+import re
 import os
 import sys
 import time
@@ -36,7 +37,8 @@ def pmc_traffic(entry):
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json")
     try:
         with open(path) as f:
-            e = json.load(f)["entries"].get(entry)
+            entries = json.load(f)["entries"]
+            e = entries.get(entry) or entries.get(re.sub(r"_\d+x\d+$", "", entry))  # conv/wgrad entries carry a channel-shape suffix
         return e["traffic_bytes_per_launch"] if e else None
     except (OSError, ValueError, KeyError):
         return None
