@@ -449,6 +449,12 @@ void Engine::backward(const uint16_t* d_labels, const float* d_weights, double l
         launch_loss(a, stream);
         prof.end(stream, tok);
     }
+    for (int i = 0; i < nl; ++i) { ls[i].consumers = 0; ls[i].da_writes = 0; ls[i].fused_bwd_blocks = 0; }
+    for (int i = 0; i < nl; ++i) {
+        if (spec.layers[i].in_a >= 0) ++ls[spec.layers[i].in_a].consumers;
+        if (spec.layers[i].in_b >= 0) ++ls[spec.layers[i].in_b].consumers;
+    }
+    if (fused_head) ++ls[head.in_a].da_writes;  // the fused head kernel wrote d(dec) already
     for (int li = fused_head ? nl - 2 : nl - 1; li >= 0; --li) {
         const anh_layer_desc& L = spec.layers[li];
         LayerState& s = ls[li];
@@ -483,10 +489,15 @@ void Engine::backward(const uint16_t* d_labels, const float* d_weights, double l
             b.dgamma = grad.as<float>() + L.g_off; b.dbeta = grad.as<float>() + L.beta_off;
             b.partials = bn_partials.as<double>(); b.coef = s.coef;
             // one profiler entry per kernel: reduce reads da and y; apply reads both and writes dy
-            int tok = prof.begin(stream, "bn_bwd_reduce", 0, (double)p_out * L.cout * es * 2);
-            launch_bn_bwd_reduce(b, stream);
-            prof.end(stream, tok);
-            tok = prof.begin(stream, "bn_bwd_finalize", 0, (double)bn_partial_blocks(p_out) * L.cout * 16.0);
+            int tok;
+            if (s.fused_bwd_blocks > 0) {   // the conv that wrote da last left the partial sums
+                b.partials = s.bwd_partials.as<double>(); b.partial_blocks = s.fused_bwd_blocks;
+            } else {
+                tok = prof.begin(stream, "bn_bwd_reduce", 0, (double)p_out * L.cout * es * 2);
+                launch_bn_bwd_reduce(b, stream);
+                prof.end(stream, tok);
+            }
+            tok = prof.begin(stream, "bn_bwd_finalize", 0, (double)(b.partial_blocks > 0 ? b.partial_blocks : bn_partial_blocks(p_out)) * L.cout * 16.0);
             launch_bn_bwd_finalize(b, stream);
             prof.end(stream, tok);
             const bool dgrad_fuses = has_dgrad && dtype == DT_BF16 && conv_takes_mfma(dg, dtype) && conv_accepts_bnbwd(dg);
@@ -531,8 +542,20 @@ void Engine::backward(const uint16_t* d_labels, const float* d_weights, double l
             wgrad_dispatch(g, (std::string("wgrad_") + layer_tag(L)).c_str(), flops, bytes, on);
         }
         if (has_dgrad) {   // data gradient -> d(activation of the producing layers)
-            ls[L.in_a].dact_written = true;
-            if (L.in_b >= 0) ls[L.in_b].dact_written = true;
+            LayerState& P = ls[L.in_a];
+            const anh_layer_desc& PL = spec.layers[L.in_a];
+            P.dact_written = true; ++P.da_writes;
+            if (L.in_b >= 0) { ls[L.in_b].dact_written = true; ++ls[L.in_b].da_writes; }
+            // `out` becomes final with this conv: let its epilogue do that layer's bn backward reduction
+            if (PL.has_bn && P.da_writes == P.consumers && dtype == DT_BF16 && conv_takes_mfma(dg, dtype)) {
+                const int blocks = conv_fused_bnred_blocks(dg);
+                if (blocks > 0) {
+                    P.bwd_partials.reserve((size_t)blocks * 2 * PL.cout * sizeof(double));
+                    dg.bnred_y = P.raw.p; dg.bnred_scale = P.scale; dg.bnred_shift = P.shift; dg.bnred_mean = P.mean; dg.bnred_invstd = P.invstd;
+                    dg.bnred_partials = P.bwd_partials.as<double>();
+                    P.fused_bwd_blocks = blocks;
+                }
+            }
             const double bytes = (double)p_out * L.cout * (L.has_bn ? es : 4.0) * (dg.src.kind == SRC_BNBWD ? 2 : 1) +
                                  (double)p_in * L.cin * es * (L.in_b >= 0 ? 2 : 1) * (dg.out_accumulate ? 2 : 1);
             conv_dispatch(dg, (std::string("dgrad_") + layer_tag(L)).c_str(), flops, bytes);

@@ -52,6 +52,12 @@ struct ConvArgs {
     void* out2 = nullptr; int out2_accumulate = 0;  // optional second destination (skip-add gradient)
     int out_nchw = 0;                               // fp32 NCHW destination (boundary layout)
     double* stat_partials = nullptr;                // fused bn statistics (MFMA path), else nullptr
+    // Fused bn + relu backward REDUCTION (MFMA path, backward-data convs): `out` receives its final value da of a layer with
+    // raw output bnred_y and folded constants; the kernel also writes that layer's dgamma / dbeta partial sums
+    // ([channel][sum dz*xhat | sum dz][workgroup], dz = (y*scale+shift > 0) ? da : 0, xhat = (y-mean)*invstd).
+    const void* bnred_y = nullptr;
+    const float* bnred_scale = nullptr; const float* bnred_shift = nullptr; const float* bnred_mean = nullptr; const float* bnred_invstd = nullptr;
+    double* bnred_partials = nullptr;
 };
 
 // dw[tap][ci][co] = sum_pixels src(n, iy, ix, ci) * dy[n,oy,ox,co]; same gather convention as ConvArgs.
@@ -105,6 +111,7 @@ struct BnBwdArgs {
     double* partials = nullptr;
     float* coef = nullptr;  // scratch 3*c floats
     void* dy_out = nullptr; // apply: destination (default: in place over da)
+    int partial_blocks = 0; // finalize: partials per channel when the reduction came from a conv epilogue (0 = bn_partial_blocks(pixels))
 };
 void launch_bn_backward(const BnBwdArgs& a, hipStream_t s);   // = reduce, finalize, apply
 void launch_bn_bwd_reduce(const BnBwdArgs& a, hipStream_t s);
@@ -183,6 +190,7 @@ void launch_conv_mfma(const ConvArgs& a, hipStream_t s);
 // > 0: the MFMA kernel of this layer can also write the bn statistic partials (set ConvArgs::stat_partials; the
 // value is the number of partials per channel to pass to launch_bn_forward_finalize)
 int conv_fused_stat_blocks(const ConvArgs& a);
+int conv_fused_bnred_blocks(const ConvArgs& a);   // same for ConvArgs::bnred_partials (backward-data convs)
 // the layer's MFMA kernel can read its input through SRC_BNBWD (decided on the args with src.kind = SRC_RAW)
 bool conv_accepts_bnbwd(const ConvArgs& a);
 bool bn_bwd_apply_fusion_enabled();  // ANH_FUSE_BN_BWD_APPLY=1 (off by default: measured slower)

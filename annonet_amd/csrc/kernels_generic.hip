@@ -1256,7 +1256,7 @@ void launch_bn_bwd_reduce(const BnBwdArgs& a, hipStream_t s) {
 }
 
 void launch_bn_bwd_finalize(const BnBwdArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(a.c), dim3(64), 0, s, a.partials, bn_partial_blocks(a.pixels), a.pixels, a.c, a.gamma, a.invstd,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(a.c), dim3(64), 0, s, a.partials, a.partial_blocks > 0 ? a.partial_blocks : bn_partial_blocks(a.pixels), a.pixels, a.c, a.gamma, a.invstd,
                        a.dgamma, a.dbeta, a.coef);
     HIP_CHECK(hipGetLastError());
 }

@@ -68,10 +68,15 @@ __device__ __forceinline__ uint4 add_bf16x8(const uint4& p, const uint4& q) {
 // hold channels 8q + 4*half + 0..3, so two v_permlane32_swap per 16 channels leave 8 consecutive channels (16 bytes) in
 // every lane.  With "accumulate" the old values are fetched by one batch of unconditional loads (pix is clamped by the
 // caller) before any add/store, instead of a load -> wait -> store chain per 16 bytes.
+// Epilogue statistics kept per lane across all tiles of a persistent workgroup (reduced across lanes once, at kernel end):
+//   mode 1  forward bn statistics of the stored values:  stat[..][0..7] += v,        stat[..][8..15] += v*v
+//   mode 2  bn + relu backward sums for `out` = da:      stat[..][0..7] += dz*xhat,  stat[..][8..15] += dz
+// bnc = this workgroup's [scale | shift | mean | invstd][C_WG] table (LDS), yraw = the layer's raw output at this pixel.
 template <int NT>
 __device__ __forceinline__ void store_pixel_tiles_rmw(const f32x16 (&acc)[NT], const ConvArgs& a, size_t pix, bool valid, int half, int co_base,
                                                       const u32x4 (&prefetched)[NT][2], bool use_prefetched,
-                                                      float (*stat)[2][16] = nullptr, bool do_stat = false) {
+                                                      float (*stat)[2][16] = nullptr, int stat_mode = 0,
+                                                      const u32x4 (*yraw)[2] = nullptr, const float* bnc = nullptr) {
     const int C_OUT = a.c_out;  // a workgroup may own only NT*32 of the layer's output channels, starting at co_base
     uint4 q[NT][2];
 #pragma unroll
@@ -85,12 +90,38 @@ __device__ __forceinline__ void store_pixel_tiles_rmw(const f32x16 (&acc)[NT], c
             auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
             q[nt][s] = make_uint4(r0[0], r1[0], r0[1], r1[1]);
         }
-    if (do_stat && valid) {  // batch-norm statistics of the STORED (bf16-rounded) values: per-lane running sum and sum of squares
+    const size_t base = pix * C_OUT + co_base + 8 * half;
+    // ---- first destination: its final stored value is what the statistics see ----
+    bf16* out = reinterpret_cast<bf16*>(a.out);
+    uint4 fin[NT][2];
+    if (a.out_accumulate) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                const unsigned w[4] = {q[nt][s].x, q[nt][s].y, q[nt][s].z, q[nt][s].w};
+                uint4 old;
+                if (use_prefetched) { const u32x4 v = prefetched[nt][s]; old = make_uint4(v[0], v[1], v[2], v[3]); }
+                else old = *reinterpret_cast<const uint4*>(out + base + nt * 32 + 16 * s);
+                fin[nt][s] = add_bf16x8(old, q[nt][s]);
+            }
+    } else {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) fin[nt][s] = q[nt][s];
+    }
+    if (valid) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) *reinterpret_cast<uint4*>(out + base + nt * 32 + 16 * s) = fin[nt][s];
+    }
+    if (stat_mode == 1 && valid) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const unsigned w[4] = {fin[nt][s].x, fin[nt][s].y, fin[nt][s].z, fin[nt][s].w};
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const float lo = lo_f(w[i]), hi = hi_f(w[i]);
@@ -99,33 +130,47 @@ __device__ __forceinline__ void store_pixel_tiles_rmw(const f32x16 (&acc)[NT], c
                 }
             }
     }
-    bf16* outs[2] = {reinterpret_cast<bf16*>(a.out), reinterpret_cast<bf16*>(a.out2)};
-    const int accumulate[2] = {a.out_accumulate, a.out2_accumulate};
+    if (stat_mode == 2 && valid) {
+        const int cw = NT * 32;  // channels of this workgroup's table
 #pragma unroll
-    for (int d = 0; d < 2; ++d) {
-        bf16* out = outs[d];
-        if (!out) continue;
-        const size_t base = pix * C_OUT + co_base + 8 * half;
-        if (accumulate[d]) {
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const float* t0 = bnc + nt * 32 + 16 * s + 8 * half;
+                const unsigned wd[4] = {fin[nt][s].x, fin[nt][s].y, fin[nt][s].z, fin[nt][s].w};
+                const u32x4 yv4 = yraw[nt][s];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int h2 = 0; h2 < 2; ++h2) {
+                        const int j = 2 * i + h2;
+                        const float dv = h2 ? hi_f(wd[i]) : lo_f(wd[i]), yv = h2 ? hi_f(yv4[i]) : lo_f(yv4[i]);
+                        const float dz = fmaf(yv, t0[j], t0[cw + j]) > 0.f ? dv : 0.f;
+                        stat[nt][s][j] = fmaf(dz, (yv - t0[2 * cw + j]) * t0[3 * cw + j], stat[nt][s][j]);
+                        stat[nt][s][8 + j] += dz;
+                    }
+            }
+    }
+    // ---- optional second destination (skip gradient) ----
+    bf16* out2 = reinterpret_cast<bf16*>(a.out2);
+    if (out2) {
+        if (a.out2_accumulate) {
             uint4 old[NT][2];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    if (d == 0 && use_prefetched) { const u32x4 v = prefetched[nt][s]; old[nt][s] = make_uint4(v[0], v[1], v[2], v[3]); }
-                    else old[nt][s] = *reinterpret_cast<const uint4*>(out + base + nt * 32 + 16 * s);
-                }
+                for (int s = 0; s < 2; ++s) old[nt][s] = *reinterpret_cast<const uint4*>(out2 + base + nt * 32 + 16 * s);
             if (valid) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                    for (int s = 0; s < 2; ++s) *reinterpret_cast<uint4*>(out + base + nt * 32 + 16 * s) = add_bf16x8(old[nt][s], q[nt][s]);
+                    for (int s = 0; s < 2; ++s) *reinterpret_cast<uint4*>(out2 + base + nt * 32 + 16 * s) = add_bf16x8(old[nt][s], q[nt][s]);
             }
         } else if (valid) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int s = 0; s < 2; ++s) *reinterpret_cast<uint4*>(out + base + nt * 32 + 16 * s) = q[nt][s];
+                for (int s = 0; s < 2; ++s) *reinterpret_cast<uint4*>(out2 + base + nt * 32 + 16 * s) = q[nt][s];
         }
     }
 }
@@ -682,6 +727,7 @@ __device__ __forceinline__ bf16x8 lds_frag(const char* p) { return *reinterpret_
 
 struct GeoS1 {
     static constexpr int RECS = PATCH_PIX, ACC = 2;
+    static constexpr bool RMW_PREFETCH = false;  // read-modify-write destinations prefetched before the MFMA phase (register cost)
     __device__ static void decode(int rec, int& py, int& px, int& key) { py = rec / PW; px = rec - py * PW; key = (px >> 2) & 3; }
     __device__ static int in_y0(int ty) { return ty * TH - 1; }
     __device__ static int in_x0(int tx) { return tx * TW - 1; }
@@ -723,6 +769,7 @@ struct GeoS1 {
 
 struct GeoDown {
     static constexpr int RECS = 9 * 66, ACC = 1;
+    static constexpr bool RMW_PREFETCH = false;
     __device__ static void decode(int rec, int& py, int& px, int& key) {
         py = rec / 66;
         const int rem = rec - py * 66, par = rem >= 33, u = rem - 33 * par;
@@ -764,6 +811,7 @@ struct GeoDown {
 
 struct GeoUp {
     static constexpr int RECS = 5 * 33, ACC = 4;
+    static constexpr bool RMW_PREFETCH = true;   // the skip-gradient accumulation of this net lands in stride-2 con backward-data
     __device__ static void decode(int rec, int& py, int& px, int& key) { py = rec / 33; px = rec - py * 33; key = (px >> 2) & 3; }
     __device__ static int in_y0(int ty) { return ty * 4 - 1; }
     __device__ static int in_x0(int tx) { return tx * 32 - 1; }
@@ -843,7 +891,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
     const int H = a.h_in, W = a.w_in, c_red = a.c_red;
     const int n_slabs = c_red >> 5, n_tiles = tiles_x * tiles_y * a.n;
     constexpr bool CAN_STATS = G::ACC * NT <= 4;  // register budget of the consumer waves
-    const bool fuse_stats = CAN_STATS && a.stat_partials != nullptr;
+    const bool fuse_stats = CAN_STATS && a.stat_partials != nullptr;   // forward: bn statistics of the output
+    const bool fuse_bnred = CAN_STATS && a.bnred_partials != nullptr;  // backward-data: dgamma / dbeta sums of the layer `out` belongs to
+    const int stat_mode = fuse_stats ? 1 : fuse_bnred ? 2 : 0;
+    float* bnc = tab + c_red * (KIND == SRC_BNBWD ? 7 : 4);            // [scale | shift | mean | invstd][C_OUT] of this workgroup's channels
 
     if (KIND != SRC_RAW) {  // SRC_BNBWD: [scale | shift | mean | invstd | coef0 | coef1 | coef2][c_red]
         for (int i = threadIdx.x; i < c_red; i += 512) {
@@ -859,6 +910,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
                 tab[2 * c_red + i] = KIND == SRC_ACT2 ? a.src.b_scale[i] : 0.f;
                 tab[3 * c_red + i] = KIND == SRC_ACT2 ? a.src.b_shift[i] : 0.f;
             }
+        }
+    }
+    if (fuse_bnred) {
+        for (int i = threadIdx.x; i < C_OUT; i += 512) {
+            bnc[i] = a.bnred_scale[co_base + i];
+            bnc[C_OUT + i] = a.bnred_shift[co_base + i];
+            bnc[2 * C_OUT + i] = a.bnred_mean[co_base + i];
+            bnc[3 * C_OUT + i] = a.bnred_invstd[co_base + i];
         }
     }
     __syncthreads();
@@ -964,8 +1023,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) wb0[ks] = swz_addr(smem + X_BYTES_, col, col >> 2, ks, half);
         f32x16 acc[G::ACC][NT];
-        u32x4 old[G::ACC][NT][2];
-        float stat[NT][2][16];  // [..][0..7] sum, [8..15] sum of squares of this lane's 8 channels per (nt, s)
+        u32x4 old[G::ACC][NT][2];   // prefetched old values of a read-modify-write destination (GeoUp)
+        u32x4 yraw[G::ACC][NT][2];  // prefetched raw outputs y of the layer whose da is written (fused bn backward reduction)
+        float stat[NT][2][16];      // per-lane running sums of this lane's 8 channels per (nt, s): see store_pixel_tiles_rmw
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -995,17 +1055,23 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
             TOCK(t_c);
             TICK();
             const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
-            const bool rmw = a.out_accumulate && slab == n_slabs - 1;
-            if (rmw) {  // the old values of a read-modify-write destination travel while the MFMAs run
+            const bool last_slab = slab == n_slabs - 1;
+            const bool rmw = G::RMW_PREFETCH && a.out_accumulate && last_slab;
+            if ((rmw || (fuse_bnred && last_slab))) {  // epilogue operands travel while the MFMAs run
                 const bf16* out = reinterpret_cast<const bf16*>(a.out);
+                const bf16* yl = reinterpret_cast<const bf16*>(a.bnred_y);
 #pragma unroll
                 for (int g = 0; g < G::ACC; ++g) {
                     size_t pix; bool valid;
                     G::out_pixel(g, a, n, ty, tx, wave, col, pix, valid);
+                    const size_t e0 = pix * a.c_out + co_base + 8 * half;
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                        for (int s2 = 0; s2 < 2; ++s2) old[g][nt][s2] = *reinterpret_cast<const u32x4*>(out + pix * a.c_out + co_base + 8 * half + nt * 32 + 16 * s2);
+                        for (int s2 = 0; s2 < 2; ++s2) {
+                            if (rmw) old[g][nt][s2] = *reinterpret_cast<const u32x4*>(out + e0 + nt * 32 + 16 * s2);
+                            if (fuse_bnred) yraw[g][nt][s2] = *reinterpret_cast<const u32x4*>(yl + e0 + nt * 32 + 16 * s2);
+                        }
                 }
             }
             G::template mfma<NT>(acc, b, wb);
@@ -1014,18 +1080,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
 #endif
             TOCK(t_a);
             TICK();
-            if (slab == n_slabs - 1) {
+            if (last_slab) {
 #pragma unroll
                 for (int g = 0; g < G::ACC; ++g) {
                     size_t pix; bool valid;
                     G::out_pixel(g, a, n, ty, tx, wave, col, pix, valid);
-                    store_pixel_tiles_rmw<NT>(acc[g], a, pix, valid, half, co_base, old[g], rmw, stat, fuse_stats);
+                    store_pixel_tiles_rmw<NT>(acc[g], a, pix, valid, half, co_base, old[g], rmw, stat, stat_mode, yraw[g], bnc);
                 }
             }
             TOCK(t_b);
             tile = ntile; slab = nslab; ++it;
         }
-        if (fuse_stats) {
+        if (stat_mode) {
             __syncthreads();  // (matched by the producers) every wave is done with the staging buffers
             float* red = reinterpret_cast<float*>(smem) + (size_t)(wave * 64 + lane) * (32 * NT);
 #pragma unroll
@@ -1036,7 +1102,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
                     for (int e = 0; e < 16; ++e) red[(nt * 2 + s2) * 16 + e] = stat[nt][s2][e];
         }
     }
-    if (fuse_stats) {
+    if (stat_mode) {
         if (producer) __syncthreads();
         __syncthreads();
         // thread t < 64 NT sums (channel, which) over the 4 consumer waves x 32 pixel columns, in a fixed order, in double
@@ -1048,7 +1114,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
             double sum = 0.0;
             for (int w = 0; w < 4; ++w)
                 for (int c = 0; c < 32; ++c) sum += (double)red[(size_t)(w * 64 + hf * 32 + c) * (32 * NT) + (nt * 2 + s2) * 16 + which * 8 + j];
-            a.stat_partials[((size_t)(co_base + ch) * 2 + which) * gridDim.x + blockIdx.x] = sum;
+            double* dst = fuse_stats ? a.stat_partials : a.bnred_partials;
+            dst[((size_t)(co_base + ch) * 2 + which) * gridDim.x + blockIdx.x] = sum;
         }
     }
 #ifdef ANH_WS_PROFILE
@@ -1064,7 +1131,7 @@ template <class G, int NT>
 void launch_ws(const ConvArgs& a, int tiles_x, int tiles_y, int flip, hipStream_t s) {
     const int n_tiles = tiles_x * tiles_y * a.n, groups = a.c_out / (NT * 32);
     const dim3 grid((unsigned)std::max(1, std::min(n_tiles, ws_target_wgs() / groups)), (unsigned)groups), block(512);
-    const size_t lds = 2 * ((size_t)G::RECS * 64 + (size_t)9 * NT * 32 * 64) + (size_t)a.c_red * (a.src.kind == SRC_BNBWD ? 28 : 16);
+    const size_t lds = 2 * ((size_t)G::RECS * 64 + (size_t)9 * NT * 32 * 64) + (size_t)a.c_red * (a.src.kind == SRC_BNBWD ? 28 : 16) + (size_t)NT * 32 * 16;
     auto launch = [&](auto kernel) {
         if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 #ifndef ANH_WS_PROFILE
@@ -1667,12 +1734,22 @@ int conv_fused_stat_blocks(const ConvArgs& a) {
     return p.grid_x;
 }
 
+int conv_fused_bnred_blocks(const ConvArgs& a) {
+    if (!mfma_conv_supported(a) || stem_mfma_ok(a) || (int64_t)a.n * a.h_out * a.w_out == 0) return 0;
+    static const int on = getenv("ANH_FUSE_BN_BWD_REDUCE") ? atoi(getenv("ANH_FUSE_BN_BWD_REDUCE")) : 1;
+    const ConvPlan p = conv_plan(a);
+    const int acc = p.geo == 0 ? 2 : p.geo == 1 ? 1 : 4;
+    if (!on || p.form != 2 || acc * p.nt > 4) return 0;
+    return p.grid_x;
+}
+
 void launch_conv_mfma(const ConvArgs& a, hipStream_t s) {
     if (!mfma_conv_supported(a)) fail(ANH_ERR_INTERNAL, "conv_mfma: unsupported shape");
     if ((int64_t)a.n * a.h_out * a.w_out == 0) return;
     if (stem_mfma_ok(a)) { launch_stem_mfma(a, s); return; }
     const ConvPlan p = conv_plan(a);
     ANH_REQUIRE(!a.stat_partials || conv_fused_stat_blocks(a) > 0, "conv_mfma: this layer's kernel does not fuse bn statistics");
+    ANH_REQUIRE(!a.bnred_partials || (conv_fused_bnred_blocks(a) > 0 && !a.stat_partials), "conv_mfma: this layer's kernel does not fuse the bn backward reduction");
     if (p.geo == 0) {
         if (p.form == 2) { if (p.nt == 1) launch_ws<GeoS1, 1>(a, p.tiles_x, p.tiles_y, p.flip, s); else launch_ws<GeoS1, 2>(a, p.tiles_x, p.tiles_y, p.flip, s); }
         else if (a.c_out == 32) launch_s1<1, 9>(a, s);
