@@ -480,7 +480,7 @@ void Engine::backward(const uint16_t* d_labels, const float* d_weights, double l
         // Fused schedule (two streams, MFMA path): the main stream runs reduce -> finalize -> backward-data conv, the conv
         // applying bn + relu backward to (da, y) while staging; the elementwise apply pass — needed by the filter gradient
         // only — runs out of place on the second stream ahead of that layer's wgrad.
-        bool fused_apply = false;
+        bool fused_apply = false, wgrad_computes_dy = false;
         if (L.has_bn) {
             ANH_REQUIRE(s.dact_written, "internal: layer output has no consumer");
             BnBwdArgs b;
@@ -511,9 +511,18 @@ void Engine::backward(const uint16_t* d_labels, const float* d_weights, double l
                 apply_on = aux_stream;
                 if (has_dgrad) b.dy_out = s.dyp.p;               // da stays intact for the conv on the main stream
             }
-            tok = prof.begin(apply_on, "bn_bwd_apply", 0, (double)p_out * L.cout * es * 3);
-            launch_bn_bwd_apply(b, apply_on);
-            prof.end(apply_on, tok);
+            // a layer without backward-data conv (the stem): only its filter gradient consumes dy, and the stem wgrad
+            // kernel can compute dy from (da, y) while staging -> no apply pass on the critical path
+            WgradArgs probe;
+            probe.src = layer_source(li, last_image); probe.dy_dtype = dtype;
+            probe.n = s.n; probe.h_in = s.h_in; probe.w_in = s.w_in; probe.c_in = L.cin; probe.h_out = s.h; probe.w_out = s.w; probe.c_out = L.cout;
+            probe.k = L.k; probe.stride = L.stride; probe.pad = L.pad; probe.gather = L.type;
+            wgrad_computes_dy = !has_dgrad && wgrad_accepts_bnbwd(probe, dtype);
+            if (!wgrad_computes_dy) {
+                tok = prof.begin(apply_on, "bn_bwd_apply", 0, (double)p_out * L.cout * es * 3);
+                launch_bn_bwd_apply(b, apply_on);
+                prof.end(apply_on, tok);
+            }
             dy = b.dy_out ? b.dy_out : s.dact.p; dy_dt = dtype;
             if (fused_apply && has_dgrad) {
                 dg.src.kind = SRC_BNBWD; dg.src.a = s.dact.p; dg.src.b = s.raw.p;
@@ -530,7 +539,11 @@ void Engine::backward(const uint16_t* d_labels, const float* d_weights, double l
             g.h_out = s.h; g.w_out = s.w; g.c_out = L.cout;
             g.k = L.k; g.stride = L.stride; g.pad = L.pad; g.gather = L.type;
             g.dw = grad.as<float>() + L.w_off;
-            const double bytes = (double)p_in * L.cin * (L.in_a < 0 ? 1.0 : es) * (L.in_b >= 0 ? 2 : 1) + (double)p_out * L.cout * (L.has_bn ? es : 4.0);
+            if (wgrad_computes_dy) {
+                g.dy = s.dact.p; g.dy_y = s.raw.p;
+                g.dy_scale = s.scale; g.dy_shift = s.shift; g.dy_mean = s.mean; g.dy_invstd = s.invstd; g.dy_coef = s.coef;
+            }
+            const double bytes = (double)p_in * L.cin * (L.in_a < 0 ? 1.0 : es) * (L.in_b >= 0 ? 2 : 1) + (double)p_out * L.cout * (L.has_bn ? es : 4.0) * (wgrad_computes_dy ? 2 : 1);
             hipStream_t on = stream;
             if (two_streams) {
                 if (!fused_apply) {   // dy of this layer is final on the main stream: let the second stream pick it up

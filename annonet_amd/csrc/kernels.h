@@ -71,11 +71,17 @@ struct WgradArgs {
     float* partials = nullptr;  // scratch, >= splits * k*k*c_in*c_out floats
     int64_t partials_capacity = 0;
     int* splits_out = nullptr;  // when set: the partial-sum pass is left to the caller (launch_reduce_partials with *splits_out)
+    // dy not materialised (wgrad_accepts_bnbwd): `dy` points at da, and dy = bn + relu backward of (da, dy_y) is applied
+    // while staging — the expression of SRC_BNBWD / bn_bwd_apply with this layer's constants
+    const void* dy_y = nullptr;
+    const float* dy_scale = nullptr; const float* dy_shift = nullptr; const float* dy_mean = nullptr; const float* dy_invstd = nullptr;
+    const float* dy_coef = nullptr;
 };
 
 void launch_conv_generic(const ConvArgs& a, hipStream_t s);
 void launch_wgrad_generic(const WgradArgs& a, hipStream_t s);
 int64_t wgrad_generic_scratch_floats(const WgradArgs& a);
+bool wgrad_accepts_bnbwd(const WgradArgs& a, DType mode);   // decided on the args with dy_y unset
 
 // batch-norm forward statistics over y[P][C]: partial sums -> mean/var -> folded (scale, shift); optional running update
 struct BnFwdArgs {

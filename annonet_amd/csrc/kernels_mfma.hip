@@ -1176,7 +1176,7 @@ void launch_ws(const ConvArgs& a, int tiles_x, int tiles_y, int flip, hipStream_
 // 25*CIN read an all-zero plane.  The 16 k-steps of an 8x32 tile are split over the 4 waves; accumulators persist
 // over the workgroup's tiles; every wave writes its own partial (fixed-order reduction afterwards).
 // ---------------------------------------------------------------------------------------------------------------
-template <int CIN>
+template <int CIN, bool BNBWD>
 __global__ __launch_bounds__(256, 2) void wgrad_stem_mfma_kernel(WgradArgs a, WgSide dy_side, int tiles_x, int tiles_y, int total_tiles, int splits) {
     constexpr int ROWS = 25 * CIN, RT = (ROWS + 31) / 32, PLANE = 12 * 5 * 64;  // bytes of one channel plane
     constexpr int NI = (12 * 36 * CIN + 255) / 256;   // image bytes per thread
@@ -1225,7 +1225,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_stem_mfma_kernel(WgradArgs a, Wg
     // ---- software pipeline over this workgroup's tiles: loads of tile i+1 fly while the MFMAs of tile i run ----
     unsigned char ipx[NI];
     unsigned iok = 0, gok = 0;
-    uint4 graw[4];
+    uint4 graw[4], yraw[4];
+    // BNBWD: dy is computed from (da, y) while staging; this thread's 8 channels' constants stay in registers
+    float bsc[8], bsf[8], bm[8], bis[8], bk0[8], bk1[8], bk2[8];
+    if (BNBWD) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int ch = c16 * 8 + j;
+            bsc[j] = a.dy_scale[ch]; bsf[j] = a.dy_shift[ch]; bm[j] = a.dy_mean[ch]; bis[j] = a.dy_invstd[ch];
+            bk0[j] = a.dy_coef[ch]; bk1[j] = a.dy_coef[32 + ch]; bk2[j] = a.dy_coef[64 + ch];
+        }
+    }
+    const bf16* dyy = reinterpret_cast<const bf16*>(a.dy_y);
     const bf16* dyp = reinterpret_cast<const bf16*>(a.dy);
     const size_t dy_plane = (size_t)a.h_out * a.w_out * 32;
     auto fetch = [&](int tile) {
@@ -1248,6 +1259,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_stem_mfma_kernel(WgradArgs a, Wg
         for (int jj = 0; jj < 4; ++jj) {
             const int oy = y0 + t_row0 + 2 * jj, cy = min(oy, a.h_out - 1);
             graw[jj] = *reinterpret_cast<const uint4*>(g + (cy * a.w_out + cx) * 32 + c16 * 8);
+            if (BNBWD) yraw[jj] = *reinterpret_cast<const uint4*>(dyy + (size_t)n * dy_plane + (cy * a.w_out + cx) * 32 + c16 * 8);
             gok |= ((oy == cy && ox == cx) ? 1u : 0u) << jj;
         }
     };
@@ -1273,7 +1285,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_stem_mfma_kernel(WgradArgs a, Wg
         }
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
-            const uint4 v = ((gok >> jj) & 1u) ? graw[jj] : make_uint4(0u, 0u, 0u, 0u);
+            const uint4 dyv = BNBWD ? chunk_bnbwd(graw[jj], yraw[jj], bsc, bsf, bm, bis, bk0, bk1, bk2) : graw[jj];
+            const uint4 v = ((gok >> jj) & 1u) ? dyv : make_uint4(0u, 0u, 0u, 0u);
             *reinterpret_cast<uint4*>(lbuf + gdst0 + jj * (2 * 32 * 64)) = v;
         }
         __syncthreads();  // two buffers: the writes above cannot race with a slower wave still reading the other one
@@ -1324,8 +1337,11 @@ void launch_wgrad_stem_mfma(const WgradArgs& a, hipStream_t s) {
     const int total = tiles_x * tiles_y * a.n, blocks = stem_wgrad_mfma_blocks(a);
     const WgSide dy{reinterpret_cast<const bf16*>(a.dy), nullptr, nullptr, nullptr, nullptr, nullptr, a.h_out, a.w_out, 32};
     const size_t lds = 2 * (256 * 64 + (size_t)(a.c_in + 1) * 12 * 5 * 64);  // two buffers, each with its zero plane
-    if (a.c_in == 3) hipLaunchKernelGGL((wgrad_stem_mfma_kernel<3>), dim3(blocks), dim3(256), lds, s, a, dy, tiles_x, tiles_y, total, blocks);
-    else hipLaunchKernelGGL((wgrad_stem_mfma_kernel<1>), dim3(blocks), dim3(256), lds, s, a, dy, tiles_x, tiles_y, total, blocks);
+    if (a.dy_y) {
+        if (a.c_in == 3) hipLaunchKernelGGL((wgrad_stem_mfma_kernel<3, true>), dim3(blocks), dim3(256), lds, s, a, dy, tiles_x, tiles_y, total, blocks);
+        else hipLaunchKernelGGL((wgrad_stem_mfma_kernel<1, true>), dim3(blocks), dim3(256), lds, s, a, dy, tiles_x, tiles_y, total, blocks);
+    } else if (a.c_in == 3) hipLaunchKernelGGL((wgrad_stem_mfma_kernel<3, false>), dim3(blocks), dim3(256), lds, s, a, dy, tiles_x, tiles_y, total, blocks);
+    else hipLaunchKernelGGL((wgrad_stem_mfma_kernel<1, false>), dim3(blocks), dim3(256), lds, s, a, dy, tiles_x, tiles_y, total, blocks);
     HIP_CHECK(hipGetLastError());
     if (a.splits_out) *a.splits_out = blocks; else launch_reduce_partials(a.partials, blocks, (int64_t)25 * a.c_in * 32, a.dw, s);
 }
@@ -1766,7 +1782,13 @@ void launch_conv_mfma(const ConvArgs& a, hipStream_t s) {
     }
 }
 
+bool wgrad_accepts_bnbwd(const WgradArgs& a, DType mode) {
+    static const int on = getenv("ANH_FUSE_STEM_BN_APPLY") ? atoi(getenv("ANH_FUSE_STEM_BN_APPLY")) : 1;
+    return on && mode == DT_BF16 && stem_wgrad_mfma_ok(a) && a.c_out == 32;
+}
+
 bool mfma_wgrad_supported(const WgradArgs& a) {
+    if (a.dy_y && !stem_wgrad_mfma_ok(a)) return false;   // only the stem kernel computes dy on the fly
     if (stem_wgrad_mfma_ok(a)) return true;
     if (a.k != 3 || a.src.kind == SRC_IMAGE || a.src.dtype != DT_BF16 || a.dy_dtype != DT_BF16) return false;
     const bool s1 = a.stride == 1 && a.pad == 1 && a.gather == 0 && a.h_in == a.h_out && a.w_in == a.w_out;
