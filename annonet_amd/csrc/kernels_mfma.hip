@@ -1105,17 +1105,26 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
     if (stat_mode) {
         if (producer) __syncthreads();
         __syncthreads();
-        // thread t < 64 NT sums (channel, which) over the 4 consumer waves x 32 pixel columns, in a fixed order, in double
-        const int t = threadIdx.x;
-        if (t < 64 * NT) {
+        // (channel, which) = 64 NT sums over the 4 consumer waves x 32 pixel columns, in a fixed order, in double: a group of
+        // 512 / (64 NT) adjacent threads shares one sum (strided columns, then an xor-shuffle tree)
+        constexpr int GRP = 512 / (64 * NT);   // 8 or 4 threads per sum
+        const int t = threadIdx.x / GRP, part = threadIdx.x % GRP;
+        {
             const int ch = t >> 1, which = t & 1;
             const int nt = ch >> 5, s2 = (ch >> 4) & 1, hf = (ch >> 3) & 1, j = ch & 7;
             const float* red = reinterpret_cast<const float*>(smem);
             double sum = 0.0;
-            for (int w = 0; w < 4; ++w)
-                for (int c = 0; c < 32; ++c) sum += (double)red[(size_t)(w * 64 + hf * 32 + c) * (32 * NT) + (nt * 2 + s2) * 16 + which * 8 + j];
-            double* dst = fuse_stats ? a.stat_partials : a.bnred_partials;
-            dst[((size_t)(co_base + ch) * 2 + which) * gridDim.x + blockIdx.x] = sum;
+#pragma unroll 4
+            for (int e = part; e < 128; e += GRP) {
+                const int w = e >> 5, c = e & 31;
+                sum += (double)red[(size_t)(w * 64 + hf * 32 + c) * (32 * NT) + (nt * 2 + s2) * 16 + which * 8 + j];
+            }
+#pragma unroll
+            for (int off = 1; off < GRP; off <<= 1) sum += __shfl_xor(sum, off, 64);
+            if (part == 0) {
+                double* dst = fuse_stats ? a.stat_partials : a.bnred_partials;
+                dst[((size_t)(co_base + ch) * 2 + which) * gridDim.x + blockIdx.x] = sum;
+            }
         }
     }
 #ifdef ANH_WS_PROFILE
