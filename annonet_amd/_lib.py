@@ -4,6 +4,12 @@ import ctypes as C
 import os
 import subprocess
 
+# The training step overlaps its filter-gradient kernels with the bn / backward-data chain on a second HIP stream.  HIP maps
+# streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) round-robin; with torch.distributed loaded (its own
+# streams) the two streams of a trainer can land on ONE queue and serialise (measured 2.29 vs 2.02 ms/step).  More
+# queues avoid the collision; this only takes effect if set before the HIP runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libannonet_hip.so")
 CSRC = os.path.join(_HERE, "csrc")

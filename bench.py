@@ -20,6 +20,8 @@ import time
 
 import numpy as np
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before HIP initialises: keeps the trainer's two streams on separate hardware queues (annonet_amd/_lib.py)
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
