@@ -57,6 +57,10 @@ class OpInput(C.Structure):
     _fields_ = [("x", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p)]
 
 
+class OpBnDy(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("da", "y", "scale", "shift", "mean", "invstd", "coef")]
+
+
 class TilingParams(C.Structure):
     _fields_ = [("max_tile_width", C.c_int), ("max_tile_height", C.c_int), ("overlap_x", C.c_int), ("overlap_y", C.c_int)]
 
@@ -140,6 +144,9 @@ _SIGNATURES = {  # ConvDesc / OpInput are defined above
     "anh_op_conv_forward": (C.c_int, [C.c_int, C.POINTER(ConvDesc), C.c_int, C.c_int, C.c_int, C.POINTER(OpInput), C.POINTER(OpInput), _P, _P, _P, C.POINTER(C.c_int)]),
     "anh_op_conv_backward_data": (C.c_int, [C.c_int, C.POINTER(ConvDesc), C.c_int, C.c_int, C.c_int, _P, _P, _P, C.POINTER(C.c_int)]),
     "anh_op_conv_backward_filter": (C.c_int, [C.c_int, C.POINTER(ConvDesc), C.c_int, C.c_int, C.c_int, C.POINTER(OpInput), C.POINTER(OpInput), _P, _P, C.POINTER(C.c_int)]),
+    "anh_op_conv_forward_stats": (C.c_int, [C.c_int, C.POINTER(ConvDesc), C.c_int, C.c_int, C.c_int, C.POINTER(OpInput), C.POINTER(OpInput), _P, _P, _P, C.POINTER(C.c_int)]),
+    "anh_op_conv_backward_data_bn": (C.c_int, [C.c_int, C.POINTER(ConvDesc), C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(C.c_int)]),
+    "anh_op_conv_backward_filter_bn": (C.c_int, [C.c_int, C.POINTER(ConvDesc), C.c_int, C.c_int, C.c_int, _P, C.POINTER(OpBnDy), _P, C.POINTER(C.c_int)]),
     "anh_get_tiles": (C.c_int, [C.c_int, C.c_int, C.POINTER(TilingParams), C.POINTER(C.POINTER(Tile)), C.POINTER(C.c_size_t)]),
     "anh_set_weights": (C.c_int, [_P, C.c_int, C.c_int, C.c_double, C.c_double, _P]),
     "anh_random_rect_containing_point": (C.c_int, [C.c_uint32, C.c_uint32, C.c_long, C.c_long, C.c_long, C.c_long, C.POINTER(Rect)]),

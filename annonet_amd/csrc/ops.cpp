@@ -235,4 +235,163 @@ int anh_op_conv_backward_filter(int precision, const anh_conv_desc* d, int n, in
     });
 }
 
+// ---- the fused forms (see include/annonet_hip.h) ----
+int anh_op_conv_forward_stats(int precision, const anh_conv_desc* d, int n, int h_in, int w_in, const anh_op_input* a, const anh_op_input* b,
+                              const float* filters, float* y, double* sums, int* fused) {
+    return guarded([&] {
+        check_desc(d, n, h_in, w_in);
+        ANH_REQUIRE(filters && y && sums, "null argument");
+        const DType dt = precision == ANH_BF16 ? DT_BF16 : DT_F32;
+        const int h_out = out_dim(*d, h_in), w_out = out_dim(*d, w_in);
+        ANH_REQUIRE(h_out >= 1 && w_out >= 1, "input too small");
+        Stream st;
+        OpSource in;
+        make_source(in, a, b, (size_t)n * h_in * w_in * d->cin, d->cin, dt);
+        Filters f;
+        upload_filters(f, *d, filters, dt);
+        DevBuf out, partials, stat;
+        const size_t out_elems = (size_t)n * h_out * w_out * d->cout;
+        const int64_t pixels = (int64_t)n * h_out * w_out;
+        out.reserve(out_elems * (dt == DT_BF16 ? 2 : 4));
+        ConvArgs c;
+        c.src = in.src;
+        c.n = n; c.h_in = h_in; c.w_in = w_in; c.c_red = d->cin; c.h_out = h_out; c.w_out = w_out; c.c_out = d->cout;
+        c.k = d->k; c.stride = d->stride; c.pad = d->pad; c.gather = d->type;
+        c.w_f32 = f.tm_f32.as<float>(); c.w_bf16 = f.km_bf16.p;
+        c.out = out.p; c.out_dtype = dt;
+        const bool fast = conv_takes_mfma(c, dt);
+        int blocks = fast ? conv_fused_stat_blocks(c) : 0;
+        const int fused_here = blocks > 0;
+        partials.reserve((size_t)std::max(blocks, std::max(bn_partial_blocks(pixels), 1)) * 2 * d->cout * sizeof(double));
+        if (fused_here) c.stat_partials = partials.as<double>();
+        if (fast) launch_conv_mfma(c, st.s); else launch_conv_generic(c, st.s);
+        if (!fused_here) {
+            BnFwdArgs bn;
+            bn.y = out.p; bn.dtype = dt; bn.pixels = pixels; bn.c = d->cout; bn.partials = partials.as<double>();
+            blocks = launch_bn_forward_partials(bn, st.s);
+        }
+        HIP_CHECK(hipStreamSynchronize(st.s));
+        download(out, y, out_elems, dt);
+        std::vector<double> p((size_t)blocks * 2 * d->cout);
+        HIP_CHECK(hipMemcpy(p.data(), partials.p, p.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (int ch = 0; ch < d->cout; ++ch)
+            for (int which = 0; which < 2; ++which) {
+                double s = 0;
+                for (int k = 0; k < blocks; ++k) s += p[((size_t)ch * 2 + which) * blocks + k];
+                sums[ch * 2 + which] = s;
+            }
+        if (fused) *fused = fused_here;
+    });
+}
+
+int anh_op_conv_backward_data_bn(int precision, const anh_conv_desc* d, int n, int h_in, int w_in, const float* dy, const float* filters,
+                                 const float* dx_init, const float* y_prev, const float* scale, const float* shift, const float* mean,
+                                 const float* invstd, float* dx, double* sums, int* fused) {
+    return guarded([&] {
+        check_desc(d, n, h_in, w_in);
+        ANH_REQUIRE(dy && filters && dx && y_prev && scale && shift && mean && invstd && sums, "null argument");
+        const DType dt = precision == ANH_BF16 ? DT_BF16 : DT_F32;
+        const int h_out = out_dim(*d, h_in), w_out = out_dim(*d, w_in);
+        ANH_REQUIRE(h_out >= 1 && w_out >= 1, "input too small");
+        Stream st;
+        DevBuf g, out, yp, sc, sf, mn, is, partials, coef;
+        upload(g, dy, (size_t)n * h_out * w_out * d->cout, dt);
+        Filters f;
+        upload_filters(f, *d, filters, dt);
+        const size_t out_elems = (size_t)n * h_in * w_in * d->cin;
+        const int64_t pixels = (int64_t)n * h_in * w_in;
+        if (dx_init) upload(out, dx_init, out_elems, dt); else out.reserve(out_elems * (dt == DT_BF16 ? 2 : 4));
+        upload(yp, y_prev, out_elems, dt);
+        upload_f32(sc, scale, d->cin); upload_f32(sf, shift, d->cin); upload_f32(mn, mean, d->cin); upload_f32(is, invstd, d->cin);
+        ConvArgs c;
+        c.src.kind = SRC_RAW; c.src.dtype = dt; c.src.a = g.p;
+        c.n = n; c.h_in = h_out; c.w_in = w_out; c.c_red = d->cout; c.h_out = h_in; c.w_out = w_in; c.c_out = d->cin;
+        c.k = d->k; c.stride = d->stride; c.pad = d->pad; c.gather = 1 - d->type;
+        c.w_f32 = f.km_f32.as<float>(); c.w_bf16 = f.tm_bf16.p;
+        c.out = out.p; c.out_dtype = dt; c.out_accumulate = dx_init ? 1 : 0;
+        const bool fast = conv_takes_mfma(c, dt);
+        int blocks = fast ? conv_fused_bnred_blocks(c) : 0;
+        const int fused_here = blocks > 0;
+        partials.reserve((size_t)std::max(blocks, std::max(bn_partial_blocks(pixels), 1)) * 2 * d->cin * sizeof(double));
+        if (fused_here) {
+            c.bnred_y = yp.p; c.bnred_scale = sc.as<float>(); c.bnred_shift = sf.as<float>(); c.bnred_mean = mn.as<float>(); c.bnred_invstd = is.as<float>();
+            c.bnred_partials = partials.as<double>();
+        }
+        if (fast) launch_conv_mfma(c, st.s); else launch_conv_generic(c, st.s);
+        if (!fused_here) {
+            BnBwdArgs bn;
+            bn.da = out.p; bn.y = yp.p; bn.dtype = dt; bn.pixels = pixels; bn.c = d->cin;
+            bn.mean = mn.as<float>(); bn.invstd = is.as<float>(); bn.scale = sc.as<float>(); bn.shift = sf.as<float>();
+            bn.partials = partials.as<double>();
+            launch_bn_bwd_reduce(bn, st.s);
+            blocks = bn_partial_blocks(pixels);
+        }
+        HIP_CHECK(hipStreamSynchronize(st.s));
+        download(out, dx, out_elems, dt);
+        std::vector<double> p((size_t)blocks * 2 * d->cin);
+        HIP_CHECK(hipMemcpy(p.data(), partials.p, p.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (int ch = 0; ch < d->cin; ++ch)
+            for (int which = 0; which < 2; ++which) {
+                double s = 0;
+                for (int k = 0; k < blocks; ++k) s += p[((size_t)ch * 2 + which) * blocks + k];
+                sums[ch * 2 + which] = s;
+            }
+        if (fused) *fused = fused_here;
+    });
+}
+
+int anh_op_conv_backward_filter_bn(int precision, const anh_conv_desc* d, int n, int h_in, int w_in, const uint8_t* image,
+                                   const anh_op_bn_dy* dy, float* dw, int* computed_in_kernel) {
+    return guarded([&] {
+        check_desc(d, n, h_in, w_in);
+        ANH_REQUIRE(image && dy && dy->da && dy->y && dy->scale && dy->shift && dy->mean && dy->invstd && dy->coef && dw, "null argument");
+        const DType dt = precision == ANH_BF16 ? DT_BF16 : DT_F32;
+        const int h_out = out_dim(*d, h_in), w_out = out_dim(*d, w_in);
+        ANH_REQUIRE(h_out >= 1 && w_out >= 1, "input too small");
+        Stream st;
+        DevBuf img, da, yy, sc, sf, mn, is, cf, out, scratch;
+        const size_t img_bytes = (size_t)n * h_in * w_in * d->cin;
+        img.reserve(img_bytes);
+        HIP_CHECK(hipMemcpy(img.p, image, img_bytes, hipMemcpyHostToDevice));
+        const size_t g_elems = (size_t)n * h_out * w_out * d->cout;
+        upload(da, dy->da, g_elems, dt); upload(yy, dy->y, g_elems, dt);
+        upload_f32(sc, dy->scale, d->cout); upload_f32(sf, dy->shift, d->cout); upload_f32(mn, dy->mean, d->cout);
+        upload_f32(is, dy->invstd, d->cout); upload_f32(cf, dy->coef, (size_t)3 * d->cout);
+        const int kk = d->k * d->k;
+        const size_t nw = (size_t)kk * d->cin * d->cout;
+        out.reserve(nw * 4);
+        WgradArgs w;
+        w.src.kind = SRC_IMAGE; w.src.img = img.as<uint8_t>(); w.src.img_h = h_in; w.src.img_w = w_in; w.src.img_sample_stride = (int64_t)h_in * w_in * d->cin;
+        w.dy = da.p; w.dy_dtype = dt;
+        w.n = n; w.h_in = h_in; w.w_in = w_in; w.c_in = d->cin; w.h_out = h_out; w.w_out = w_out; w.c_out = d->cout;
+        w.k = d->k; w.stride = d->stride; w.pad = d->pad; w.gather = d->type;
+        w.dw = out.as<float>();
+        const bool in_kernel = wgrad_accepts_bnbwd(w, dt);
+        if (in_kernel) {
+            w.dy_y = yy.p; w.dy_scale = sc.as<float>(); w.dy_shift = sf.as<float>(); w.dy_mean = mn.as<float>(); w.dy_invstd = is.as<float>();
+            w.dy_coef = cf.as<float>();
+        } else {   // the unfused schedule: materialise dy first
+            BnBwdArgs bn;
+            bn.da = da.p; bn.y = yy.p; bn.dtype = dt; bn.pixels = (int64_t)n * h_out * w_out; bn.c = d->cout;
+            bn.mean = mn.as<float>(); bn.invstd = is.as<float>(); bn.scale = sc.as<float>(); bn.shift = sf.as<float>(); bn.coef = cf.as<float>();
+            launch_bn_bwd_apply(bn, st.s);
+        }
+        const bool fast = wgrad_takes_mfma(w, dt);
+        const int64_t need = fast ? wgrad_mfma_scratch_floats(w) : wgrad_generic_scratch_floats(w);
+        scratch.reserve((size_t)std::max<int64_t>(need, 1) * 4);
+        w.partials = scratch.as<float>(); w.partials_capacity = (int64_t)(scratch.bytes / 4);
+        if (fast) launch_wgrad_mfma(w, st.s); else launch_wgrad_generic(w, st.s);
+        HIP_CHECK(hipStreamSynchronize(st.s));
+        std::vector<float> tm(nw);
+        HIP_CHECK(hipMemcpy(tm.data(), out.p, nw * 4, hipMemcpyDeviceToHost));
+        for (int t = 0; t < kk; ++t)
+            for (int ci = 0; ci < d->cin; ++ci)
+                for (int co = 0; co < d->cout; ++co) {
+                    const size_t dst = d->type == 0 ? ((size_t)co * d->cin + ci) * kk + t : ((size_t)ci * d->cout + co) * kk + t;
+                    dw[dst] = tm[((size_t)t * d->cin + ci) * d->cout + co];
+                }
+        if (computed_in_kernel) *computed_in_kernel = in_kernel ? 1 : 0;
+    });
+}
+
 }  // extern "C"

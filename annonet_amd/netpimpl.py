@@ -430,6 +430,52 @@ def op_conv_backward_data(precision, desc, dy, filters, in_hw):
     return dx, bool(used.value)
 
 
+def op_conv_forward_stats(precision, desc, xa, sa=None, ta=None, xb=None, sb=None, tb=None, filters=None):
+    """Forward conv with the fused bn-statistics epilogue.  Returns (y, sums [cout, 2] = (sum y, sum y^2), fused)."""
+    keep = []
+    a = _op_input(xa, sa, ta, keep)
+    b = _op_input(xb, sb, tb, keep)
+    n, h, w, _ = keep[0].shape
+    d = _lib.ConvDesc(*desc)
+    f = np.ascontiguousarray(filters, dtype=np.float32)
+    y = np.empty((n, _out_dim(desc, h), _out_dim(desc, w), desc[5]), np.float32)
+    sums = np.empty((desc[5], 2), np.float64)
+    fused = C.c_int(0)
+    check(_lib.lib().anh_op_conv_forward_stats(precision, C.byref(d), n, h, w, C.byref(a), C.byref(b) if b is not None else None,
+                                               _ptr(f), _ptr(y), _ptr(sums), C.byref(fused)))
+    return y, sums, bool(fused.value)
+
+
+def op_conv_backward_data_bn(precision, desc, dy, filters, in_hw, y_prev, scale, shift, mean, invstd, dx_init=None):
+    """Backward-data conv (+= dx_init) with the fused bn + relu backward reduction of the layer that receives dx.
+    Returns (dx, sums [cin, 2] = (sum dz*xhat, sum dz), fused)."""
+    d = _lib.ConvDesc(*desc)
+    g = np.ascontiguousarray(dy, dtype=np.float32)
+    f = np.ascontiguousarray(filters, dtype=np.float32)
+    n = g.shape[0]
+    arrs = [np.ascontiguousarray(v, dtype=np.float32) for v in (y_prev, scale, shift, mean, invstd)]
+    init = None if dx_init is None else np.ascontiguousarray(dx_init, dtype=np.float32)
+    dx = np.empty((n, in_hw[0], in_hw[1], desc[4]), np.float32)
+    sums = np.empty((desc[4], 2), np.float64)
+    fused = C.c_int(0)
+    check(_lib.lib().anh_op_conv_backward_data_bn(precision, C.byref(d), n, in_hw[0], in_hw[1], _ptr(g), _ptr(f), _ptr(init),
+                                                  *[_ptr(v) for v in arrs], _ptr(dx), _ptr(sums), C.byref(fused)))
+    return dx, sums, bool(fused.value)
+
+
+def op_conv_backward_filter_bn(precision, desc, image_u8, da, y, scale, shift, mean, invstd, coef):
+    """Stem filter gradient with dy = bn + relu backward of (da, y) computed while staging.  Returns (dw, in_kernel)."""
+    d = _lib.ConvDesc(*desc)
+    img = np.ascontiguousarray(image_u8, dtype=np.uint8)
+    n, h, w, _ = img.shape
+    arrs = [np.ascontiguousarray(v, dtype=np.float32) for v in (da, y, scale, shift, mean, invstd, coef)]
+    bn = _lib.OpBnDy(*[v.ctypes.data for v in arrs])
+    dw = np.empty(desc[1] * desc[1] * desc[4] * desc[5], np.float32)
+    flag = C.c_int(0)
+    check(_lib.lib().anh_op_conv_backward_filter_bn(precision, C.byref(d), n, h, w, _ptr(img), C.byref(bn), _ptr(dw), C.byref(flag)))
+    return dw, bool(flag.value)
+
+
 def op_conv_backward_filter(precision, desc, xa, sa=None, ta=None, xb=None, sb=None, tb=None, dy=None):
     keep = []
     a = _op_input(xa, sa, ta, keep)

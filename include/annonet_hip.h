@@ -189,6 +189,21 @@ int anh_op_conv_backward_data(int precision, const anh_conv_desc* d, int n, int 
                               const float* filters_canonical, float* dx_nhwc, int* used_mfma);
 int anh_op_conv_backward_filter(int precision, const anh_conv_desc* d, int n, int h_in, int w_in, const anh_op_input* a, const anh_op_input* b,
                                 const float* dy_nhwc, float* dw_canonical, int* used_mfma);
+/* The same ops with the epilogues / prologues the training step fuses into them (kernel-level parity tests):
+ *  _forward_stats      also returns the batch-norm statistics of the STORED output: sums[2*cout] = per channel (sum y, sum y*y);
+ *                      *fused = 1 when the conv kernel produced them itself (else the separate statistics kernel ran).
+ *  _backward_data_bn   dx (+= dx_init when given: the skip-gradient accumulation) and the bn + relu backward sums of the layer
+ *                      that receives dx: y_prev = its raw output, (scale, shift, mean, invstd)[cin];
+ *                      sums[2*cin] = per channel (sum dz*xhat, sum dz), dz = (y*scale+shift > 0) ? dx : 0, xhat = (y-mean)*invstd.
+ *  bn_dy               describes a gradient that is not materialised: dy = coef0*(dz - coef1 - xhat*coef2) from (da, y) */
+typedef struct { const float* da; const float* y; const float* scale; const float* shift; const float* mean; const float* invstd; const float* coef; } anh_op_bn_dy;
+int anh_op_conv_forward_stats(int precision, const anh_conv_desc* d, int n, int h_in, int w_in, const anh_op_input* a, const anh_op_input* b,
+                              const float* filters_canonical, float* y_nhwc, double* sums, int* fused);
+int anh_op_conv_backward_data_bn(int precision, const anh_conv_desc* d, int n, int h_in, int w_in, const float* dy_nhwc,
+                                 const float* filters_canonical, const float* dx_init, const float* y_prev, const float* scale,
+                                 const float* shift, const float* mean, const float* invstd, float* dx_nhwc, double* sums, int* fused);
+int anh_op_conv_backward_filter_bn(int precision, const anh_conv_desc* d, int n, int h_in, int w_in, const uint8_t* image_u8,
+                                   const anh_op_bn_dy* dy, float* dw_canonical, int* computed_dy_in_kernel);
 
 /* ---- host logic ---- */
 /* tiling::get_tiles(width, height, params) (annonet_infer.cpp:42): *tiles is malloc'd, release with anh_free */

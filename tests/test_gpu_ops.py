@@ -111,3 +111,84 @@ def test_ops_reject_bad_arguments():
         aa.op_conv_forward(aa.ANH_FP32, (0, 3, 0, 1, 8, 8), x, filters=np.zeros(9 * 64, np.float32))  # stride 0
     with pytest.raises(aa.AnnonetHipError):
         aa.op_conv_forward(aa.ANH_FP32, (0, 3, 2, 0, 8, 8), x[:, :2, :2], filters=np.zeros(9 * 64, np.float32))  # too small
+
+
+# ---- the epilogues / prologues the training step fuses into the MFMA kernels -------------------------------------------------
+# The statistics are defined on the STORED outputs, so the expected sums are computed (in float64) from the tensor the op
+# returns: the check is independent of the conv's own rounding.  Tolerance: fp32 per-lane running sums over <= a few
+# thousand values, then double: rtol 2e-5 of the sum of magnitudes.
+FUSED_SHAPES = [
+    ((0, 3, 1, 1, 32, 32), 3, 21, 37),    # GeoS1, one channel group, ragged edges
+    ((0, 3, 1, 1, 64, 64), 2, 18, 33),    # GeoS1, two 32-channel tiles per workgroup
+    ((0, 3, 1, 1, 128, 128), 1, 9, 35),   # two workgroup groups of 64 channels
+    ((0, 3, 2, 0, 32, 64), 2, 23, 31),    # GeoDown
+    ((1, 3, 2, 0, 64, 32), 2, 11, 15),    # GeoUp, fused (one channel tile)
+    ((1, 3, 2, 0, 128, 64), 1, 7, 9),     # GeoUp with two tiles: not fused -> the separate kernels must agree too
+]
+
+
+@pytest.mark.parametrize("prologue", [1, 2])
+@pytest.mark.parametrize("desc,n,h,w", FUSED_SHAPES)
+def test_conv_forward_fused_bn_statistics(desc, n, h, w, prologue):
+    xa, kw, filters, _ = make_inputs(desc, n, h, w, 11, prologue, True)
+    y_ref, _ = aa.op_conv_forward(aa.ANH_BF16, desc, xa, filters=filters, **kw)
+    y, sums, fused = aa.op_conv_forward_stats(aa.ANH_BF16, desc, xa, filters=filters, **kw)
+    assert np.array_equal(y, y_ref)                        # the epilogue must not disturb the result
+    y64 = y.astype(np.float64).reshape(-1, desc[5])
+    want = np.stack([y64.sum(0), (y64 * y64).sum(0)], 1)
+    scale = np.stack([np.abs(y64).sum(0), (y64 * y64).sum(0)], 1) + 1e-12
+    assert (np.abs(sums - want) <= 2e-5 * scale).all(), float((np.abs(sums - want) / scale).max())
+    cout_tiles = min(desc[5], 64) // 32
+    assert fused == (not (desc[0] == 1 and cout_tiles == 2))   # every geometry but GeoUp with two channel tiles fuses
+
+
+@pytest.mark.parametrize("accumulate", [False, True])
+@pytest.mark.parametrize("desc,n,h,w", FUSED_SHAPES)
+def test_conv_backward_data_fused_bn_reduction(desc, n, h, w, accumulate):
+    rng = np.random.default_rng(5)
+    cin, cout = desc[4], desc[5]
+    ho, wo = aa.netpimpl._out_dim(desc, h), aa.netpimpl._out_dim(desc, w)
+    k = desc[1]
+    lim = np.sqrt(6.0 / (k * k * (cin + cout)))
+    filters = rng.uniform(-lim, lim, k * k * cin * cout).astype(np.float32)
+    dy = orc.bf16_round(rng.normal(0, 1, (n, ho, wo, cout)).astype(np.float32))
+    y_prev = orc.bf16_round(rng.normal(0, 1, (n, h, w, cin)).astype(np.float32))
+    init = orc.bf16_round(rng.normal(0, 1, (n, h, w, cin)).astype(np.float32)) if accumulate else None
+    scale = rng.uniform(0.5, 1.5, cin).astype(np.float32); shift = rng.uniform(-0.3, 0.3, cin).astype(np.float32)
+    mean = rng.uniform(-0.2, 0.2, cin).astype(np.float32); invstd = rng.uniform(0.7, 1.4, cin).astype(np.float32)
+    dx_ref, _ = aa.op_conv_backward_data(aa.ANH_BF16, desc, dy, filters, (h, w))
+    dx, sums, fused = aa.op_conv_backward_data_bn(aa.ANH_BF16, desc, dy, filters, (h, w), y_prev, scale, shift, mean, invstd, dx_init=init)
+    if accumulate:
+        assert np.array_equal(dx, orc.bf16_round(init + dx_ref))   # bf16(old + bf16(conv)): the stored skip-gradient sum
+    else:
+        assert np.array_equal(dx, dx_ref)
+    # expected sums from the stored dx, with the kernels' fp32 mask and xhat expressions
+    z = y_prev.astype(np.float64) * scale + shift                    # the sign of the kernels' single-rounding fmaf
+    dz = np.where(z > 0, dx, 0).astype(np.float64)
+    xhat = ((y_prev - mean).astype(np.float32) * invstd).astype(np.float64)
+    want = np.stack([(dz * xhat).reshape(-1, cin).sum(0), dz.reshape(-1, cin).sum(0)], 1)
+    mag = np.stack([np.abs(dz * xhat).reshape(-1, cin).sum(0), np.abs(dz).reshape(-1, cin).sum(0)], 1) + 1e-12
+    assert (np.abs(sums - want) <= 1e-4 * mag).all(), float((np.abs(sums - want) / mag).max())
+    assert isinstance(fused, bool)
+
+
+def test_stem_filter_gradient_computes_dy_in_kernel():
+    desc, n, h, w = (0, 5, 1, 2, 3, 32), 3, 21, 43
+    rng = np.random.default_rng(9)
+    img = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+    da = orc.bf16_round(rng.normal(0, 1, (n, h, w, 32)).astype(np.float32))
+    y = orc.bf16_round(rng.normal(0, 1, (n, h, w, 32)).astype(np.float32))
+    scale = rng.uniform(0.5, 1.5, 32).astype(np.float32); shift = rng.uniform(-0.3, 0.3, 32).astype(np.float32)
+    mean = rng.uniform(-0.2, 0.2, 32).astype(np.float32); invstd = rng.uniform(0.7, 1.4, 32).astype(np.float32)
+    coef = np.concatenate([rng.uniform(0.5, 1.5, 32), rng.uniform(-0.01, 0.01, 32), rng.uniform(-0.01, 0.01, 32)]).astype(np.float32)
+    dw, in_kernel = aa.op_conv_backward_filter_bn(aa.ANH_BF16, desc, img, da, y, scale, shift, mean, invstd, coef)
+    assert in_kernel
+    # reference: dy materialised with the bn_bwd_apply expression (fp32, bf16-rounded as stored), then the plain stem wgrad
+    z = y.astype(np.float64) * scale + shift
+    dz = np.where(z > 0, da, 0).astype(np.float32)
+    xhat = ((y - mean).astype(np.float32) * invstd).astype(np.float32)
+    dyv = orc.bf16_round((coef[:32] * ((dz - coef[32:64]).astype(np.float32) - (xhat * coef[64:]).astype(np.float32))).astype(np.float32))
+    x = img.astype(np.float32) / 256.0
+    want = orc.op_conv_backward_filter(desc, x, dy=dyv)
+    tol = 2e-3 * np.abs(want).max() + 1e-6
+    assert np.abs(dw - want).max() <= tol, float(np.abs(dw - want).max() / tol)
