@@ -1,0 +1,60 @@
+"""Every kernel-schedule switch of the library must train the same net.
+
+The switches are environment variables read once per process, so each variant runs
+tests/helpers/run_train_steps.py in its own process: 3 bf16 steps on a seeded batch of 6 tiles 99x99.
+  * variants that only move work between streams or kernels WITHOUT changing any summation order are bit-identical to
+    the default: one stream instead of two; the bn + relu backward applied in the backward-data conv's prologue;
+  * variants that change a summation order (bn statistics / bn backward sums in a conv epilogue vs. the separate
+    kernels; the classic one-tile conv kernels; dy materialised for the stem) agree to bf16-training tolerance.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def run_variant(tmp_path, name, env):
+    out = str(tmp_path / f"{name}.npz")
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, os.path.join(HERE, "helpers", "run_train_steps.py"), out], env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return np.load(out)
+
+
+@pytest.fixture(scope="module")
+def default_run(tmp_path_factory):
+    return run_variant(tmp_path_factory.mktemp("sched"), "default", {})
+
+
+@pytest.mark.parametrize("name,env", [
+    ("one_stream", {"ANH_CONCURRENT_WGRAD": "0"}),
+    ("bn_backward_in_conv_prologue", {"ANH_FUSE_BN_BWD_APPLY": "1"}),
+])
+def test_schedule_is_bit_identical(tmp_path, default_run, name, env):
+    got = run_variant(tmp_path, name, env)
+    np.testing.assert_array_equal(got["losses"], default_run["losses"])
+    np.testing.assert_array_equal(got["params"], default_run["params"])
+    np.testing.assert_array_equal(got["running"], default_run["running"])
+
+
+@pytest.mark.parametrize("name,env", [
+    ("separate_bn_statistics", {"ANH_FUSE_BN_STATS": "0"}),
+    ("separate_bn_backward_reduction", {"ANH_FUSE_BN_BWD_REDUCE": "0"}),
+    ("stem_dy_materialised", {"ANH_FUSE_STEM_BN_APPLY": "0"}),
+    ("classic_conv_kernels", {"ANH_CONV_WS": "0"}),
+])
+def test_schedule_agrees_within_bf16_training_tolerance(tmp_path, default_run, name, env):
+    got = run_variant(tmp_path, name, env)
+    np.testing.assert_allclose(got["losses"], default_run["losses"], rtol=2e-3)
+    dp = got["params"] - default_run["params"]
+    ref = default_run["params"]
+    assert np.linalg.norm(dp) <= 2e-3 * np.linalg.norm(ref), float(np.linalg.norm(dp) / np.linalg.norm(ref))
+    run = default_run["running"]   # means (near zero) and variances: absolute bar relative to the largest statistic
+    np.testing.assert_allclose(got["running"], run, rtol=2e-3, atol=2e-3 * np.abs(run).max())
