@@ -709,6 +709,169 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_mfma_kernel(WgParams a, int t
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// wgrad3x3_ws: the same filter-gradient computation, operand layout and output as wgrad3x3_mfma, warp-specialised like
+// conv3x3_ws: 512 threads, waves 4..7 (producers) fetch pixel tile i+1 into registers, apply the prologues and write LDS
+// buffer (i+1)&1 while waves 0..3 (consumers) run the transposing reads + MFMAs of tile i from buffer i&1; one barrier
+// per tile.  128 tile channels (NTC = 4) at stride 1 use 4x32 pixel tiles so that two buffers fit in LDS.
+// ---------------------------------------------------------------------------------------------------------------
+template <int NTC, int KP, int KT, int STRIDE>
+__global__ __launch_bounds__(512, 2) void wgrad3x3_ws_kernel(WgParams a, int tiles_x, int tiles_y, int total_tiles, int splits) {
+    constexpr int TH = STRIDE == 1 ? (NTC == 4 ? 4 : 8) : 4, TW = 32, TILE_PIX = TH * TW, KS = TILE_PIX / 16;
+    constexpr int RECS = STRIDE == 1 ? (TH + 2) * 34 : 9 * 66, ORIGIN = STRIDE == 1 ? -1 : 0;
+    constexpr int P_ITEMS = RECS * 4, NP = (P_ITEMS + 255) / 256;   // patch chunks per producer thread
+    constexpr int JPN = TILE_PIX / 64, NT_ = NTC * JPN;            // tile chunks per producer thread: JPN per 32-channel group
+    constexpr int BUF_BYTES = RECS * 64 + TILE_PIX * NTC * 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TPW = (9 * NTC + 3) / 4;  // output tiles per consumer wave
+
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const bool producer = wave >= 4;
+    const int tid = threadIdx.x & 255, lane = tid & 63, c16 = tid & 3;
+    const int slab = blockIdx.y, split = blockIdx.x;
+    const int cc = slab * 32;
+
+    float* tab = reinterpret_cast<float*>(smem + 2 * BUF_BYTES);  // tile side's bn constants: [a_scale | a_shift | b_scale | b_shift][NTC*32]
+    if (KT != SRC_RAW) {
+        for (int i = threadIdx.x; i < NTC * 32; i += 512) {
+            tab[i] = a.tile.a_scale[i];
+            tab[NTC * 32 + i] = a.tile.a_shift[i];
+            tab[2 * NTC * 32 + i] = KT == SRC_ACT2 ? a.tile.b_scale[i] : 0.f;
+            tab[3 * NTC * 32 + i] = KT == SRC_ACT2 ? a.tile.b_shift[i] : 0.f;
+        }
+    }
+    __syncthreads();
+
+    int tile = split, it = 0;
+    if (producer) {
+        // per-channel bn constants of the patch side: this thread's 8 channels, in registers
+        float psa[8], pta[8], psb[8], ptb[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            psa[j] = KP != SRC_RAW ? a.patch.a_scale[cc + c16 * 8 + j] : 0.f;
+            pta[j] = KP != SRC_RAW ? a.patch.a_shift[cc + c16 * 8 + j] : 0.f;
+            psb[j] = KP == SRC_ACT2 ? a.patch.b_scale[cc + c16 * 8 + j] : 0.f;
+            ptb[j] = KP == SRC_ACT2 ? a.patch.b_shift[cc + c16 * 8 + j] : 0.f;
+        }
+        // staging geometry, fixed per thread: patch chunk jj = record (tid >> 2) + 64 jj -> (row, column), swizzled by column
+        int pgeo[NP], pdst[NP];
+#pragma unroll
+        for (int jj = 0; jj < NP; ++jj) {
+            const int rec = min((tid >> 2) + 64 * jj, RECS - 1);
+            int py, px, key;
+            if (STRIDE == 1) { py = rec / 34; px = rec - py * 34; key = (px >> 2) & 3; }
+            else { py = rec / 66; const int rem = rec - py * 66; const int par = rem >= 33; const int u = rem - 33 * par; px = 2 * u + par; key = (u >> 2) & 3; }
+            pgeo[jj] = py | (px << 8);
+            pdst[jj] = rec * 64 + ((c16 ^ key) << 4);
+        }
+        // tile chunk jj = 32-channel group jj / JPN, row (tid >> 7) + 2 (jj % JPN), column (tid >> 2) & 31
+        const int t_x = (tid >> 2) & 31, t_row0 = tid >> 7;
+        const int tdst0 = RECS * 64 + (t_row0 * 32 + t_x) * 64 + ((c16 ^ ((t_x >> 2) & 3)) << 4);
+        RawChunk<KP> praw[NP];
+        RawChunk<KT> traw[NT_];
+        unsigned pok = 0, tok = 0;
+        const size_t p_plane = (size_t)a.patch.h * a.patch.w * a.patch.c, t_plane = (size_t)a.tile.h * a.tile.w * a.tile.c;  // < 2^31 elements (host check)
+        auto fetch = [&](int tile_) __attribute__((always_inline)) {
+            const int tx = tile_ % tiles_x, ty = (tile_ / tiles_x) % tiles_y, n = tile_ / (tiles_x * tiles_y);
+            const int x0 = tx * TW, y0 = ty * TH;
+            const bf16* pa = a.patch.a + (size_t)n * p_plane;
+            const bf16* pb = KP == SRC_ACT2 ? a.patch.b + (size_t)n * p_plane : nullptr;
+            const int yb = STRIDE * y0 + ORIGIN, xb = STRIDE * x0 + ORIGIN;
+            pok = 0;
+#pragma unroll
+            for (int jj = 0; jj < NP; ++jj) {
+                const int iy = yb + (pgeo[jj] & 255), ix = xb + (pgeo[jj] >> 8);
+                const int cy = min(max(iy, 0), a.patch.h - 1), cx = min(max(ix, 0), a.patch.w - 1);
+                praw[jj] = side_load_at<KP>(pa, pb, (cy * a.patch.w + cx) * a.patch.c + cc + c16 * 8);
+                pok |= ((iy == cy && ix == cx) ? 1u : 0u) << jj;
+            }
+            const bf16* ta = a.tile.a + (size_t)n * t_plane;
+            const bf16* tb = KT == SRC_ACT2 ? a.tile.b + (size_t)n * t_plane : nullptr;
+            const int ox = x0 + t_x, cx = min(ox, a.tile.w - 1);
+            tok = 0;
+#pragma unroll
+            for (int jj = 0; jj < NT_; ++jj) {
+                const int oy = y0 + t_row0 + 2 * (jj % JPN), cy = min(oy, a.tile.h - 1);
+                traw[jj] = side_load_at<KT>(ta, tb, (cy * a.tile.w + cx) * a.tile.c + (jj / JPN) * 32 + c16 * 8);
+                tok |= ((oy == cy && ox == cx) ? 1u : 0u) << jj;
+            }
+        };
+        if (tile < total_tiles) fetch(tile);
+        for (; tile < total_tiles; tile += splits, ++it) {
+            char* lbuf = smem + (it & 1) * BUF_BYTES;
+#pragma unroll
+            for (int jj = 0; jj < NP; ++jj) {
+                uint4 v = chunk_convert<KP>(praw[jj], psa, pta, psb, ptb);
+                if (!((pok >> jj) & 1u)) v = make_uint4(0u, 0u, 0u, 0u);
+                if ((tid >> 2) + 64 * jj < RECS) *reinterpret_cast<uint4*>(lbuf + pdst[jj]) = v;
+            }
+#pragma unroll
+            for (int jj = 0; jj < NT_; ++jj) {
+                const float* t0 = tab + (jj / JPN) * 32 + c16 * 8;
+                uint4 v = chunk_convert<KT>(traw[jj], t0, t0 + NTC * 32, t0 + 2 * NTC * 32, t0 + 3 * NTC * 32);
+                if (!((tok >> jj) & 1u)) v = make_uint4(0u, 0u, 0u, 0u);
+                *reinterpret_cast<uint4*>(lbuf + tdst0 + ((jj / JPN) * TILE_PIX + 2 * (jj % JPN) * 32) * 64) = v;
+            }
+            if (tile + splits < total_tiles) fetch(tile + splits);
+            __syncthreads();  // buffer it & 1 is full; the consumers are done with buffer (it + 1) & 1
+        }
+    } else {
+        const int nt_mine = wave % NTC;
+        // this wave's output tiles j = wave + 4i -> (tap, nt_mine); a wave short of tiles repeats its previous one (never
+        // written), which keeps the MFMA phase free of branches.  pofs / tofs: lane part of the operand addresses
+        int pofs[TPW][2], tofs[2];
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            const int j = wave + 4 * i, jc = j < 9 * NTC ? j : j - 4;
+            const int tap = jc / NTC, ky = tap / 3, kx = tap - ky * 3;
+            const int first = STRIDE == 1 ? ky * 34 + kx : (ky * 2 + (kx & 1)) * 33 + (kx >> 1);
+            const int x_first = STRIDE == 1 ? kx : (kx >> 1);
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) pofs[i][rr] = first * 64 + tr_lane_offset(lane, rr, x_first);
+        }
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) tofs[rr] = RECS * 64 + nt_mine * (TILE_PIX * 64) + tr_lane_offset(lane, rr, 0);
+        f32x16 acc[TPW];
+#pragma unroll
+        for (int i = 0; i < TPW; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        for (; tile < total_tiles; tile += splits, ++it) {
+            const char* lbuf = smem + (it & 1) * BUF_BYTES;
+            const char* pa0[TPW];
+            const char* pa1[TPW];
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) { pa0[i] = lbuf + pofs[i][0]; pa1[i] = lbuf + pofs[i][1]; }
+            const char* ta0 = lbuf + tofs[0];
+            const char* ta1 = lbuf + tofs[1];
+            __syncthreads();  // buffer it & 1 is full
+            bf16x8 tf0, tf1, pf0[TPW], pf1[TPW];
+            tf0 = tr_read8_at(ta0, ta1);  // k-step 0
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) pf0[i] = tr_read8_at(pa0[i], pa1[i]);
+            wg_ksteps<0, KS, TPW, STRIDE>(ta0, ta1, pa0, pa1, tf0, pf0, tf1, pf1, acc);
+        }
+        // one partial per workgroup, laid out as dw: [tap][ci][co]
+        const size_t nw = (size_t)9 * a.c_in * a.c_out;
+        float* out = a.partials + (size_t)split * nw;
+        const int col = lane & 31, half = lane >> 5;
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            const int j = wave + 4 * i;
+            if (j < 9 * NTC) {
+                const int tap = j / NTC;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int pch = cc + (r & 3) + 8 * (r >> 2) + 4 * half;  // patch channel (accumulator row)
+                    const int tch = nt_mine * 32 + col;                      // tile channel (accumulator column)
+                    const int ci = a.transpose_out ? tch : pch, co = a.transpose_out ? pch : tch;
+                    out[((size_t)tap * a.c_in + ci) * a.c_out + co] = acc[i][r];
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Geometry policies of the persistent 3x3 conv kernel (conv3x3_ws below): stride-1 con and its mirrored backward-data;
 // stride-2 con / cont backward-data; cont / stride-2 con backward-data.
 // LDS pixel records are swizzled by the patch COLUMN (column within the parity plane for stride 2), so every operand
@@ -1355,13 +1518,16 @@ void launch_wgrad_stem_mfma(const WgradArgs& a, hipStream_t s) {
     if (a.splits_out) *a.splits_out = blocks; else launch_reduce_partials(a.partials, blocks, (int64_t)25 * a.c_in * 32, a.dw, s);
 }
 
-struct WgPlan { int stride, ntc, slabs, tiles_x, tiles_y, total, splits; size_t lds; bool cont; };
+struct WgPlan { int stride, ntc, slabs, tiles_x, tiles_y, total, splits; size_t lds; bool cont, ws; };
 
 WgPlan wgrad_plan_mfma(const WgradArgs& a) {
     WgPlan p{};
     p.stride = a.stride;
     p.cont = a.gather == 1;
-    const int th = a.stride == 1 ? 8 : 4;
+    static const int ws_on = getenv("ANH_WGRAD_WS") ? atoi(getenv("ANH_WGRAD_WS")) : 1;
+    p.ws = ws_on != 0;
+    const int ntc_ = (p.cont ? a.c_in : a.c_out) / 32;
+    const int th = a.stride == 1 ? ((p.ws && ntc_ == 4) ? 4 : 8) : 4;
     const int lr_h = p.cont ? a.h_in : a.h_out, lr_w = p.cont ? a.w_in : a.w_out;   // the low-res (tile) tensor
     const int c_tile = p.cont ? a.c_in : a.c_out, c_patch = p.cont ? a.c_out : a.c_in;
     p.ntc = c_tile / 32;
@@ -1369,9 +1535,10 @@ WgPlan wgrad_plan_mfma(const WgradArgs& a) {
     p.tiles_x = (lr_w + 31) / 32;
     p.tiles_y = (lr_h + th - 1) / th;
     p.total = p.tiles_x * p.tiles_y * a.n;
-    p.lds = (size_t)(a.stride == 1 ? 340 : 594) * 64 + (size_t)p.ntc * th * 32 * 64;
+    p.lds = (size_t)(a.stride == 1 ? (th + 2) * 34 : 594) * 64 + (size_t)p.ntc * th * 32 * 64;
     const size_t tab = (size_t)p.ntc * 32 * 16;            // the tile side's bn constants
-    p.lds = (2 * p.lds + tab <= 160 * 1024 ? 2 * p.lds : p.lds) + tab;  // double-buffered when it fits (the kernel makes the same decision)
+    if (p.ws) p.lds = 2 * p.lds + tab;                     // the warp-specialised kernel always runs two buffers
+    else p.lds = (2 * p.lds + tab <= 160 * 1024 ? 2 * p.lds : p.lds) + tab;  // double-buffered when it fits (the kernel makes the same decision)
     // one workgroup per CU: these kernels share the chip with the backward-data chain (second stream), and every
     // workgroup writes a full partial, so fewer workgroups also means less partial-sum traffic
     const int target = 256;
@@ -1381,6 +1548,12 @@ WgPlan wgrad_plan_mfma(const WgradArgs& a) {
 
 template <int NTC, int KP, int KT, int STRIDE>
 void launch_wg(const WgParams& prm, const WgPlan& p, hipStream_t s) {
+    if (p.ws) {
+        auto kernel = wgrad3x3_ws_kernel<NTC, KP, KT, STRIDE>;
+        if (p.lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
+        hipLaunchKernelGGL(kernel, dim3(p.splits, p.slabs), dim3(512), p.lds, s, prm, p.tiles_x, p.tiles_y, p.total, p.splits);
+        return;
+    }
     auto kernel = wgrad3x3_mfma_kernel<NTC, KP, KT, STRIDE>;
     if (p.lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
     hipLaunchKernelGGL(kernel, dim3(p.splits, p.slabs), dim3(256), p.lds, s, prm, p.tiles_x, p.tiles_y, p.total, p.splits);
