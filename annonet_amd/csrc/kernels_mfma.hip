@@ -508,7 +508,9 @@ __device__ __forceinline__ bf16x8 tr_read8_at(const char* a0, const char* a1) {
 
 // k-steps KS0, KS0+1 of the wgrad MFMA phase (template recursion = fully unrolled with compile-time LDS offsets):
 // fragments of step ks+1 are requested before the MFMAs of step ks issue.
-template <int KS0, int KS, int TPW, int STRIDE>
+// SWAP: accumulate the TRANSPOSED output tile (A = tile fragment, B = patch fragment), so that the accumulator's lane
+// (column) index is the patch channel — the contiguous index of dW when patch channels are the output channels (cont).
+template <int KS0, int KS, int TPW, int STRIDE, bool SWAP = false>
 __device__ __forceinline__ void wg_ksteps(const char* ta0, const char* ta1, const char* (&pa0)[TPW], const char* (&pa1)[TPW],
                                           bf16x8& tf0, bf16x8 (&pf0)[TPW], bf16x8& tf1, bf16x8 (&pf1)[TPW], f32x16 (&acc)[TPW]) {
     if constexpr (KS0 < KS) {
@@ -520,7 +522,7 @@ __device__ __forceinline__ void wg_ksteps(const char* ta0, const char* ta1, cons
             for (int i = 0; i < TPW; ++i) pf1[i] = tr_read8_at(pa0[i] + pimm, pa1[i] + pimm);
         }
 #pragma unroll
-        for (int i = 0; i < TPW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf0[i], tf0, acc[i], 0, 0, 0);
+        for (int i = 0; i < TPW; ++i) acc[i] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf0, pf0[i], acc[i], 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf0[i], tf0, acc[i], 0, 0, 0);
         if constexpr (KS0 + 2 < KS) {
             constexpr int row = (KS0 + 2) >> 1, xh = ((KS0 + 2) & 1) << 4;
             constexpr int timm = (row * 32 + xh) * 64, pimm = (STRIDE == 1 ? row * 34 + xh : row * 132 + xh) * 64;
@@ -529,8 +531,8 @@ __device__ __forceinline__ void wg_ksteps(const char* ta0, const char* ta1, cons
             for (int i = 0; i < TPW; ++i) pf0[i] = tr_read8_at(pa0[i] + pimm, pa1[i] + pimm);
         }
 #pragma unroll
-        for (int i = 0; i < TPW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf1[i], tf1, acc[i], 0, 0, 0);
-        wg_ksteps<KS0 + 2, KS, TPW, STRIDE>(ta0, ta1, pa0, pa1, tf0, pf0, tf1, pf1, acc);
+        for (int i = 0; i < TPW; ++i) acc[i] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf1, pf1[i], acc[i], 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf1[i], tf1, acc[i], 0, 0, 0);
+        wg_ksteps<KS0 + 2, KS, TPW, STRIDE, SWAP>(ta0, ta1, pa0, pa1, tf0, pf0, tf1, pf1, acc);
     }
 }
 
@@ -714,7 +716,7 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_mfma_kernel(WgParams a, int t
 // buffer (i+1)&1 while waves 0..3 (consumers) run the transposing reads + MFMAs of tile i from buffer i&1; one barrier
 // per tile.  128 tile channels (NTC = 4) at stride 1 use 4x32 pixel tiles so that two buffers fit in LDS.
 // ---------------------------------------------------------------------------------------------------------------
-template <int NTC, int KP, int KT, int STRIDE>
+template <int NTC, int KP, int KT, int STRIDE, bool TRANS>
 __global__ __launch_bounds__(512, 2) void wgrad3x3_ws_kernel(WgParams a, int tiles_x, int tiles_y, int total_tiles, int splits) {
     constexpr int TH = STRIDE == 1 ? (NTC == 4 ? 4 : 8) : 4, TW = 32, TILE_PIX = TH * TW, KS = TILE_PIX / 16;
     constexpr int RECS = STRIDE == 1 ? (TH + 2) * 34 : 9 * 66, ORIGIN = STRIDE == 1 ? -1 : 0;
@@ -848,7 +850,8 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_ws_kernel(WgParams a, int til
             tf0 = tr_read8_at(ta0, ta1);  // k-step 0
 #pragma unroll
             for (int i = 0; i < TPW; ++i) pf0[i] = tr_read8_at(pa0[i], pa1[i]);
-            wg_ksteps<0, KS, TPW, STRIDE>(ta0, ta1, pa0, pa1, tf0, pf0, tf1, pf1, acc);
+            // TRANS (cont: patch channels = output channels): accumulate transposed, so that the partial's stores run along co
+            wg_ksteps<0, KS, TPW, STRIDE, TRANS>(ta0, ta1, pa0, pa1, tf0, pf0, tf1, pf1, acc);
         }
         // one partial per workgroup, laid out as dw: [tap][ci][co]
         const size_t nw = (size_t)9 * a.c_in * a.c_out;
@@ -861,9 +864,10 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_ws_kernel(WgParams a, int til
                 const int tap = j / NTC;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int pch = cc + (r & 3) + 8 * (r >> 2) + 4 * half;  // patch channel (accumulator row)
-                    const int tch = nt_mine * 32 + col;                      // tile channel (accumulator column)
-                    const int ci = a.transpose_out ? tch : pch, co = a.transpose_out ? pch : tch;
+                    const int rowc = (r & 3) + 8 * (r >> 2) + 4 * half;      // accumulator row -> channel within the 32-channel tile
+                    const int pch = cc + (TRANS ? col : rowc);               // patch channel
+                    const int tch = nt_mine * 32 + (TRANS ? rowc : col);     // tile channel
+                    const int ci = TRANS ? tch : pch, co = TRANS ? pch : tch;
                     out[((size_t)tap * a.c_in + ci) * a.c_out + co] = acc[i][r];
                 }
             }
@@ -1549,9 +1553,16 @@ WgPlan wgrad_plan_mfma(const WgradArgs& a) {
 template <int NTC, int KP, int KT, int STRIDE>
 void launch_wg(const WgParams& prm, const WgPlan& p, hipStream_t s) {
     if (p.ws) {
-        auto kernel = wgrad3x3_ws_kernel<NTC, KP, KT, STRIDE>;
-        if (p.lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
-        hipLaunchKernelGGL(kernel, dim3(p.splits, p.slabs), dim3(512), p.lds, s, prm, p.tiles_x, p.tiles_y, p.total, p.splits);
+        auto launch = [&](auto kernel) {
+            if (p.lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
+            hipLaunchKernelGGL(kernel, dim3(p.splits, p.slabs), dim3(512), p.lds, s, prm, p.tiles_x, p.tiles_y, p.total, p.splits);
+        };
+        constexpr bool can_be_cont = STRIDE == 2 && KP == SRC_RAW;   // cont: the patch is dy (raw), its channels are the output channels
+        if constexpr (can_be_cont) {
+            if (p.cont) { launch(wgrad3x3_ws_kernel<NTC, KP, KT, STRIDE, true>); return; }
+        }
+        ANH_REQUIRE(!p.cont, "wgrad_mfma: transposed layer on a non-transposing kernel");
+        if constexpr (KT == SRC_RAW) launch(wgrad3x3_ws_kernel<NTC, KP, KT, STRIDE, false>);
         return;
     }
     auto kernel = wgrad3x3_mfma_kernel<NTC, KP, KT, STRIDE>;
