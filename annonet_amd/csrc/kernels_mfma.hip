@@ -768,53 +768,63 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_ws_kernel(WgParams a, int til
         // tile chunk jj = 32-channel group jj / JPN, row (tid >> 7) + 2 (jj % JPN), column (tid >> 2) & 31
         const int t_x = (tid >> 2) & 31, t_row0 = tid >> 7;
         const int tdst0 = RECS * 64 + (t_row0 * 32 + t_x) * 64 + ((c16 ^ ((t_x >> 2) & 3)) << 4);
-        RawChunk<KP> praw[NP];
-        RawChunk<KT> traw[NT_];
-        unsigned pok = 0, tok = 0;
+        // TWO register sets: the loads of tiles i+1 and i+2 are in flight while tile i is committed — one tile of MFMA
+        // time does not cover the memory latency under load
+        struct Regs { RawChunk<KP> p[NP]; RawChunk<KT> t[NT_]; unsigned pok, tok; };
+        Regs ra, rb;
         const size_t p_plane = (size_t)a.patch.h * a.patch.w * a.patch.c, t_plane = (size_t)a.tile.h * a.tile.w * a.tile.c;  // < 2^31 elements (host check)
-        auto fetch = [&](int tile_) __attribute__((always_inline)) {
+        auto fetch = [&](Regs& R, int tile_) __attribute__((always_inline)) {
             const int tx = tile_ % tiles_x, ty = (tile_ / tiles_x) % tiles_y, n = tile_ / (tiles_x * tiles_y);
             const int x0 = tx * TW, y0 = ty * TH;
             const bf16* pa = a.patch.a + (size_t)n * p_plane;
             const bf16* pb = KP == SRC_ACT2 ? a.patch.b + (size_t)n * p_plane : nullptr;
             const int yb = STRIDE * y0 + ORIGIN, xb = STRIDE * x0 + ORIGIN;
-            pok = 0;
+            R.pok = 0;
 #pragma unroll
             for (int jj = 0; jj < NP; ++jj) {
                 const int iy = yb + (pgeo[jj] & 255), ix = xb + (pgeo[jj] >> 8);
                 const int cy = min(max(iy, 0), a.patch.h - 1), cx = min(max(ix, 0), a.patch.w - 1);
-                praw[jj] = side_load_at<KP>(pa, pb, (cy * a.patch.w + cx) * a.patch.c + cc + c16 * 8);
-                pok |= ((iy == cy && ix == cx) ? 1u : 0u) << jj;
+                R.p[jj] = side_load_at<KP>(pa, pb, (cy * a.patch.w + cx) * a.patch.c + cc + c16 * 8);
+                R.pok |= ((iy == cy && ix == cx) ? 1u : 0u) << jj;
             }
             const bf16* ta = a.tile.a + (size_t)n * t_plane;
             const bf16* tb = KT == SRC_ACT2 ? a.tile.b + (size_t)n * t_plane : nullptr;
             const int ox = x0 + t_x, cx = min(ox, a.tile.w - 1);
-            tok = 0;
+            R.tok = 0;
 #pragma unroll
             for (int jj = 0; jj < NT_; ++jj) {
                 const int oy = y0 + t_row0 + 2 * (jj % JPN), cy = min(oy, a.tile.h - 1);
-                traw[jj] = side_load_at<KT>(ta, tb, (cy * a.tile.w + cx) * a.tile.c + (jj / JPN) * 32 + c16 * 8);
-                tok |= ((oy == cy && ox == cx) ? 1u : 0u) << jj;
+                R.t[jj] = side_load_at<KT>(ta, tb, (cy * a.tile.w + cx) * a.tile.c + (jj / JPN) * 32 + c16 * 8);
+                R.tok |= ((oy == cy && ox == cx) ? 1u : 0u) << jj;
             }
         };
-        if (tile < total_tiles) fetch(tile);
-        for (; tile < total_tiles; tile += splits, ++it) {
-            char* lbuf = smem + (it & 1) * BUF_BYTES;
+        auto commit = [&](const Regs& R, char* lbuf) __attribute__((always_inline)) {
 #pragma unroll
             for (int jj = 0; jj < NP; ++jj) {
-                uint4 v = chunk_convert<KP>(praw[jj], psa, pta, psb, ptb);
-                if (!((pok >> jj) & 1u)) v = make_uint4(0u, 0u, 0u, 0u);
+                uint4 v = chunk_convert<KP>(R.p[jj], psa, pta, psb, ptb);
+                if (!((R.pok >> jj) & 1u)) v = make_uint4(0u, 0u, 0u, 0u);
                 if ((tid >> 2) + 64 * jj < RECS) *reinterpret_cast<uint4*>(lbuf + pdst[jj]) = v;
             }
 #pragma unroll
             for (int jj = 0; jj < NT_; ++jj) {
                 const float* t0 = tab + (jj / JPN) * 32 + c16 * 8;
-                uint4 v = chunk_convert<KT>(traw[jj], t0, t0 + NTC * 32, t0 + 2 * NTC * 32, t0 + 3 * NTC * 32);
-                if (!((tok >> jj) & 1u)) v = make_uint4(0u, 0u, 0u, 0u);
+                uint4 v = chunk_convert<KT>(R.t[jj], t0, t0 + NTC * 32, t0 + 2 * NTC * 32, t0 + 3 * NTC * 32);
+                if (!((R.tok >> jj) & 1u)) v = make_uint4(0u, 0u, 0u, 0u);
                 *reinterpret_cast<uint4*>(lbuf + tdst0 + ((jj / JPN) * TILE_PIX + 2 * (jj % JPN) * 32) * 64) = v;
             }
-            if (tile + splits < total_tiles) fetch(tile + splits);
-            __syncthreads();  // buffer it & 1 is full; the consumers are done with buffer (it + 1) & 1
+        };
+        if (tile < total_tiles) fetch(ra, tile);
+        if (tile + splits < total_tiles) fetch(rb, tile + splits);
+        while (tile < total_tiles) {   // unrolled by two so that the register sets are addressed statically
+            commit(ra, smem);
+            if (tile + 2 * splits < total_tiles) fetch(ra, tile + 2 * splits);
+            __syncthreads();  // buffer 0 is full; the consumers are done with buffer 1
+            tile += splits;
+            if (tile >= total_tiles) break;
+            commit(rb, smem + BUF_BYTES);
+            if (tile + 2 * splits < total_tiles) fetch(rb, tile + 2 * splits);
+            __syncthreads();
+            tile += splits;
         }
     } else {
         const int nt_mine = wave % NTC;
