@@ -49,6 +49,7 @@ def test_schedule_is_bit_identical(tmp_path, default_run, name, env):
     ("separate_bn_backward_reduction", {"ANH_FUSE_BN_BWD_REDUCE": "0"}),
     ("stem_dy_materialised", {"ANH_FUSE_STEM_BN_APPLY": "0"}),
     ("classic_conv_kernels", {"ANH_CONV_WS": "0"}),
+    ("single_role_filter_gradient_kernels", {"ANH_WGRAD_WS": "0"}),
 ])
 def test_schedule_agrees_within_bf16_training_tolerance(tmp_path, default_run, name, env):
     got = run_variant(tmp_path, name, env)
