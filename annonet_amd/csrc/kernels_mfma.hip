@@ -1786,6 +1786,15 @@ __global__ __launch_bounds__(256, 2) void stem_mfma_kernel(ConvArgs a, int tiles
                 wf[ky][ks][j] = (bf16)w;
             }
 
+    const bool fuse_stats = a.stat_partials != nullptr;   // training forward: bn statistics of the stored output, as conv3x3_ws
+    float stat[1][2][16];
+    u32x4 none[1][2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        none[0][s2] = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int e = 0; e < 16; ++e) stat[0][s2][e] = 0.f;
+    }
     for (int i = tid; i < 12 * SPW; i += 256) patch[i] = 0ull;
     for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
         const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
@@ -1829,8 +1838,29 @@ __global__ __launch_bounds__(256, 2) void stem_mfma_kernel(ConvArgs a, int tiles
             const bool valid = oy < a.h_out && ox < a.w_out;
             const size_t pix = ((size_t)n * a.h_out + (valid ? oy : 0)) * a.w_out + (valid ? ox : 0);
             f32x16 one[1] = {acc[g]};
-            store_pixel_tiles<1>(one, a, pix, valid, half);
+            store_pixel_tiles_rmw<1>(one, a, pix, valid, half, 0, none, false, stat, fuse_stats ? 1 : 0);
         }
+    }
+    if (fuse_stats) {   // per-lane running sums -> one partial per workgroup, [channel][sum | sum of squares][workgroup] (as conv3x3_ws)
+        __shared__ float red[256 * 32];
+        __syncthreads();
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) red[tid * 32 + s2 * 16 + e] = stat[0][s2][e];
+        __syncthreads();
+        const int t = tid >> 2, part = tid & 3;   // 64 sums (32 channels x 2), four threads each
+        const int ch = t >> 1, which = t & 1;
+        const int s2 = (ch >> 4) & 1, hf = (ch >> 3) & 1, j = ch & 7;
+        double sum = 0.0;
+#pragma unroll 4
+        for (int e = part; e < 128; e += 4) {
+            const int w = e >> 5, c = e & 31;
+            sum += (double)red[(w * 64 + hf * 32 + c) * 32 + s2 * 16 + which * 8 + j];
+        }
+        sum += __shfl_xor(sum, 1, 64);
+        sum += __shfl_xor(sum, 2, 64);
+        if (part == 0) a.stat_partials[((size_t)ch * 2 + which) * gridDim.x + blockIdx.x] = sum;
     }
 }
 
@@ -1838,10 +1868,14 @@ bool stem_mfma_ok(const ConvArgs& a) {
     return a.src.kind == SRC_IMAGE && a.k == 5 && a.stride == 1 && a.pad == 2 && a.gather == 0 && a.c_out == 32 && (a.c_red == 1 || a.c_red == 3) &&
            a.h_in == a.h_out && a.w_in == a.w_out && !a.bias && !a.out_nchw && a.out_dtype == DT_BF16 && a.w_f32;
 }
+int stem_mfma_blocks(const ConvArgs& a) {
+    const int total = ((a.w_out + 31) / 32) * ((a.h_out + 7) / 8) * a.n;
+    return std::min(total, 1024);
+}
 void launch_stem_mfma(const ConvArgs& a, hipStream_t s) {
     const int tiles_x = (a.w_out + 31) / 32, tiles_y = (a.h_out + 7) / 8;
     const int total = tiles_x * tiles_y * a.n;
-    const dim3 grid((unsigned)std::min(total, 1024)), block(256);
+    const dim3 grid((unsigned)stem_mfma_blocks(a)), block(256);
     if (a.c_red == 3) hipLaunchKernelGGL((stem_mfma_kernel<3>), grid, block, 0, s, a, tiles_x, tiles_y, total);
     else hipLaunchKernelGGL((stem_mfma_kernel<1>), grid, block, 0, s, a, tiles_x, tiles_y, total);
     HIP_CHECK(hipGetLastError());
@@ -1945,8 +1979,9 @@ bool conv_accepts_bnbwd(const ConvArgs& a) {
 // Number of per-workgroup statistic partials the conv kernel will write when ConvArgs::stat_partials is set
 // (layout [channel][sum | sum of squares][workgroup]); 0 when this layer's kernel does not fuse the statistics.
 int conv_fused_stat_blocks(const ConvArgs& a) {
-    if (!mfma_conv_supported(a) || stem_mfma_ok(a) || (int64_t)a.n * a.h_out * a.w_out == 0) return 0;
+    if (!mfma_conv_supported(a) || (int64_t)a.n * a.h_out * a.w_out == 0) return 0;
     static const int on = getenv("ANH_FUSE_BN_STATS") ? atoi(getenv("ANH_FUSE_BN_STATS")) : 1;
+    if (stem_mfma_ok(a)) return on && !a.out_accumulate && !a.out2 ? stem_mfma_blocks(a) : 0;
     const ConvPlan p = conv_plan(a);
     const int acc = p.geo == 0 ? 2 : p.geo == 1 ? 1 : 4;
     if (!on || p.form != 2 || acc * p.nt > 4 || a.out_accumulate || a.out2) return 0;
