@@ -420,6 +420,7 @@ void Engine::backward(const uint16_t* d_labels, const float* d_weights, double l
     const double es = (double)elem_size(dtype);
     const bool fused_head = head_is_fused();
     for (auto& s : ls) s.dact_written = false;
+    int head_bnred_blocks_ = 0;
     if (fused_head) {
         HeadTrainArgs t;
         t.src = layer_source(nl - 1, last_image); t.c_in = head.cin; t.k = head.cout;
@@ -432,9 +433,19 @@ void Engine::backward(const uint16_t* d_labels, const float* d_weights, double l
         t.loss_out = loss_dev; t.loss_out_f32 = grad.as<float>() + spec.n_params;
         t.dbias = grad.as<float>() + head.b_off; t.dw = grad.as<float>() + head.w_off;
         t.error_flag = error_flag;
+        // the head's input layer (single bn layer): its da is produced here from its y -> leave its bn backward sums too
+        static const bool fuse_head_bnred = !(getenv("ANH_FUSE_BN_BWD_REDUCE") && atoi(getenv("ANH_FUSE_BN_BWD_REDUCE")) == 0);
+        LayerState& hp = ls[head.in_a];
+        int head_bnred_blocks = 0;
+        if (fuse_head_bnred && t.src.kind == SRC_ACT && spec.layers[head.in_a].has_bn) {
+            head_bnred_blocks = head_train_blocks(P);
+            hp.bwd_partials.reserve((size_t)head_bnred_blocks * 2 * head.cin * sizeof(double));
+            t.bnred_mean = hp.mean; t.bnred_invstd = hp.invstd; t.bnred_partials = hp.bwd_partials.as<double>();
+        }
         const int tok = prof.begin(stream, "head_fused_fwd_loss_bwd", 2.0 * 3 * head.cin * head.cout * (double)P, (double)P * (head.cin * es * 2 + head.cout * 4.0 + 6.0));
         launch_head_train(t, stream);
         prof.end(stream, tok);
+        head_bnred_blocks_ = head_bnred_blocks;
         ls[head.in_a].dact_written = true;
     } else {
         LossArgs a;
@@ -454,7 +465,7 @@ void Engine::backward(const uint16_t* d_labels, const float* d_weights, double l
         if (spec.layers[i].in_a >= 0) ++ls[spec.layers[i].in_a].consumers;
         if (spec.layers[i].in_b >= 0) ++ls[spec.layers[i].in_b].consumers;
     }
-    if (fused_head) ++ls[head.in_a].da_writes;  // the fused head kernel wrote d(dec) already
+    if (fused_head) { ++ls[head.in_a].da_writes; ls[head.in_a].fused_bwd_blocks = head_bnred_blocks_; }  // the fused head kernel wrote d(dec) already
     for (int li = fused_head ? nl - 2 : nl - 1; li >= 0; --li) {
         const anh_layer_desc& L = spec.layers[li];
         LayerState& s = ls[li];

@@ -185,8 +185,12 @@ struct HeadTrainArgs {
     double* partials = nullptr;
     double* loss_out = nullptr; float* loss_out_f32 = nullptr; float* dbias = nullptr; float* dw = nullptr;
     int* error_flag = nullptr;
+    // optional (single-input head): also leave the bn + relu backward sums of the layer that produced the input —
+    // the head computes that layer's da from its raw output y in the same pass.  Layout [channel][sum dz*xhat | sum dz][workgroup].
+    const float* bnred_mean = nullptr; const float* bnred_invstd = nullptr; double* bnred_partials = nullptr;
 };
 bool head_train_supported(const HeadTrainArgs& a);
+int head_train_blocks(int64_t pixels);   // workgroups of the launch = partials per channel
 int64_t head_train_partial_doubles(const HeadTrainArgs& a);
 void launch_head_train(const HeadTrainArgs& a, hipStream_t s);
 

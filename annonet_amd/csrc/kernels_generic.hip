@@ -811,6 +811,7 @@ struct HeadArgs {
     double scale;
     double* partials;              // [blocks][1 + K + 32*K]
     int* error_flag;
+    const float* bn_mean; const float* bn_invstd; double* bn_partials;   // fused bn backward sums of the input layer (SRC_ACT only)
 };
 
 // Four lanes share a pixel: lane `sub` owns channels 8*sub..8*sub+7 (one 16-byte chunk), so a wave reads / writes 1 KiB
@@ -832,6 +833,13 @@ __global__ __launch_bounds__(256) void head_train_kernel(HeadArgs a) {
     for (int c = 0; c < 8; ++c) {
         sa[c] = a.src.a_scale[c0 + c]; ta[c] = a.src.a_shift[c0 + c];
         sb[c] = KIND == SRC_ACT2 ? a.src.b_scale[c0 + c] : 0.f; tb[c] = KIND == SRC_ACT2 ? a.src.b_shift[c0 + c] : 0.f;
+    }
+    const bool bnred = KIND == SRC_ACT && a.bn_partials != nullptr;
+    float bm[8], bis[8], sg[8], sb2[8];   // bn backward sums of the input layer: sg = sum dz*xhat, sb2 = sum dz
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        bm[c] = bnred ? a.bn_mean[c0 + c] : 0.f; bis[c] = bnred ? a.bn_invstd[c0 + c] : 0.f;
+        sg[c] = 0.f; sb2[c] = 0.f;
     }
     float dw[8][KM], db[KM];
 #pragma unroll
@@ -857,10 +865,13 @@ __global__ __launch_bounds__(256) void head_train_kernel(HeadArgs a) {
         r.wgt = a.weights[pc];
     };
     auto process = [&](int64_t p, const Pre& r) {
-        float x[8];
+        float x[8], yraw[8];
         raw_to_float(r.xa, x);
 #pragma unroll
-        for (int c = 0; c < 8; ++c) x[c] = relu_affine(x[c], sa[c], ta[c]);
+        for (int c = 0; c < 8; ++c) { yraw[c] = x[c]; x[c] = relu_affine(x[c], sa[c], ta[c]); }
+        bool pos[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) pos[c] = x[c] > 0.f;   // relu(z) > 0  <=>  z = y*scale+shift > 0
         if (KIND == SRC_ACT2) {
             float u[8];
             raw_to_float(r.xb, u);
@@ -917,6 +928,14 @@ __global__ __launch_bounds__(256) void head_train_kernel(HeadArgs a) {
             for (int k = 0; k < KM; ++k) db[k] += g[k];
         }
         store8<T>(da + (size_t)p * C + c0, dx);
+        if (bnred) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float dz = pos[c] ? operand_round<T>(dx[c]) : 0.f;   // the STORED da, as bn_bwd_reduce would read it
+                sg[c] = fmaf(dz, (yraw[c] - bm[c]) * bis[c], sg[c]);
+                sb2[c] += dz;
+            }
+        }
     };
     int64_t p = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
     Pre r0, r1;
@@ -948,7 +967,19 @@ __global__ __launch_bounds__(256) void head_train_kernel(HeadArgs a) {
 #pragma unroll
             for (int k = 0; k < KM; ++k) { const double v = fold(dw[c][k]); if (lane < 4) red[wave][1 + KM + (lane * 8 + c) * KM + k] = v; }
     }
+    __shared__ double redb[4][2][C];
+    if (bnred) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const double v0 = fold(sg[c]), v1 = fold(sb2[c]);
+            if (lane < 4) { redb[wave][0][lane * 8 + c] = v0; redb[wave][1][lane * 8 + c] = v1; }
+        }
+    }
     __syncthreads();
+    if (bnred && threadIdx.x < 2 * C) {
+        const int ch = threadIdx.x >> 1, which = threadIdx.x & 1;
+        a.bn_partials[((size_t)ch * 2 + which) * gridDim.x + blockIdx.x] = ((redb[0][which][ch] + redb[1][which][ch]) + redb[2][which][ch]) + redb[3][which][ch];
+    }
     const int slots = 1 + K + C * K;
     for (int sidx = threadIdx.x; sidx < slots; sidx += blockDim.x) {
         int src;
@@ -1179,6 +1210,7 @@ void launch_head_train(const HeadTrainArgs& t, hipStream_t s) {
     HeadArgs a;
     a.src = t.src; a.w_tm = t.w_tm; a.w_km = t.w_km; a.bias = t.bias; a.labels = t.labels; a.weights = t.weights;
     a.logits = t.logits; a.da = t.da; a.pixels = t.pixels; a.k = t.k; a.scale = t.scale; a.partials = t.partials; a.error_flag = t.error_flag;
+    a.bn_mean = t.bnred_mean; a.bn_invstd = t.bnred_invstd; a.bn_partials = t.src.kind == SRC_ACT ? t.bnred_partials : nullptr;
     const int blocks = head_train_blocks(t.pixels);
     const bool bf = t.src.dtype == DT_BF16;
     if (t.src.kind == SRC_ACT) {
