@@ -237,12 +237,12 @@ def test_bf16_forward(levels, scaler, minf):
     assert mism.mean() <= 0.03 and ((srt[:, -1] - srt[:, -2])[mism] <= 2 * tol).all()  # only near-ties may flip
 
 
-@pytest.mark.parametrize("levels,scaler,minf", [(2, 1.0, 1), (1, 0.25, 4), (3, 0.5, 1), (2, 0.1, 5)])
-def test_bf16_training_step(levels, scaler, minf):
-    o, t = trainer_pair(levels, 3, 3, scaler, minf, aa.ANH_BF16)
+@pytest.mark.parametrize("levels,scaler,minf,in_ch", [(2, 1.0, 1, 3), (1, 0.25, 4, 3), (3, 0.5, 1, 3), (2, 0.1, 5, 3), (1, 1.0, 1, 1)])
+def test_bf16_training_step(levels, scaler, minf, in_ch):
+    o, t = trainer_pair(levels, in_ch, 3, scaler, minf, aa.ANH_BF16)   # in_ch = 1: the grayscale build variant
     rng = np.random.default_rng(2)
     d = o.recommended_input_dim(35)
-    img, lab, w, wl = make_batch(rng, 4, d, 3, 3)
+    img, lab, w, wl = make_batch(rng, 4, d, in_ch, 3)
     p0, r0, m0 = o.params.copy(), o.running.copy(), o.momentum.copy()
     fp32_loss = o.train_step(img, lab, w, apply_update=False)
     o.set_bf16_emulation(True)
