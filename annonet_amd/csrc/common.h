@@ -52,4 +52,7 @@ struct DevBuf {
     template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per kernel (and again only if a launch needs more)
+void ensure_dynamic_lds(const void* kernel, size_t bytes);
+
 }  // namespace anh

@@ -15,6 +15,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <mutex>
+#include <unordered_map>
 #include <cstdio>
 #include <vector>
 
@@ -22,6 +24,19 @@
 #include "kernels.h"
 
 namespace anh {
+
+void ensure_dynamic_lds(const void* kernel, size_t bytes) {
+    if (bytes <= 64 * 1024) return;   // the default limit
+    static std::mutex mu;   // handles may be driven from different threads
+    static std::unordered_map<const void*, size_t> configured;
+    std::lock_guard<std::mutex> lock(mu);
+    size_t& have = configured[kernel];
+    if (bytes > have) {
+        HIP_CHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        have = bytes;
+    }
+}
+
 namespace {
 
 typedef __bf16 bf16;
@@ -1319,7 +1334,7 @@ void launch_ws(const ConvArgs& a, int tiles_x, int tiles_y, int flip, hipStream_
     const dim3 grid((unsigned)std::max(1, std::min(n_tiles, ws_target_wgs() / groups)), (unsigned)groups), block(512);
     const size_t lds = 2 * ((size_t)G::RECS * 64 + (size_t)9 * NT * 32 * 64) + (size_t)a.c_red * (a.src.kind == SRC_BNBWD ? 28 : 16) + (size_t)NT * 32 * 16;
     auto launch = [&](auto kernel) {
-        if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), lds);
 #ifndef ANH_WS_PROFILE
         hipLaunchKernelGGL(kernel, grid, block, lds, s, a, tiles_x, tiles_y, flip, (long long*)nullptr);
 #else
@@ -1564,7 +1579,7 @@ template <int NTC, int KP, int KT, int STRIDE>
 void launch_wg(const WgParams& prm, const WgPlan& p, hipStream_t s) {
     if (p.ws) {
         auto launch = [&](auto kernel) {
-            if (p.lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
+            ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), p.lds);
             hipLaunchKernelGGL(kernel, dim3(p.splits, p.slabs), dim3(512), p.lds, s, prm, p.tiles_x, p.tiles_y, p.total, p.splits);
         };
         constexpr bool can_be_cont = STRIDE == 2 && KP == SRC_RAW;   // cont: the patch is dy (raw), its channels are the output channels
@@ -1576,7 +1591,7 @@ void launch_wg(const WgParams& prm, const WgPlan& p, hipStream_t s) {
         return;
     }
     auto kernel = wgrad3x3_mfma_kernel<NTC, KP, KT, STRIDE>;
-    if (p.lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
+    ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), p.lds);
     hipLaunchKernelGGL(kernel, dim3(p.splits, p.slabs), dim3(256), p.lds, s, prm, p.tiles_x, p.tiles_y, p.total, p.splits);
 }
 
