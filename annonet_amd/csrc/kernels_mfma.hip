@@ -746,14 +746,15 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_ws_kernel(WgParams a, int til
     const int tid = threadIdx.x & 255, lane = tid & 63, c16 = tid & 3;
     const int slab = blockIdx.y, split = blockIdx.x;
     const int cc = slab * 32;
+    const int tch0 = blockIdx.z * (NTC * 32);   // 256 tile channels run as two workgroup groups of 128 (levels = 3)
 
     float* tab = reinterpret_cast<float*>(smem + 2 * BUF_BYTES);  // tile side's bn constants: [a_scale | a_shift | b_scale | b_shift][NTC*32]
     if (KT != SRC_RAW) {
         for (int i = threadIdx.x; i < NTC * 32; i += 512) {
-            tab[i] = a.tile.a_scale[i];
-            tab[NTC * 32 + i] = a.tile.a_shift[i];
-            tab[2 * NTC * 32 + i] = KT == SRC_ACT2 ? a.tile.b_scale[i] : 0.f;
-            tab[3 * NTC * 32 + i] = KT == SRC_ACT2 ? a.tile.b_shift[i] : 0.f;
+            tab[i] = a.tile.a_scale[tch0 + i];
+            tab[NTC * 32 + i] = a.tile.a_shift[tch0 + i];
+            tab[2 * NTC * 32 + i] = KT == SRC_ACT2 ? a.tile.b_scale[tch0 + i] : 0.f;
+            tab[3 * NTC * 32 + i] = KT == SRC_ACT2 ? a.tile.b_shift[tch0 + i] : 0.f;
         }
     }
     __syncthreads();
@@ -809,7 +810,7 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_ws_kernel(WgParams a, int til
 #pragma unroll
             for (int jj = 0; jj < NT_; ++jj) {
                 const int oy = y0 + t_row0 + 2 * (jj % JPN), cy = min(oy, a.tile.h - 1);
-                R.t[jj] = side_load_at<KT>(ta, tb, (cy * a.tile.w + cx) * a.tile.c + (jj / JPN) * 32 + c16 * 8);
+                R.t[jj] = side_load_at<KT>(ta, tb, (cy * a.tile.w + cx) * a.tile.c + tch0 + (jj / JPN) * 32 + c16 * 8);
                 R.tok |= ((oy == cy && ox == cx) ? 1u : 0u) << jj;
             }
         };
@@ -891,7 +892,7 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_ws_kernel(WgParams a, int til
                 for (int r = 0; r < 16; ++r) {
                     const int rowc = (r & 3) + 8 * (r >> 2) + 4 * half;      // accumulator row -> channel within the 32-channel tile
                     const int pch = cc + (TRANS ? col : rowc);               // patch channel
-                    const int tch = nt_mine * 32 + (TRANS ? rowc : col);     // tile channel
+                    const int tch = tch0 + nt_mine * 32 + (TRANS ? rowc : col);   // tile channel
                     const int ci = TRANS ? tch : pch, co = TRANS ? pch : tch;
                     out[((size_t)tap * a.c_in + ci) * a.c_out + co] = acc[i][r];
                 }
@@ -1547,7 +1548,7 @@ void launch_wgrad_stem_mfma(const WgradArgs& a, hipStream_t s) {
     if (a.splits_out) *a.splits_out = blocks; else launch_reduce_partials(a.partials, blocks, (int64_t)25 * a.c_in * 32, a.dw, s);
 }
 
-struct WgPlan { int stride, ntc, slabs, tiles_x, tiles_y, total, splits; size_t lds; bool cont, ws; };
+struct WgPlan { int stride, ntc, zgroups, slabs, tiles_x, tiles_y, total, splits; size_t lds; bool cont, ws; };
 
 WgPlan wgrad_plan_mfma(const WgradArgs& a) {
     WgPlan p{};
@@ -1555,11 +1556,12 @@ WgPlan wgrad_plan_mfma(const WgradArgs& a) {
     p.cont = a.gather == 1;
     static const int ws_on = getenv("ANH_WGRAD_WS") ? atoi(getenv("ANH_WGRAD_WS")) : 1;
     p.ws = ws_on != 0;
-    const int ntc_ = (p.cont ? a.c_in : a.c_out) / 32;
+    const int ntc_ = std::min((p.cont ? a.c_in : a.c_out) / 32, 4);
     const int th = a.stride == 1 ? ((p.ws && ntc_ == 4) ? 4 : 8) : 4;
     const int lr_h = p.cont ? a.h_in : a.h_out, lr_w = p.cont ? a.w_in : a.w_out;   // the low-res (tile) tensor
     const int c_tile = p.cont ? a.c_in : a.c_out, c_patch = p.cont ? a.c_out : a.c_in;
-    p.ntc = c_tile / 32;
+    p.ntc = std::min(c_tile / 32, 4);
+    p.zgroups = c_tile / (p.ntc * 32);   // 256 tile channels: two groups of 128 (warp-specialised kernel only)
     p.slabs = c_patch / 32;
     p.tiles_x = (lr_w + 31) / 32;
     p.tiles_y = (lr_h + th - 1) / th;
@@ -1571,7 +1573,7 @@ WgPlan wgrad_plan_mfma(const WgradArgs& a) {
     // one workgroup per CU: these kernels share the chip with the backward-data chain (second stream), and every
     // workgroup writes a full partial, so fewer workgroups also means less partial-sum traffic
     const int target = 256;
-    p.splits = std::max(1, std::min(p.total, target / p.slabs));
+    p.splits = std::max(1, std::min(p.total, target / (p.slabs * p.zgroups)));
     return p;
 }
 
@@ -1580,7 +1582,7 @@ void launch_wg(const WgParams& prm, const WgPlan& p, hipStream_t s) {
     if (p.ws) {
         auto launch = [&](auto kernel) {
             ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), p.lds);
-            hipLaunchKernelGGL(kernel, dim3(p.splits, p.slabs), dim3(512), p.lds, s, prm, p.tiles_x, p.tiles_y, p.total, p.splits);
+            hipLaunchKernelGGL(kernel, dim3(p.splits, p.slabs, p.zgroups), dim3(512), p.lds, s, prm, p.tiles_x, p.tiles_y, p.total, p.splits);
         };
         constexpr bool can_be_cont = STRIDE == 2 && KP == SRC_RAW;   // cont: the patch is dy (raw), its channels are the output channels
         if constexpr (can_be_cont) {
@@ -1590,6 +1592,7 @@ void launch_wg(const WgParams& prm, const WgPlan& p, hipStream_t s) {
         if constexpr (KT == SRC_RAW) launch(wgrad3x3_ws_kernel<NTC, KP, KT, STRIDE, false>);
         return;
     }
+    ANH_REQUIRE(p.zgroups == 1, "wgrad_mfma: 256 tile channels need the warp-specialised kernel");
     auto kernel = wgrad3x3_mfma_kernel<NTC, KP, KT, STRIDE>;
     ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), p.lds);
     hipLaunchKernelGGL(kernel, dim3(p.splits, p.slabs), dim3(256), p.lds, s, prm, p.tiles_x, p.tiles_y, p.total, p.splits);
@@ -1928,7 +1931,7 @@ void launch_up(const ConvArgs& a, hipStream_t s) {
 
 }  // namespace
 
-namespace { bool bnbwd_form_ok(const ConvArgs& a); }
+namespace { bool bnbwd_form_ok(const ConvArgs& a); bool ws_form_ok(const ConvArgs& a); }
 
 bool mfma_conv_supported(const ConvArgs& a) {
     if (stem_mfma_ok(a)) return true;
@@ -1936,13 +1939,14 @@ bool mfma_conv_supported(const ConvArgs& a) {
     if (a.src.kind == SRC_IMAGE || a.src.dtype != DT_BF16 || a.out_dtype != DT_BF16 || a.out_nchw || a.bias) return false;
     if (a.c_red % 32 != 0) return false;
     if (a.src.kind == SRC_BNBWD && !bnbwd_form_ok(a)) return false;  // only the warp-specialised kernels carry that prologue
+    // output channels: 32, or any multiple of 64 up to 256 (workgroup groups of 64 channels: levels = 3 reaches 256)
+    const bool c_ok = a.c_out == 32 || a.c_out == 64 || a.c_out == 128 || a.c_out == 256;
     if (a.stride == 1 && a.pad == 1)
-        return (a.c_out == 32 || a.c_out == 64 || a.c_out == 128) && a.h_in == a.h_out && a.w_in == a.w_out;
+        return c_ok && a.h_in == a.h_out && a.w_in == a.w_out;
     if (a.stride == 2 && a.pad == 0 && a.gather == 0)
-        return (a.c_out == 32 || a.c_out == 64 || a.c_out == 128) && a.h_in >= 3 && a.w_in >= 3 && a.h_out == (a.h_in - 3) / 2 + 1 &&
-               a.w_out == (a.w_in - 3) / 2 + 1;
-    if (a.stride == 2 && a.pad == 0 && a.gather == 1)
-        return (a.c_out == 32 || a.c_out == 64) && a.h_out == 2 * a.h_in + 1 && a.w_out == 2 * a.w_in + 1;
+        return c_ok && a.h_in >= 3 && a.w_in >= 3 && a.h_out == (a.h_in - 3) / 2 + 1 && a.w_out == (a.w_in - 3) / 2 + 1;
+    if (a.stride == 2 && a.pad == 0 && a.gather == 1)   // the classic up kernel has no channel groups: 128 only on the persistent kernel
+        return (a.c_out == 32 || a.c_out == 64 || (a.c_out == 128 && ws_form_ok(a))) && a.h_out == 2 * a.h_in + 1 && a.w_out == 2 * a.w_in + 1;
     return false;
 }
 
@@ -1973,6 +1977,7 @@ ConvPlan conv_plan(const ConvArgs& a) {
 }  // namespace
 
 namespace {
+bool ws_form_ok(const ConvArgs& a) { return a.k == 3 && conv_plan(a).form == 2; }
 bool bnbwd_form_ok(const ConvArgs& a) {
     // Off by default.  Measured: with the apply pass moved to the second stream the backward step gets
     // SLOWER (2.34 vs 2.01 ms) — the backward pass is HBM-bound as a whole, and this schedule adds a read of y per layer.
@@ -2026,8 +2031,8 @@ void launch_conv_mfma(const ConvArgs& a, hipStream_t s) {
     } else if (p.geo == 1) {
         if (p.form == 2) { if (p.nt == 1) launch_ws<GeoDown, 1>(a, p.tiles_x, p.tiles_y, 0, s); else launch_ws<GeoDown, 2>(a, p.tiles_x, p.tiles_y, 0, s); }
         else if (a.c_out == 32) launch_down<1, 9>(a, s);
-        else if (a.c_out == 64) launch_down<2, 9>(a, s);
-        else launch_down<4, 3>(a, s);
+        else if (a.c_out == 128) launch_down<4, 3>(a, s);
+        else launch_down<2, 9>(a, s);   // 64, or 256 as four groups of 64
     } else {
         if (p.form == 2) { if (p.nt == 1) launch_ws<GeoUp, 1>(a, p.tiles_x, p.tiles_y, 0, s); else launch_ws<GeoUp, 2>(a, p.tiles_x, p.tiles_y, 0, s); }
         else if (a.c_out == 32) launch_up<1>(a, s);
@@ -2050,7 +2055,8 @@ bool mfma_wgrad_supported(const WgradArgs& a) {
     const int c_tile = a.gather == 1 ? a.c_in : a.c_out, c_patch = a.gather == 1 ? a.c_out : a.c_in;
     const int64_t plane_in = (int64_t)a.h_in * a.w_in * a.c_in, plane_out = (int64_t)a.h_out * a.w_out * a.c_out;
     if (plane_in >= (1ll << 31) || plane_out >= (1ll << 31)) return false;  // the kernel indexes within one image with 32-bit offsets
-    return c_patch % 32 == 0 && (c_tile == 32 || c_tile == 64 || c_tile == 128);
+    static const int ws_on = getenv("ANH_WGRAD_WS") ? atoi(getenv("ANH_WGRAD_WS")) : 1;
+    return c_patch % 32 == 0 && (c_tile == 32 || c_tile == 64 || c_tile == 128 || (c_tile == 256 && ws_on));
 }
 
 int64_t wgrad_mfma_scratch_floats(const WgradArgs& a) {

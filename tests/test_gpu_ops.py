@@ -26,6 +26,9 @@ SHAPES = [
     ((0, 3, 2, 0, 64, 128), 1, 15, 19),
     ((1, 3, 2, 0, 128, 64), 1, 7, 9),     # up (transposed)
     ((1, 3, 2, 0, 64, 32), 2, 11, 15),
+    ((0, 3, 1, 1, 256, 256), 1, 9, 19),   # levels = 3: 256 channels (four workgroup groups of 64; filter gradient in two tile groups)
+    ((0, 3, 2, 0, 128, 256), 1, 13, 17),
+    ((1, 3, 2, 0, 256, 128), 1, 5, 7),
     ((0, 1, 1, 0, 32, 3), 2, 17, 13),     # head
     ((0, 3, 1, 1, 8, 16), 1, 12, 10),     # narrow nets (width scaler < 1)
     ((0, 3, 1, 1, 40, 24), 1, 10, 13),    # widths that are not multiples of 32
@@ -121,6 +124,7 @@ FUSED_SHAPES = [
     ((0, 3, 1, 1, 32, 32), 3, 21, 37),    # GeoS1, one channel group, ragged edges
     ((0, 3, 1, 1, 64, 64), 2, 18, 33),    # GeoS1, two 32-channel tiles per workgroup
     ((0, 3, 1, 1, 128, 128), 1, 9, 35),   # two workgroup groups of 64 channels
+    ((0, 3, 1, 1, 256, 256), 1, 9, 19),   # four groups
     ((0, 3, 2, 0, 32, 64), 2, 23, 31),    # GeoDown
     ((1, 3, 2, 0, 64, 32), 2, 11, 15),    # GeoUp, fused (one channel tile)
     ((1, 3, 2, 0, 128, 64), 1, 7, 9),     # GeoUp with two tiles: not fused -> the separate kernels must agree too
@@ -192,3 +196,13 @@ def test_stem_filter_gradient_computes_dy_in_kernel():
     want = orc.op_conv_backward_filter(desc, x, dy=dyv)
     tol = 2e-3 * np.abs(want).max() + 1e-6
     assert np.abs(dw - want).max() <= tol, float(np.abs(dw - want).max() / tol)
+
+
+def test_256_channel_layers_take_the_mfma_kernels():
+    """levels = 3 at width 1.0 reaches 256 channels: the three layer kinds must not fall back to the generic kernels."""
+    for desc, n, h, w in [((0, 3, 1, 1, 256, 256), 1, 9, 19), ((0, 3, 2, 0, 128, 256), 1, 13, 17), ((1, 3, 2, 0, 256, 128), 1, 5, 7)]:
+        xa, kw, filters, rng = make_inputs(desc, n, h, w, 4, 1, True)
+        y, mfma_f = aa.op_conv_forward(aa.ANH_BF16, desc, xa, filters=filters, **kw)
+        dx, mfma_b = aa.op_conv_backward_data(aa.ANH_BF16, desc, orc.bf16_round(rng.normal(0, 1, y.shape).astype(np.float32)), filters, (h, w))
+        dw, mfma_w = aa.op_conv_backward_filter(aa.ANH_BF16, desc, xa, dy=orc.bf16_round(rng.normal(0, 1e-3, y.shape).astype(np.float32)), **kw)
+        assert mfma_f and mfma_b and mfma_w, (desc, mfma_f, mfma_b, mfma_w)

@@ -237,7 +237,7 @@ def test_bf16_forward(levels, scaler, minf):
     assert mism.mean() <= 0.03 and ((srt[:, -1] - srt[:, -2])[mism] <= 2 * tol).all()  # only near-ties may flip
 
 
-@pytest.mark.parametrize("levels,scaler,minf,in_ch", [(2, 1.0, 1, 3), (1, 0.25, 4, 3), (3, 0.5, 1, 3), (2, 0.1, 5, 3), (1, 1.0, 1, 1)])
+@pytest.mark.parametrize("levels,scaler,minf,in_ch", [(2, 1.0, 1, 3), (1, 0.25, 4, 3), (3, 0.5, 1, 3), (2, 0.1, 5, 3), (1, 1.0, 1, 1), (3, 1.0, 1, 3)])
 def test_bf16_training_step(levels, scaler, minf, in_ch):
     o, t = trainer_pair(levels, in_ch, 3, scaler, minf, aa.ANH_BF16)   # in_ch = 1: the grayscale build variant
     rng = np.random.default_rng(2)
