@@ -267,42 +267,6 @@ int anh_infer_device(anh_runtime* h, const uint8_t* d_image, int height, int wid
     });
 }
 
-// detection-level filter (annonet_infer.cpp:187-239) on the host.  Seeds are looked up at (row, col): the reference
-// stores (r, c) but reads (point.y(), point.x()) — transposed (annonet_infer.cpp:210 vs :222); see DESIGN.md.
-static void detection_filter(const float* blended, int K, int H, int W, const double* det, uint16_t* labels) {
-    const size_t plane = (size_t)H * W;
-    std::vector<unsigned> blob(plane, 0);
-    std::vector<size_t> stack;
-    unsigned next_id = 1;
-    for (size_t start = 0; start < plane; ++start) {
-        if (labels[start] == 0 || blob[start]) continue;
-        const uint16_t lab = labels[start];
-        const unsigned id = next_id++;
-        blob[start] = id; stack.push_back(start);
-        while (!stack.empty()) {
-            const size_t cur = stack.back(); stack.pop_back();
-            const long r = (long)(cur / W), c = (long)(cur % W);
-            for (long dr = -1; dr <= 1; ++dr)
-                for (long dc = -1; dc <= 1; ++dc) {
-                    const long r2 = r + dr, c2 = c + dc;
-                    if (r2 < 0 || r2 >= H || c2 < 0 || c2 >= W) continue;
-                    const size_t j = (size_t)r2 * W + c2;
-                    if (blob[j] || labels[j] != lab) continue;
-                    blob[j] = id; stack.push_back(j);
-                }
-        }
-    }
-    std::unordered_set<unsigned> detected;
-    for (size_t i = 0; i < plane; ++i) {
-        const uint16_t lab = labels[i];
-        if (lab == 0 || lab == ANH_LABEL_IGNORE || lab >= K) continue;
-        const float clean = blended[i], mine = blended[(size_t)lab * plane + i];
-        if ((double)(mine - clean) > det[lab] - det[0]) detected.insert(blob[i]);
-    }
-    for (size_t i = 0; i < plane; ++i)
-        if (blob[i] && !detected.count(blob[i])) labels[i] = 0;
-}
-
 int anh_infer(anh_runtime* h, const uint8_t* image, int height, int width, const double* gains, const double* detection_levels,
               const anh_tiling_params* tiling, uint16_t* result, float* blended_out) {
     return guarded([&] {
@@ -317,15 +281,21 @@ int anh_infer(anh_runtime* h, const uint8_t* image, int height, int width, const
         e.stage_result.reserve(plane * 2);
         HIP_CHECK(hipMemcpyAsync(e.stage_image.p, image, plane * C, hipMemcpyHostToDevice, e.stream));
         e.infer_device(e.stage_image.as<uint8_t>(), height, width, gains, tiles, e.stage_result.as<uint16_t>(), e.stage_blended.as<float>());
-        HIP_CHECK(hipMemcpyAsync(result, e.stage_result.p, plane * 2, hipMemcpyDeviceToHost, e.stream));
         bool use_det = false;
         if (detection_levels) for (int k = 0; k < K; ++k) { ANH_REQUIRE(detection_levels[k] >= 0.0, "detection levels must be >= 0"); if (detection_levels[k] > 0.0) use_det = true; }
-        std::vector<float> tmp;
-        float* bl = blended_out;
-        if (use_det && !bl) { tmp.resize(plane * K); bl = tmp.data(); }
-        if (bl) HIP_CHECK(hipMemcpyAsync(bl, e.stage_blended.p, plane * K * 4, hipMemcpyDeviceToHost, e.stream));
+        if (use_det) {
+            // detection-level filter (annonet_infer.cpp:187-239), on the resident planes and label map.  Seeds are looked up at
+            // (row, col): the reference stores (r, c) but reads (point.y(), point.x()) — transposed (:210 vs :222); see DESIGN.md.
+            e.stage_out.reserve(plane + (size_t)K * sizeof(double) + 64);
+            uint8_t* flags = e.stage_out.as<uint8_t>();
+            double* d_det = reinterpret_cast<double*>(flags + ((plane + 15) / 16) * 16);
+            int* d_changed = reinterpret_cast<int*>(d_det + K);
+            HIP_CHECK(hipMemcpyAsync(d_det, detection_levels, (size_t)K * sizeof(double), hipMemcpyHostToDevice, e.stream));
+            run_detection_filter(e.stage_blended.as<float>(), e.stage_result.as<uint16_t>(), K, height, width, d_det, flags, d_changed, e.stream);
+        }
+        HIP_CHECK(hipMemcpyAsync(result, e.stage_result.p, plane * 2, hipMemcpyDeviceToHost, e.stream));
+        if (blended_out) HIP_CHECK(hipMemcpyAsync(blended_out, e.stage_blended.p, plane * K * 4, hipMemcpyDeviceToHost, e.stream));
         e.synchronize();
-        if (use_det) detection_filter(bl, K, height, width, detection_levels, result);
     });
 }
 

@@ -172,6 +172,9 @@ void launch_blend(const BlendArgs& a, hipStream_t s);
 void launch_argmax(const float* blended, int k, int64_t pixels, const double* gains_or_null, uint16_t* labels, hipStream_t s);
 
 void launch_fill_zero(void* p, size_t bytes, hipStream_t s);
+// detection-level filter of annonet_infer() on the device (kernels_generic.hip)
+void run_detection_filter(const float* d_blended, uint16_t* d_labels, int k, int h, int w, const double* d_det, uint8_t* d_flags, int* d_changed,
+                          hipStream_t s);
 void launch_reduce_partials(const float* partials, int splits, int64_t nw, float* out, hipStream_t s);
 
 // training-time tail fused into one pass: 1x1 head forward + weighted softmax log-loss + head backward-data + head

@@ -1111,7 +1111,96 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float* blended, int k
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// detection-level filter (annonet_infer.cpp:187-239) on the device.  A blob = 8-connected pixels of one non-zero label; a blob
+// without a seed pixel (class score above "clean" by more than its detection level) is relabelled 0.  Instead of labelling
+// components, the seed property is flooded through them: 32x32 tiles (+1 halo) iterate in LDS until nothing changes inside
+// the tile; the launch is repeated until no tile changed.  Flags only ever go 0 -> 1, so the in-place sweeps are race-benign.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void det_seed_kernel(const float* blended, const uint16_t* labels, int k, int64_t pixels, const double* det, uint8_t* flags) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < pixels; p += stride) {
+        const uint16_t lab = labels[p];
+        uint8_t f = 0;
+        if (lab != 0 && lab != ANH_LABEL_IGNORE && lab < k) {
+            const float clean = blended[p], mine = blended[(size_t)lab * pixels + p];
+            if ((double)(mine - clean) > det[lab] - det[0]) f = 1;
+        }
+        flags[p] = f;
+    }
+}
+
+__global__ __launch_bounds__(256) void det_flood_kernel(const uint16_t* labels, uint8_t* flags, int h, int w, int* changed) {
+    constexpr int T = 32, S = T + 2;
+    __shared__ uint16_t lab[S][S];
+    __shared__ uint8_t flg[S][S];
+    const int x0 = blockIdx.x * T - 1, y0 = blockIdx.y * T - 1;
+    for (int i = threadIdx.x; i < S * S; i += 256) {
+        const int ly = i / S, lx = i - ly * S, y = y0 + ly, x = x0 + lx;
+        const bool in = y >= 0 && y < h && x >= 0 && x < w;
+        lab[ly][lx] = in ? labels[(size_t)y * w + x] : (uint16_t)0;   // label 0 never joins a blob
+        flg[ly][lx] = in ? flags[(size_t)y * w + x] : (uint8_t)0;
+    }
+    __syncthreads();
+    bool mine_changed = false;
+    for (;;) {
+        bool sweep = false;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = threadIdx.x + 256 * q, ly = 1 + (i >> 5), lx = 1 + (i & 31);
+            const uint16_t l = lab[ly][lx];
+            if (l != 0 && !flg[ly][lx]) {
+                bool any = false;
+#pragma unroll
+                for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                    for (int dx = -1; dx <= 1; ++dx) any = any || (lab[ly + dy][lx + dx] == l && flg[ly + dy][lx + dx]);
+                if (any) { flg[ly][lx] = 1; sweep = true; }
+            }
+        }
+        mine_changed = mine_changed || sweep;
+        if (!__syncthreads_or(sweep)) break;
+    }
+    if (mine_changed) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = threadIdx.x + 256 * q, ly = 1 + (i >> 5), lx = 1 + (i & 31), y = y0 + ly, x = x0 + lx;
+            if (y < h && x < w && flg[ly][lx]) flags[(size_t)y * w + x] = 1;
+        }
+        *changed = 1;
+    }
+}
+
+__global__ __launch_bounds__(256) void det_apply_kernel(uint16_t* labels, const uint8_t* flags, int64_t pixels) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < pixels; p += stride)
+        if (labels[p] != 0 && !flags[p]) labels[p] = 0;
+}
+
 }  // namespace
+
+// Relabels every blob without a seed to 0, in place.  d_flags: H*W bytes of scratch; d_changed: one int; det: K doubles on the device.
+void run_detection_filter(const float* d_blended, uint16_t* d_labels, int k, int h, int w, const double* d_det, uint8_t* d_flags, int* d_changed,
+                          hipStream_t s) {
+    const int64_t pixels = (int64_t)h * w;
+    if (pixels == 0) return;
+    const int blocks = (int)std::min<int64_t>((pixels + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(det_seed_kernel, dim3(blocks), dim3(256), 0, s, d_blended, d_labels, k, pixels, d_det, d_flags);
+    HIP_CHECK(hipGetLastError());
+    const dim3 grid((unsigned)((w + 31) / 32), (unsigned)((h + 31) / 32));
+    for (int round = 0;; ++round) {
+        ANH_REQUIRE(round < 100000, "detection filter did not converge");
+        HIP_CHECK(hipMemsetAsync(d_changed, 0, sizeof(int), s));
+        for (int rep = 0; rep < 4; ++rep) hipLaunchKernelGGL(det_flood_kernel, grid, dim3(256), 0, s, d_labels, d_flags, h, w, d_changed);
+        HIP_CHECK(hipGetLastError());
+        int changed = 0;
+        HIP_CHECK(hipMemcpyAsync(&changed, d_changed, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        if (!changed) break;
+    }
+    hipLaunchKernelGGL(det_apply_kernel, dim3(blocks), dim3(256), 0, s, d_labels, d_flags, pixels);
+    HIP_CHECK(hipGetLastError());
+}
 
 // ===================================================================================================
 // launchers

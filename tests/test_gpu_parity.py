@@ -89,6 +89,13 @@ def test_infer_detection_levels_and_nan():
     img = np.random.default_rng(4).integers(0, 256, (31, 31, 3), dtype=np.uint8)
     for det in ([0.0, 1e9, 1e9], [0.0, 0.0, 0.0], [0.0, 0.5, 0.25], [0.1, 0.0, 2.0]):
         np.testing.assert_array_equal(aa.annonet_infer(net, img, detection_levels=det), o.infer(img, detection_levels=det))
+    # blobs that span many 32x32 flood tiles of the device-side filter (large flat regions, ragged image size)
+    base = np.random.default_rng(5).integers(0, 256, (6, 7, 3))
+    big = np.kron(base, np.ones((27, 25, 1))).astype(np.uint8)[:150, :170]
+    labels0 = o.infer(big)
+    assert max(np.bincount(labels0.ravel())) > 4000          # there are blobs larger than a few tiles
+    for det in ([0.0, 0.05, 0.02], [0.02, 0.3, 0.0], [0.0, 1e9, 0.01]):
+        np.testing.assert_array_equal(aa.annonet_infer(net, big, detection_levels=det), o.infer(big, detection_levels=det))
     # all-NaN logits keep the start label 65535 (annonet_infer.cpp:172-183)
     p, r = net.get_params()
     head = aa.net_layers(net.cfg)[-1]
