@@ -65,9 +65,19 @@ struct anh_trainer {
     std::deque<PendingLoss> pending;
     std::vector<hipEvent_t> free_events;
     int next_slot = 0;
-    std::vector<uint8_t> pack_img;
-    std::vector<uint16_t> pack_lab;
-    std::vector<float> pack_w;
+    // Host-buffer steps (StartTraining): two staging sets, each a pinned host block + a device block holding
+    // [images | labels u16 | weights f32].  Step k packs into set k&1 while the GPU still runs step k-1, uploads it on a copy
+    // stream and chains the compute behind the upload with events; the call returns once the inputs are packed
+    // (annonet_train_main.cpp:585-586 refills samples/labels right after StartTraining returns).
+    struct StageSet {
+        void* pinned = nullptr; size_t pinned_bytes = 0;
+        DevBuf dev;
+        hipEvent_t uploaded = nullptr, consumed = nullptr;   // H2D of this set done / the step that read it has finished
+        bool in_flight = false;
+    };
+    StageSet stage[2];
+    hipStream_t copy_stream = nullptr;
+    unsigned long host_steps = 0;
 
     bool initialized = false, dirty = false;
     // The reference configures AFTER Initialize() (annonet_train_main.cpp:400-410: Initialize, SetNetWidth, ..., SetClassCount);
@@ -102,6 +112,12 @@ struct anh_trainer {
         for (auto& p : pending) (void)hipEventDestroy(p.ev);
         for (auto e : free_events) (void)hipEventDestroy(e);
         if (loss_ring) (void)hipHostFree(loss_ring);
+        for (auto& st : stage) {
+            if (st.pinned) (void)hipHostFree(st.pinned);
+            if (st.uploaded) (void)hipEventDestroy(st.uploaded);
+            if (st.consumed) (void)hipEventDestroy(st.consumed);
+        }
+        if (copy_stream) (void)hipStreamDestroy(copy_stream);
     }
 };
 
@@ -425,31 +441,58 @@ int anh_trainer_step(anh_trainer* h, const uint8_t* const* images, const anh_wla
         Engine& e = h->engine();
         const int C = e.spec.cfg.in_channels, K = e.spec.cfg.classes;
         const size_t plane = (size_t)height * width;
-        h->pack_img.resize((size_t)n * plane * C);
-        h->pack_lab.resize((size_t)n * plane);
-        h->pack_w.resize((size_t)n * plane);
-        for (int i = 0; i < n; ++i) {
-            ANH_REQUIRE(images[i] && labels[i], "null sample");
-            std::memcpy(h->pack_img.data() + (size_t)i * plane * C, images[i], plane * C);
-            for (size_t p = 0; p < plane; ++p) {
-                const anh_wlabel& wl = labels[i][p];
-                ANH_REQUIRE(wl.label == ANH_LABEL_IGNORE || wl.label < K, "label value exceeds the class count");
-                h->pack_lab[(size_t)i * plane + p] = wl.label;
-                h->pack_w[(size_t)i * plane + p] = wl.weight;
-            }
+        const size_t img_bytes = (size_t)n * plane * C, lab_off = (img_bytes + 255) / 256 * 256, lab_bytes = (size_t)n * plane * 2;
+        const size_t w_off = (lab_off + lab_bytes + 255) / 256 * 256, total = w_off + (size_t)n * plane * 4;
+        for (int i = 0; i < n; ++i) ANH_REQUIRE(images[i] && labels[i], "null sample");
+
+        anh_trainer::StageSet& st = h->stage[h->host_steps & 1];
+        if (!h->copy_stream) HIP_CHECK(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+        if (!st.uploaded) {
+            HIP_CHECK(hipEventCreateWithFlags(&st.uploaded, hipEventDisableTiming));
+            HIP_CHECK(hipEventCreateWithFlags(&st.consumed, hipEventDisableTiming));
         }
-        e.stage_image.reserve(h->pack_img.size());
-        e.stage_labels.reserve(h->pack_lab.size() * 2);
-        e.stage_weights.reserve(h->pack_w.size() * 4);
-        // synchronous copies: the host refills samples/labels right after StartTraining returns (annonet_train_main.cpp:585-586)
-        e.synchronize();
-        HIP_CHECK(hipMemcpy(e.stage_image.p, h->pack_img.data(), h->pack_img.size(), hipMemcpyHostToDevice));
-        HIP_CHECK(hipMemcpy(e.stage_labels.p, h->pack_lab.data(), h->pack_lab.size() * 2, hipMemcpyHostToDevice));
-        HIP_CHECK(hipMemcpy(e.stage_weights.p, h->pack_w.data(), h->pack_w.size() * 4, hipMemcpyHostToDevice));
-        int rc = anh_trainer_forward_backward_device(h, e.stage_image.as<uint8_t>(), e.stage_labels.as<uint16_t>(), e.stage_weights.as<float>(), n, height, width, (double)n);
+        if (st.in_flight) HIP_CHECK(hipEventSynchronize(st.uploaded));   // the pinned block is free again (upload of step k-2 done)
+        if (total > st.pinned_bytes) {
+            if (st.in_flight) HIP_CHECK(hipEventSynchronize(st.consumed));
+            if (st.pinned) HIP_CHECK(hipHostFree(st.pinned));
+            st.pinned = nullptr; st.pinned_bytes = 0;
+            HIP_CHECK(hipHostMalloc(&st.pinned, total, hipHostMallocDefault));
+            st.pinned_bytes = total;
+            st.dev.reserve(total);
+        }
+        // ---- pack: images as they are, weighted labels split into a u16 and an f32 plane; labels validated on the way ----
+        uint8_t* base = static_cast<uint8_t*>(st.pinned);
+        uint16_t* plab = reinterpret_cast<uint16_t*>(base + lab_off);
+        float* pw = reinterpret_cast<float*>(base + w_off);
+        bool bad_label = false;
+        for (int i = 0; i < n; ++i) {
+            std::memcpy(base + (size_t)i * plane * C, images[i], plane * C);
+            const anh_wlabel* src = labels[i];
+            uint16_t* dl = plab + (size_t)i * plane;
+            float* dw = pw + (size_t)i * plane;
+            unsigned worst = 0;
+            for (size_t p = 0; p < plane; ++p) {
+                const uint16_t l = src[p].label;
+                dl[p] = l; dw[p] = src[p].weight;
+                worst |= (unsigned)(l != ANH_LABEL_IGNORE && l >= K);
+            }
+            bad_label = bad_label || worst != 0;
+        }
+        ANH_REQUIRE(!bad_label, "label value exceeds the class count");
+        // ---- upload behind the step that last read this device block, compute behind the upload ----
+        if (st.in_flight) HIP_CHECK(hipStreamWaitEvent(h->copy_stream, st.consumed, 0));
+        HIP_CHECK(hipMemcpyAsync(st.dev.p, st.pinned, total, hipMemcpyHostToDevice, h->copy_stream));
+        HIP_CHECK(hipEventRecord(st.uploaded, h->copy_stream));
+        HIP_CHECK(hipStreamWaitEvent(e.stream, st.uploaded, 0));
+        uint8_t* dbase = st.dev.as<uint8_t>();
+        int rc = anh_trainer_forward_backward_device(h, dbase, reinterpret_cast<uint16_t*>(dbase + lab_off), reinterpret_cast<float*>(dbase + w_off), n, height,
+                                                     width, (double)n);
         if (rc != ANH_OK) fail(rc, g_error);
         rc = anh_trainer_apply_update(h, 1.0);
         if (rc != ANH_OK) fail(rc, g_error);
+        HIP_CHECK(hipEventRecord(st.consumed, e.stream));
+        st.in_flight = true;
+        ++h->host_steps;
     });
 }
 
