@@ -44,6 +44,23 @@ namespace anh { void set_last_error(const std::string& message) { g_error = mess
 
 struct anh_runtime {
     std::unique_ptr<Engine> eng;
+    // host-buffer annonet_infer(): image strips go up and label strips come down through small pinned rings while the tiles
+    // compute, so that neither transfer is exposed (anh_infer below)
+    static constexpr int kRing = 3;
+    struct Pinned { void* p = nullptr; size_t bytes = 0; hipEvent_t done = nullptr; bool busy = false; };
+    Pinned up[kRing], down[kRing];
+    hipStream_t copy_up = nullptr, copy_down = nullptr;
+    std::vector<hipEvent_t> strip_events;
+    ~anh_runtime() {
+        for (auto* ring : {up, down})
+            for (int i = 0; i < kRing; ++i) {
+                if (ring[i].p) (void)hipHostFree(ring[i].p);
+                if (ring[i].done) (void)hipEventDestroy(ring[i].done);
+            }
+        for (auto ev : strip_events) (void)hipEventDestroy(ev);
+        if (copy_up) (void)hipStreamDestroy(copy_up);
+        if (copy_down) (void)hipStreamDestroy(copy_down);
+    }
 };
 
 struct anh_trainer {
@@ -283,6 +300,112 @@ int anh_infer_device(anh_runtime* h, const uint8_t* d_image, int height, int wid
     });
 }
 
+namespace {
+void ring_reserve(anh_runtime::Pinned& b, size_t bytes) {
+    if (!b.done) HIP_CHECK(hipEventCreateWithFlags(&b.done, hipEventDisableTiming));
+    if (bytes <= b.bytes) return;
+    if (b.p) HIP_CHECK(hipHostFree(b.p));
+    b.p = nullptr; b.bytes = 0;
+    HIP_CHECK(hipHostMalloc(&b.p, bytes, hipHostMallocDefault));
+    b.bytes = bytes;
+}
+
+// The streamed form of annonet_infer() for host buffers: the image is uploaded in row strips (host memcpy into a pinned ring
+// -> async DMA on a copy stream), a tile starts as soon as the rows of its window are resident, and the label rows that no
+// later tile can touch are arg-maxed and sent back (pinned ring -> host memcpy) while the next tile row computes.
+void infer_streamed(anh_runtime* h, const uint8_t* image, int H, int W, const double* gains, const std::vector<anh_tile>& tiles, uint16_t* result) {
+    Engine& e = *h->eng;
+    const int K = e.spec.cfg.classes, C = e.spec.cfg.in_channels;
+    const size_t plane = (size_t)H * W, row_bytes = (size_t)W * C;
+    if (!h->copy_up) {
+        HIP_CHECK(hipStreamCreateWithFlags(&h->copy_up, hipStreamNonBlocking));
+        HIP_CHECK(hipStreamCreateWithFlags(&h->copy_down, hipStreamNonBlocking));
+    }
+    const int strip_rows = std::max(1, (int)std::min<size_t>((size_t)H, ((size_t)4 << 20) / std::max<size_t>(row_bytes, 1)));   // ~4 MiB strips
+    const int n_strips = (H + strip_rows - 1) / strip_rows;
+    while ((int)h->strip_events.size() < n_strips) {
+        hipEvent_t ev;
+        HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        h->strip_events.push_back(ev);
+    }
+    for (int i = 0; i < anh_runtime::kRing; ++i) { h->up[i].busy = false; h->down[i].busy = false; }
+    uint8_t* d_image = e.stage_image.as<uint8_t>();
+    float* d_blended = e.stage_blended.as<float>();
+    uint16_t* d_labels = e.stage_result.as<uint16_t>();
+    launch_fill_zero(d_blended, plane * K * 4, e.stream);
+    const double* d_gains = e.upload_gains(gains);
+
+    int uploaded = 0, next_strip = 0;
+    auto upload_until = [&](int rows) {   // rows [0, rows) resident (as far as the copy stream is concerned)
+        rows = std::min(rows, H);
+        while (uploaded < rows) {
+            anh_runtime::Pinned& b = h->up[next_strip % anh_runtime::kRing];
+            const int r0 = uploaded, r1 = std::min(H, r0 + strip_rows);
+            const size_t bytes = (size_t)(r1 - r0) * row_bytes;
+            if (b.busy) HIP_CHECK(hipEventSynchronize(b.done));
+            ring_reserve(b, (size_t)strip_rows * row_bytes);
+            std::memcpy(b.p, image + (size_t)r0 * row_bytes, bytes);
+            HIP_CHECK(hipMemcpyAsync(d_image + (size_t)r0 * row_bytes, b.p, bytes, hipMemcpyHostToDevice, h->copy_up));
+            HIP_CHECK(hipEventRecord(b.done, h->copy_up));
+            HIP_CHECK(hipEventRecord(h->strip_events[next_strip], h->copy_up));
+            b.busy = true;
+            uploaded = r1; ++next_strip;
+        }
+    };
+    struct Down { int slot, r0, r1; };
+    std::vector<Down> pending;
+    auto drain = [&](size_t keep) {       // copy finished label strips out of the pinned ring
+        while (pending.size() > keep) {
+            const Down d = pending.front();
+            pending.erase(pending.begin());
+            anh_runtime::Pinned& b = h->down[d.slot];
+            HIP_CHECK(hipEventSynchronize(b.done));
+            std::memcpy(result + (size_t)d.r0 * W, b.p, (size_t)(d.r1 - d.r0) * W * 2);
+            b.busy = false;
+        }
+    };
+    hipEvent_t labels_ready;
+    HIP_CHECK(hipEventCreateWithFlags(&labels_ready, hipEventDisableTiming));
+    int labels_done = 0, down_slot = 0;
+    const size_t max_down_rows = std::min<size_t>((size_t)H, std::max<size_t>(1, ((size_t)16 << 20) / ((size_t)W * 2)));   // label strips of <= 16 MiB
+    auto send_labels = [&](int until) {   // rows [labels_done, until) are final on the compute stream
+        while (labels_done < until) {
+            const int r0 = labels_done, r1 = (int)std::min<size_t>((size_t)until, (size_t)r0 + max_down_rows);
+            launch_argmax_range(d_blended, K, (int64_t)plane, (int64_t)r0 * W, (int64_t)r1 * W, d_gains, d_labels, e.stream);
+            HIP_CHECK(hipEventRecord(labels_ready, e.stream));
+            drain(anh_runtime::kRing - 1);
+            anh_runtime::Pinned& b = h->down[down_slot];   // free: at most kRing - 1 strips are pending
+            ring_reserve(b, max_down_rows * W * 2);
+            HIP_CHECK(hipStreamWaitEvent(h->copy_down, labels_ready, 0));
+            HIP_CHECK(hipMemcpyAsync(b.p, d_labels + (size_t)r0 * W, (size_t)(r1 - r0) * W * 2, hipMemcpyDeviceToHost, h->copy_down));
+            HIP_CHECK(hipEventRecord(b.done, h->copy_down));
+            b.busy = true;
+            pending.push_back(Down{down_slot, r0, r1});
+            down_slot = (down_slot + 1) % anh_runtime::kRing;
+            labels_done = r1;
+        }
+    };
+    // rows below final_after[i] receive nothing from the tiles after i
+    std::vector<int> final_after(tiles.size());
+    int lowest_top = H;
+    for (size_t i = tiles.size(); i-- > 0;) { final_after[i] = std::min(lowest_top, H); lowest_top = std::min(lowest_top, (int)std::max(0l, (long)tiles[i].full_rect.top)); }
+    for (size_t i = 0; i < tiles.size(); ++i) {
+        const TileWindow win = tile_window(tiles[i], e.spec.cfg.levels);
+        const int need = std::min(H, std::max(1, win.top + win.height));   // clamp-to-edge reads reach row 0 / row H-1 at most
+        upload_until(need);
+        HIP_CHECK(hipStreamWaitEvent(e.stream, h->strip_events[(need - 1) / strip_rows], 0));
+        e.infer_tile(tiles[i], d_image, H, W, d_blended);
+        upload_until(uploaded + strip_rows);   // stay a few strips ahead of the tiles: one more strip per tile enqueued
+        if (final_after[i] > labels_done) send_labels(final_after[i]);
+    }
+    upload_until(H);        // an image larger than its tiles' windows cannot occur, but keep the invariant
+    send_labels(H);
+    drain(0);
+    HIP_CHECK(hipEventDestroy(labels_ready));
+    e.synchronize();
+}
+}  // namespace
+
 int anh_infer(anh_runtime* h, const uint8_t* image, int height, int width, const double* gains, const double* detection_levels,
               const anh_tiling_params* tiling, uint16_t* result, float* blended_out) {
     return guarded([&] {
@@ -295,10 +418,12 @@ int anh_infer(anh_runtime* h, const uint8_t* image, int height, int width, const
         e.stage_image.reserve(plane * C);
         e.stage_blended.reserve(plane * K * 4);
         e.stage_result.reserve(plane * 2);
-        HIP_CHECK(hipMemcpyAsync(e.stage_image.p, image, plane * C, hipMemcpyHostToDevice, e.stream));
-        e.infer_device(e.stage_image.as<uint8_t>(), height, width, gains, tiles, e.stage_result.as<uint16_t>(), e.stage_blended.as<float>());
         bool use_det = false;
         if (detection_levels) for (int k = 0; k < K; ++k) { ANH_REQUIRE(detection_levels[k] >= 0.0, "detection levels must be >= 0"); if (detection_levels[k] > 0.0) use_det = true; }
+        static const bool streamed = !(getenv("ANH_INFER_STREAMED") && atoi(getenv("ANH_INFER_STREAMED")) == 0);
+        if (streamed && !use_det && !blended_out) { infer_streamed(h, image, height, width, gains, tiles, result); return; }
+        HIP_CHECK(hipMemcpyAsync(e.stage_image.p, image, plane * C, hipMemcpyHostToDevice, e.stream));
+        e.infer_device(e.stage_image.as<uint8_t>(), height, width, gains, tiles, e.stage_result.as<uint16_t>(), e.stage_blended.as<float>());
         if (use_det) {
             // detection-level filter (annonet_infer.cpp:187-239), on the resident planes and label map.  Seeds are looked up at
             // (row, col): the reference stores (r, c) but reads (point.y(), point.x()) — transposed (:210 vs :222); see DESIGN.md.

@@ -646,35 +646,42 @@ void Engine::layer_tensor(int layer, int which, float* out_host, int64_t capacit
 // ---------------------------------------------------------------------------------------------------
 // tiled inference (annonet_infer.cpp:42-214)
 // ---------------------------------------------------------------------------------------------------
+// one tile of annonet_infer(): clamp-to-edge window of the resident image -> net forward -> blend into the resident planes
+void Engine::infer_tile(const anh_tile& t, const uint8_t* d_image, int H, int W, float* d_blended) {
+    const int K = spec.cfg.classes;
+    const TileWindow win = tile_window(t, spec.cfg.levels);
+    Src image;
+    image.kind = SRC_IMAGE;
+    image.img = d_image; image.img_h = H; image.img_w = W; image.img_left = win.left; image.img_top = win.top;
+    tile_out.reserve((size_t)K * win.height * win.width * 4);
+    forward_inference(image, 1, win.height, win.width, tile_out.as<float>());
+    BlendArgs b;
+    b.logits_nchw = tile_out.as<float>(); b.blended = d_blended;
+    b.k = K; b.tile_h = win.height; b.tile_w = win.width; b.tile_left = win.left; b.tile_top = win.top;
+    b.img_h = H; b.img_w = W;
+    b.full[0] = t.full_rect.left; b.full[1] = t.full_rect.top; b.full[2] = t.full_rect.right; b.full[3] = t.full_rect.bottom;
+    b.unique[0] = t.unique_rect.left; b.unique[1] = t.unique_rect.top; b.unique[2] = t.unique_rect.right; b.unique[3] = t.unique_rect.bottom;
+    const int tok = prof.begin(stream, "blend_accumulate", 0, (double)K * win.height * win.width * 12);
+    launch_blend(b, stream);
+    prof.end(stream, tok);
+}
+
+const double* Engine::upload_gains(const double* gains_host) {
+    if (!gains_host) return nullptr;
+    const int K = spec.cfg.classes;
+    gains_dev.reserve((size_t)K * sizeof(double));
+    HIP_CHECK(hipMemcpyAsync(gains_dev.p, gains_host, (size_t)K * sizeof(double), hipMemcpyHostToDevice, stream));
+    return gains_dev.as<double>();
+}
+
 void Engine::infer_device(const uint8_t* d_image, int H, int W, const double* gains_host, const std::vector<anh_tile>& tiles,
                           uint16_t* d_labels, float* d_blended) {
     ANH_REQUIRE(H >= 1 && W >= 1, "empty image");
     const int K = spec.cfg.classes;
     const int64_t pixels = (int64_t)H * W;
     launch_fill_zero(d_blended, (size_t)K * pixels * 4, stream);
-    for (const anh_tile& t : tiles) {
-        const TileWindow win = tile_window(t, spec.cfg.levels);
-        Src image;
-        image.kind = SRC_IMAGE;
-        image.img = d_image; image.img_h = H; image.img_w = W; image.img_left = win.left; image.img_top = win.top;
-        tile_out.reserve((size_t)K * win.height * win.width * 4);
-        forward_inference(image, 1, win.height, win.width, tile_out.as<float>());
-        BlendArgs b;
-        b.logits_nchw = tile_out.as<float>(); b.blended = d_blended;
-        b.k = K; b.tile_h = win.height; b.tile_w = win.width; b.tile_left = win.left; b.tile_top = win.top;
-        b.img_h = H; b.img_w = W;
-        b.full[0] = t.full_rect.left; b.full[1] = t.full_rect.top; b.full[2] = t.full_rect.right; b.full[3] = t.full_rect.bottom;
-        b.unique[0] = t.unique_rect.left; b.unique[1] = t.unique_rect.top; b.unique[2] = t.unique_rect.right; b.unique[3] = t.unique_rect.bottom;
-        const int tok = prof.begin(stream, "blend_accumulate", 0, (double)K * win.height * win.width * 12);
-        launch_blend(b, stream);
-        prof.end(stream, tok);
-    }
-    const double* d_gains = nullptr;
-    if (gains_host) {
-        gains_dev.reserve((size_t)K * sizeof(double));
-        HIP_CHECK(hipMemcpyAsync(gains_dev.p, gains_host, (size_t)K * sizeof(double), hipMemcpyHostToDevice, stream));
-        d_gains = gains_dev.as<double>();
-    }
+    for (const anh_tile& t : tiles) infer_tile(t, d_image, H, W, d_blended);
+    const double* d_gains = upload_gains(gains_host);
     if (d_labels) {
         const int tok = prof.begin(stream, "argmax_gain", 0, (double)pixels * (K * 4.0 + 2.0));
         launch_argmax(d_blended, K, pixels, d_gains, d_labels, stream);

@@ -170,6 +170,7 @@ struct BlendArgs {
 };
 void launch_blend(const BlendArgs& a, hipStream_t s);
 void launch_argmax(const float* blended, int k, int64_t pixels, const double* gains_or_null, uint16_t* labels, hipStream_t s);
+void launch_argmax_range(const float* blended, int k, int64_t pixels, int64_t p0, int64_t p1, const double* gains_or_null, uint16_t* labels, hipStream_t s);
 
 void launch_fill_zero(void* p, size_t bytes, hipStream_t s);
 // detection-level filter of annonet_infer() on the device (kernels_generic.hip)

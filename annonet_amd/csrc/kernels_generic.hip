@@ -1097,9 +1097,9 @@ __global__ __launch_bounds__(256) void blend_kernel(BlendArgs a) {
 }
 
 // find_label (annonet_infer.cpp:170-185): strict '>' from -inf, start label 65535, gain added in double
-__global__ __launch_bounds__(256) void argmax_kernel(const float* blended, int k, int64_t pixels, const double* gains, uint16_t* labels) {
+__global__ __launch_bounds__(256) void argmax_kernel(const float* blended, int k, int64_t pixels, int64_t p0, int64_t p1, const double* gains, uint16_t* labels) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < pixels; p += stride) {
+    for (int64_t p = p0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < p1; p += stride) {
         uint16_t label = ANH_LABEL_IGNORE;
         float best = -INFINITY;
         for (int c = 0; c < k; ++c) {
@@ -1439,9 +1439,13 @@ void launch_blend(const BlendArgs& a, hipStream_t s) {
 }
 
 void launch_argmax(const float* blended, int k, int64_t pixels, const double* gains_or_null, uint16_t* labels, hipStream_t s) {
-    if (pixels == 0) return;
-    const int blocks = (int)std::min<int64_t>((pixels + 255) / 256, 256 * 16);
-    hipLaunchKernelGGL(argmax_kernel, dim3(blocks), dim3(256), 0, s, blended, k, pixels, gains_or_null, labels);
+    launch_argmax_range(blended, k, pixels, 0, pixels, gains_or_null, labels, s);
+}
+// labels of the pixels [p0, p1) of planes that hold `pixels` pixels each
+void launch_argmax_range(const float* blended, int k, int64_t pixels, int64_t p0, int64_t p1, const double* gains_or_null, uint16_t* labels, hipStream_t s) {
+    if (p1 <= p0) return;
+    const int blocks = (int)std::min<int64_t>((p1 - p0 + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(argmax_kernel, dim3(blocks), dim3(256), 0, s, blended, k, pixels, p0, p1, gains_or_null, labels);
     HIP_CHECK(hipGetLastError());
 }
 

@@ -66,12 +66,16 @@ def cpu_baseline(sample_tiles=4):
     p, r = random_params(o, 2)
     o.params[:], o.running[:] = p, r
     img, lab, w = synthetic_batch(0)
-    img, lab, w = img[:sample_tiles], lab[:sample_tiles], w[:sample_tiles]
     o.train_step(img[:1], lab[:1], w[:1])  # warm-up (page-in, OpenMP pool)
+    t0 = time.perf_counter()
+    o.train_step(img[:2], lab[:2], w[:2], apply_update=False)  # estimate of the per-tile cost
+    per_tile = (time.perf_counter() - t0) / 2
+    sample_tiles = int(min(len(img), max(sample_tiles, round(12.0 / max(per_tile, 1e-3)))))  # ~12 s of CPU work, at most the whole batch
+    img, lab, w = img[:sample_tiles], lab[:sample_tiles], w[:sample_tiles]
     t0 = time.perf_counter()
     o.train_step(img, lab, w)
     dt = time.perf_counter() - t0
-    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    cores = int(os.environ["OMP_NUM_THREADS"])   # set by oracle/oracle.py: the CPUs this job may use, capped at 16 (a one-GPU box's share)
     return {"value": sample_tiles / dt, "unit": "tiles/s", "cores": cores, "kind": "port",
             "sample": f"1 training step on {sample_tiles} tiles of {TILE}x{TILE}x3 (same net, fp32 CPU oracle, {dt:.2f} s)"}
 

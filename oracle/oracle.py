@@ -12,6 +12,19 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
+
+def default_threads():
+    """OpenMP threads for the oracle: the CPUs this process may run on, capped at 16.  A GPU box reports every core of the
+    host (256) while a one-GPU job owns a share of 16; 256 threads on that share run the oracle ~10x slower."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))
+
+
+os.environ.setdefault("OMP_NUM_THREADS", str(default_threads()))   # before libgomp starts with the oracle library
+
 IGNORE = 65535
 
 
