@@ -70,7 +70,7 @@ def cpu_baseline(sample_tiles=4):
     t0 = time.perf_counter()
     o.train_step(img[:2], lab[:2], w[:2], apply_update=False)  # estimate of the per-tile cost
     per_tile = (time.perf_counter() - t0) / 2
-    sample_tiles = int(min(len(img), max(sample_tiles, round(12.0 / max(per_tile, 1e-3)))))  # ~12 s of CPU work, at most the whole batch
+    sample_tiles = int(min(len(img), max(sample_tiles, round(20.0 / max(per_tile, 1e-3)))))  # ~10-20 s of CPU work, at most the whole batch
     img, lab, w = img[:sample_tiles], lab[:sample_tiles], w[:sample_tiles]
     t0 = time.perf_counter()
     o.train_step(img, lab, w)
