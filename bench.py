@@ -255,7 +255,7 @@ def main():
             "config": {"workload": f"training step (fwd+loss+bwd+SGD), batch {BATCH}x3x{TILE}x{TILE} per GPU, encoder-decoder levels={LEVELS} width={WIDTH} K={CLASSES}, random init",
                        "global_batch": BATCH * world, "parallelism": f"dp{world}"},
             "roofline": roof,
-            "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline(),
+            "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline(),   # rank 0 at N=1 only
             "kernel_time_share_pct": breakdown,
             "final_loss": loss,
         }
