@@ -653,14 +653,35 @@ void Engine::infer_tile(const anh_tile& t, const uint8_t* d_image, int H, int W,
     Src image;
     image.kind = SRC_IMAGE;
     image.img = d_image; image.img_h = H; image.img_w = W; image.img_left = win.left; image.img_top = win.top;
-    tile_out.reserve((size_t)K * win.height * win.width * 4);
-    forward_inference(image, 1, win.height, win.width, tile_out.as<float>());
+    // bf16 mode: the 1x1 head and the blend run as one kernel over the last hidden tensor (the tile's logits stay on chip)
+    const anh_layer_desc& head = spec.layers.back();
+    HeadBlendArgs hb;
+    hb.src = layer_source((int)spec.layers.size() - 1, image); hb.c_in = head.cin; hb.k = head.cout;
+    const bool fuse_head = !training && head.k == 1 && head.has_bias && head.in_a >= 0 && head_blend_supported(hb);
+    if (fuse_head) {
+        ++prof.pass_index;
+        plan_dims(1, win.height, win.width);
+        for (size_t li = 0; li + 1 < spec.layers.size(); ++li) run_conv_forward((int)li, image, false, nullptr);
+    } else {
+        tile_out.reserve((size_t)K * win.height * win.width * 4);
+        forward_inference(image, 1, win.height, win.width, tile_out.as<float>());
+    }
     BlendArgs b;
-    b.logits_nchw = tile_out.as<float>(); b.blended = d_blended;
+    b.logits_nchw = fuse_head ? nullptr : tile_out.as<float>(); b.blended = d_blended;
     b.k = K; b.tile_h = win.height; b.tile_w = win.width; b.tile_left = win.left; b.tile_top = win.top;
     b.img_h = H; b.img_w = W;
     b.full[0] = t.full_rect.left; b.full[1] = t.full_rect.top; b.full[2] = t.full_rect.right; b.full[3] = t.full_rect.bottom;
     b.unique[0] = t.unique_rect.left; b.unique[1] = t.unique_rect.top; b.unique[2] = t.unique_rect.right; b.unique[3] = t.unique_rect.bottom;
+    if (fuse_head) {
+        hb.src = layer_source((int)spec.layers.size() - 1, image);   // (scale/shift pointers are stable; the tensors were just written)
+        hb.w_tm = w_tm_f32.as<float>() + head.w_off; hb.bias = master.as<float>() + head.b_off;
+        hb.blend = b;
+        const int tok = prof.begin(stream, "head_blend_fused", 2.0 * head.cin * head.cout * (double)win.height * win.width,
+                                   (double)win.height * win.width * (head.cin * 2.0 + K * 8.0));
+        launch_head_blend(hb, stream);
+        prof.end(stream, tok);
+        return;
+    }
     const int tok = prof.begin(stream, "blend_accumulate", 0, (double)K * win.height * win.width * 12);
     launch_blend(b, stream);
     prof.end(stream, tok);

@@ -169,6 +169,15 @@ struct BlendArgs {
     long full[4] = {0, 0, 0, 0}, unique[4] = {0, 0, 0, 0};  // l,t,r,b
 };
 void launch_blend(const BlendArgs& a, hipStream_t s);
+// bf16 inference: the 1x1 head (32 -> K <= 4 channels, bias) and the blend in one pass over the last hidden tensor — the tile's
+// logits never go to memory.  BlendArgs::logits_nchw is unused.  head_blend_supported() decides.
+struct HeadBlendArgs {
+    Src src; int c_in = 0, k = 0;
+    const float* w_tm = nullptr; const float* bias = nullptr;   // [ci][k] (bf16-rounded values), [k]
+    BlendArgs blend;
+};
+bool head_blend_supported(const HeadBlendArgs& a);
+void launch_head_blend(const HeadBlendArgs& a, hipStream_t s);
 void launch_argmax(const float* blended, int k, int64_t pixels, const double* gains_or_null, uint16_t* labels, hipStream_t s);
 void launch_argmax_range(const float* blended, int k, int64_t pixels, int64_t p0, int64_t p1, const double* gains_or_null, uint16_t* labels, hipStream_t s);
 

@@ -1096,6 +1096,72 @@ __global__ __launch_bounds__(256) void blend_kernel(BlendArgs a) {
     }
 }
 
+// head_blend (bf16 inference): logits = relu(bn(y)) . W + b for one tile pixel, blended straight into the resident planes.
+// Four lanes share a pixel (8 channels = one 16-byte chunk each; a wave reads 1 KiB of contiguous NHWC per instruction) and
+// combine their partial logits with two xor-shuffles, as head_train does; lane `sub` then blends class `sub`.
+template <int KIND>
+__global__ __launch_bounds__(256) void head_blend_kernel(HeadBlendArgs a) {
+    constexpr int C = kHeadC, KM = kHeadKMax;
+    const int K = a.k;
+    const int sub = threadIdx.x & 3, c0 = sub * 8;
+    const BlendArgs& b = a.blend;
+    float w[8][KM], bias[KM], sa[8], ta[8], sb[8], tb[8];
+#pragma unroll
+    for (int k = 0; k < KM; ++k) {
+        bias[k] = k < K ? a.bias[k] : 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) w[c][k] = k < K ? a.w_tm[(c0 + c) * K + k] : 0.f;
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        sa[c] = a.src.a_scale[c0 + c]; ta[c] = a.src.a_shift[c0 + c];
+        sb[c] = KIND == SRC_ACT2 ? a.src.b_scale[c0 + c] : 0.f; tb[c] = KIND == SRC_ACT2 ? a.src.b_shift[c0 + c] : 0.f;
+    }
+    const bf16* xa = reinterpret_cast<const bf16*>(a.src.a);
+    const bf16* xb = reinterpret_cast<const bf16*>(a.src.b);
+    const int64_t pixels = (int64_t)b.tile_h * b.tile_w;
+    const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 2;
+    for (int64_t p = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2; p < pixels; p += stride) {
+        float x[8];
+        load8<bf16>(xa + (size_t)p * C + c0, x);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) x[c] = relu_affine(x[c], sa[c], ta[c]);
+        if (KIND == SRC_ACT2) {
+            float u[8];
+            load8<bf16>(xb + (size_t)p * C + c0, u);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) x[c] += relu_affine(u[c], sb[c], tb[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) x[c] = operand_round<bf16>(x[c]);
+        float z[KM];
+#pragma unroll
+        for (int k = 0; k < KM; ++k) {
+            float acc = 0.f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc = fmaf(x[c], w[c][k], acc);
+            acc += __shfl_xor(acc, 1, 64);
+            acc += __shfl_xor(acc, 2, 64);
+            z[k] = acc + bias[k];
+        }
+        // blend (annonet_infer.cpp:116-164): lane `sub` owns class `sub`
+        const int y = (int)(p / b.tile_w), xx = (int)(p - (int64_t)y * b.tile_w);
+        const long long bx = (long long)b.tile_left + xx, by = (long long)b.tile_top + y;
+        if (sub >= K || by < b.full[1] || by > b.full[3] || by < 0 || by >= b.img_h || bx < b.full[0] || bx > b.full[2] || bx < 0 || bx >= b.img_w) continue;
+        float in = z[0];
+#pragma unroll
+        for (int k = 1; k < KM; ++k) in = sub == k ? z[k] : in;
+        float* out = b.blended + ((size_t)sub * b.img_h + by) * b.img_w + bx;
+        const bool inside_unique = bx >= b.unique[0] && bx <= b.unique[2] && by >= b.unique[1] && by <= b.unique[3];
+        if (inside_unique) *out = in;
+        else {
+            const double th = ramp(bx, b.full[0], b.unique[0], b.unique[2], b.full[2]);
+            const double tv = ramp(by, b.full[1], b.unique[1], b.unique[3], b.full[3]);
+            *out = (float)__dadd_rn((double)*out, __dmul_rn(__dmul_rn(th, tv), (double)in));  // float += double * float
+        }
+    }
+}
+
 // find_label (annonet_infer.cpp:170-185): strict '>' from -inf, start label 65535, gain added in double
 __global__ __launch_bounds__(256) void argmax_kernel(const float* blended, int k, int64_t pixels, int64_t p0, int64_t p1, const double* gains, uint16_t* labels) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -1429,6 +1495,20 @@ void launch_sgd(const SgdArgs& a, hipStream_t s) {
 
 void launch_tm_to_canonical(const ParamSegment* segments, int n_segments, int64_t n_params, const float* tm, float* canonical, hipStream_t s) {
     hipLaunchKernelGGL(tm_to_canonical_kernel, dim3((unsigned)((n_params + 255) / 256)), dim3(256), 0, s, segments, n_segments, n_params, tm, canonical);
+    HIP_CHECK(hipGetLastError());
+}
+
+bool head_blend_supported(const HeadBlendArgs& a) {
+    static const bool on = !(getenv("ANH_FUSE_HEAD_BLEND") && atoi(getenv("ANH_FUSE_HEAD_BLEND")) == 0);
+    return on && a.c_in == kHeadC && a.k >= 1 && a.k <= kHeadKMax && a.src.dtype == DT_BF16 && (a.src.kind == SRC_ACT || a.src.kind == SRC_ACT2);
+}
+void launch_head_blend(const HeadBlendArgs& a, hipStream_t s) {
+    ANH_REQUIRE(head_blend_supported(a), "head_blend: unsupported shape");
+    const int64_t pixels = (int64_t)a.blend.tile_h * a.blend.tile_w;
+    if (pixels <= 0) return;
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((pixels * 4 + 255) / 256, 4096));
+    if (a.src.kind == SRC_ACT) hipLaunchKernelGGL(head_blend_kernel<SRC_ACT>, dim3(blocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(head_blend_kernel<SRC_ACT2>, dim3(blocks), dim3(256), 0, s, a);
     HIP_CHECK(hipGetLastError());
 }
 

@@ -244,6 +244,28 @@ def test_bf16_forward(levels, scaler, minf):
     assert mism.mean() <= 0.03 and ((srt[:, -1] - srt[:, -2])[mism] <= 2 * tol).all()  # only near-ties may flip
 
 
+def test_bf16_tiled_inference_full_width_net():
+    """bf16 annonet_infer() on the full-width net (32-channel last hidden layer): the 1x1 head and the blend run as ONE kernel
+    (head_blend); blended planes against the bf16-restating oracle, tiles small enough to exercise ramps and ragged edges."""
+    o, net = pair(2, 3, 3, 1.0, 1, aa.ANH_BF16, seed=21)
+    rng = np.random.default_rng(12)
+    H, W = 210, 173
+    img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    ov = o.required_input_dim()
+    tp = aa.tiling.parameters(96, 128, ov, ov)
+    labels, blended = aa.annonet_infer(net, img, tiling_parameters=tp, want_blended=True)
+    streamed = aa.annonet_infer(net, img, tiling_parameters=tp)           # the streamed host path (no planes requested)
+    np.testing.assert_array_equal(streamed, labels)
+    o.set_bf16_emulation(True)
+    want_labels, want = o.infer(img, max_tile=(96, 128), overlap=ov, want_blended=True)
+    span = want.max() - want.min()
+    # the worst pixel is one bf16 rounding flip in the last hidden layer times a large head weight (identical with the
+    # unfused head, ANH_FUSE_HEAD_BLEND=0): 4.5e-3 of the span here; the mean bar is the tight one
+    assert np.abs(blended - want).max() <= 6e-3 * span, (np.abs(blended - want).max(), span)
+    assert np.abs(blended - want).mean() <= 2e-4 * span
+    assert (labels != want_labels).mean() <= 2e-3
+
+
 @pytest.mark.parametrize("levels,scaler,minf,in_ch", [(2, 1.0, 1, 3), (1, 0.25, 4, 3), (3, 0.5, 1, 3), (2, 0.1, 5, 3), (1, 1.0, 1, 1), (3, 1.0, 1, 3)])
 def test_bf16_training_step(levels, scaler, minf, in_ch):
     o, t = trainer_pair(levels, in_ch, 3, scaler, minf, aa.ANH_BF16)   # in_ch = 1: the grayscale build variant
