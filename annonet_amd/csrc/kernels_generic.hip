@@ -816,10 +816,12 @@ struct HeadArgs {
 
 // Four lanes share a pixel: lane `sub` owns channels 8*sub..8*sub+7 (one 16-byte chunk), so a wave reads / writes 1 KiB
 // of contiguous NHWC per instruction; the K partial logits are combined with two xor-shuffles.
-template <typename T, int KIND>
-__global__ __launch_bounds__(256) void head_train_kernel(HeadArgs a) {
-    constexpr int C = kHeadC, KM = kHeadKMax;
-    const int K = a.k;
+// KM = register slots per class dimension.  2, 3 and 4 classes get exact instantiations (K = KM known at compile time: no
+// per-class predicates, no dead slots); a one-class net runs the two-slot body with K at run time.
+template <typename T, int KIND, int KM, bool EXACT>
+__global__ __launch_bounds__(256, 2) void head_train_kernel(HeadArgs a) {
+    constexpr int C = kHeadC;
+    const int K = EXACT ? KM : a.k;
     const int sub = threadIdx.x & 3, c0 = sub * 8;
     // w_tm[ci][k] and w_km[k][ci] are two layouts of the same filter: one register copy serves forward and backward-data
     float w[8][KM], bias[KM], sa[8], ta[8], sb[8], tb[8];
@@ -835,12 +837,12 @@ __global__ __launch_bounds__(256) void head_train_kernel(HeadArgs a) {
         sb[c] = KIND == SRC_ACT2 ? a.src.b_scale[c0 + c] : 0.f; tb[c] = KIND == SRC_ACT2 ? a.src.b_shift[c0 + c] : 0.f;
     }
     const bool bnred = KIND == SRC_ACT && a.bn_partials != nullptr;
-    float bm[8], bis[8], sg[8], sb2[8];   // bn backward sums of the input layer: sg = sum dz*xhat, sb2 = sum dz
+    // bn backward sums of the input layer.  The loop keeps sg = sum dz*y and sb2 = sum dz; the workgroup's partial of
+    // sum dz*xhat = invstd * (sum dz*y - mean * sum dz) is formed once, in double, after the folds (8 fewer VALU per
+    // pixel and 16 fewer registers than carrying mean / invstd through the loop).
+    float sg[8], sb2[8];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        bm[c] = bnred ? a.bn_mean[c0 + c] : 0.f; bis[c] = bnred ? a.bn_invstd[c0 + c] : 0.f;
-        sg[c] = 0.f; sb2[c] = 0.f;
-    }
+    for (int c = 0; c < 8; ++c) { sg[c] = 0.f; sb2[c] = 0.f; }
     float dw[8][KM], db[KM];
 #pragma unroll
     for (int k = 0; k < KM; ++k) {
@@ -932,7 +934,7 @@ __global__ __launch_bounds__(256) void head_train_kernel(HeadArgs a) {
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 const float dz = pos[c] ? operand_round<T>(dx[c]) : 0.f;   // the STORED da, as bn_bwd_reduce would read it
-                sg[c] = fmaf(dz, (yraw[c] - bm[c]) * bis[c], sg[c]);
+                sg[c] = fmaf(dz, yraw[c], sg[c]);
                 sb2[c] += dz;
             }
         }
@@ -978,7 +980,9 @@ __global__ __launch_bounds__(256) void head_train_kernel(HeadArgs a) {
     __syncthreads();
     if (bnred && threadIdx.x < 2 * C) {
         const int ch = threadIdx.x >> 1, which = threadIdx.x & 1;
-        a.bn_partials[((size_t)ch * 2 + which) * gridDim.x + blockIdx.x] = ((redb[0][which][ch] + redb[1][which][ch]) + redb[2][which][ch]) + redb[3][which][ch];
+        const double sy = ((redb[0][0][ch] + redb[1][0][ch]) + redb[2][0][ch]) + redb[3][0][ch];
+        const double sd = ((redb[0][1][ch] + redb[1][1][ch]) + redb[2][1][ch]) + redb[3][1][ch];
+        a.bn_partials[((size_t)ch * 2 + which) * gridDim.x + blockIdx.x] = which ? sd : (double)a.bn_invstd[ch] * (sy - (double)a.bn_mean[ch] * sd);
     }
     const int slots = 1 + K + C * K;
     for (int sidx = threadIdx.x; sidx < slots; sidx += blockDim.x) {
@@ -1357,7 +1361,9 @@ void launch_reduce_partials(const float* partials, int splits, int64_t nw, float
 bool head_train_supported(const HeadTrainArgs& a) {
     return a.c_in == kHeadC && a.k >= 1 && a.k <= kHeadKMax && (a.src.kind == SRC_ACT || a.src.kind == SRC_ACT2);
 }
-int head_train_blocks(int64_t pixels) { return (int)std::max<int64_t>(1, std::min<int64_t>((pixels * 4 + 255) / 256, 2048)); }
+// 768 = 3 workgroups per CU (the two-class kernel fits 3 waves per SIMD): one resident round, so the per-workgroup
+// reduction tail (about 50 double wave-folds per thread) is paid once per CU slot and not once per 12 pixels.
+int head_train_blocks(int64_t pixels) { return (int)std::max<int64_t>(1, std::min<int64_t>((pixels * 4 + 255) / 256, 768)); }
 int64_t head_train_partial_doubles(const HeadTrainArgs& a) { return (int64_t)head_train_blocks(a.pixels) * (1 + a.k + kHeadC * a.k); }
 
 void launch_head_train(const HeadTrainArgs& t, hipStream_t s) {
@@ -1368,13 +1374,18 @@ void launch_head_train(const HeadTrainArgs& t, hipStream_t s) {
     a.bn_mean = t.bnred_mean; a.bn_invstd = t.bnred_invstd; a.bn_partials = t.src.kind == SRC_ACT ? t.bnred_partials : nullptr;
     const int blocks = head_train_blocks(t.pixels);
     const bool bf = t.src.dtype == DT_BF16;
-    if (t.src.kind == SRC_ACT) {
-        if (bf) hipLaunchKernelGGL((head_train_kernel<bf16, SRC_ACT>), dim3(blocks), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((head_train_kernel<float, SRC_ACT>), dim3(blocks), dim3(256), 0, s, a);
-    } else {
-        if (bf) hipLaunchKernelGGL((head_train_kernel<bf16, SRC_ACT2>), dim3(blocks), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((head_train_kernel<float, SRC_ACT2>), dim3(blocks), dim3(256), 0, s, a);
-    }
+    auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, s, a); };
+    auto pick = [&](auto tag_t, auto tag_kind) {
+        using T = decltype(tag_t); constexpr int KIND = decltype(tag_kind)::value;
+        switch (t.k) {
+            case 2: launch(head_train_kernel<T, KIND, 2, true>); break;
+            case 3: launch(head_train_kernel<T, KIND, 3, true>); break;
+            case 4: launch(head_train_kernel<T, KIND, 4, true>); break;
+            default: launch(head_train_kernel<T, KIND, 2, false>); break;   // one class: the two-slot body with a run-time count
+        }
+    };
+    if (t.src.kind == SRC_ACT) { if (bf) pick(bf16{}, std::integral_constant<int, SRC_ACT>{}); else pick(float{}, std::integral_constant<int, SRC_ACT>{}); }
+    else { if (bf) pick(bf16{}, std::integral_constant<int, SRC_ACT2>{}); else pick(float{}, std::integral_constant<int, SRC_ACT2>{}); }
     HIP_CHECK(hipGetLastError());
     const int slots = 1 + t.k + kHeadC * t.k;
     hipLaunchKernelGGL(head_finalize_kernel, dim3(slots), dim3(64), 0, s, t.partials, blocks, slots, t.k, t.loss_out, t.loss_out_f32, t.dbias, t.dw);

@@ -935,19 +935,24 @@ struct GeoS1 {
     template <int NT>
     __device__ static void mfma(f32x16 (&acc)[ACC][NT], const Bases& b, const char* (&wb)[2]) {
         constexpr int C_OUT = NT * 32;
+        // The two output rows of a wave and the three filter rows touch patch rows 0..3: for each (kx, k-step) those four
+        // pixel fragments are read ONCE and reused by the three ky (10 LDS reads per 12 MFMAs at NT = 2, instead of 12).
 #pragma unroll
-        for (int tl = 0; tl < 9; ++tl) {
-            const int ky = tl / 3, kx = tl - ky * 3;
+        for (int kx = 0; kx < 3; ++kx) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 xf[2];
+                bf16x8 xf[4];
 #pragma unroll
-                for (int g = 0; g < 2; ++g) xf[g] = lds_frag(b.x[kx][ks] + (g + ky) * (PW * 64));
+                for (int r = 0; r < 4; ++r) xf[r] = lds_frag(b.x[kx][ks] + r * (PW * 64));
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const bf16x8 wf = lds_frag(wb[ks] + (tl * C_OUT + nt * 32) * 64);
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int tl = ky * 3 + kx;
 #pragma unroll
-                    for (int g = 0; g < 2; ++g) acc[g][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf[g], acc[g][nt], 0, 0, 0);
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const bf16x8 wf = lds_frag(wb[ks] + (tl * C_OUT + nt * 32) * 64);
+#pragma unroll
+                        for (int g = 0; g < 2; ++g) acc[g][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf[g + ky], acc[g][nt], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -1218,6 +1223,33 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
         f32x16 acc[G::ACC][NT];
         u32x4 old[G::ACC][NT][2];   // prefetched old values of a read-modify-write destination (GeoUp)
         u32x4 yraw[G::ACC][NT][2];  // prefetched raw outputs y of the layer whose da is written (fused bn backward reduction)
+        // The 32-channel read-modify-write kernel (GeoUp, NT = 1: HBM-bound, short MFMA phase) keeps the old values a whole
+        // tile ahead: those of tile t + 1 are requested while tile t runs, so their latency is covered by a full item and
+        // not by the MFMA phase alone (measured: 133 -> 120 us on the 32x64 stride-2 backward-data; the same depth for the
+        // y operand of the stride-1 kernels measured slower, 93 -> 105 us, and is not compiled).
+        constexpr bool DEEP = NT == 1 && G::RMW_PREFETCH, DEEP_Y = false;
+        u32x4 old_n[DEEP ? G::ACC : 1][NT][2], yraw_n[DEEP_Y ? G::ACC : 1][NT][2];
+        const bool rmw_any = G::RMW_PREFETCH && a.out_accumulate;
+        const bool pre_any = rmw_any || fuse_bnred;
+        auto prefetch_epilogue = [&](int t, auto& o, auto& y, bool want_old, bool want_y) __attribute__((always_inline)) {
+            const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, n = t / (tiles_x * tiles_y);
+            const bf16* out = reinterpret_cast<const bf16*>(a.out);
+            const bf16* yl = reinterpret_cast<const bf16*>(a.bnred_y);
+#pragma unroll
+            for (int g = 0; g < G::ACC; ++g) {
+                size_t pix; bool valid;
+                G::out_pixel(g, a, n, ty, tx, wave, col, pix, valid);
+                const size_t e0 = pix * a.c_out + co_base + 8 * half;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        if (want_old) o[g][nt][s2] = *reinterpret_cast<const u32x4*>(out + e0 + nt * 32 + 16 * s2);
+                        if (want_y) y[g][nt][s2] = *reinterpret_cast<const u32x4*>(yl + e0 + nt * 32 + 16 * s2);
+                    }
+            }
+        };
+        if (DEEP && pre_any && tile < n_tiles) prefetch_epilogue(tile, old, yraw, rmw_any, fuse_bnred && DEEP_Y);
         float stat[NT][2][16];      // per-lane running sums of this lane's 8 channels per (nt, s): see store_pixel_tiles_rmw
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
@@ -1249,23 +1281,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
             TICK();
             const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
             const bool last_slab = slab == n_slabs - 1;
-            const bool rmw = G::RMW_PREFETCH && a.out_accumulate && last_slab;
-            if ((rmw || (fuse_bnred && last_slab))) {  // epilogue operands travel while the MFMAs run
-                const bf16* out = reinterpret_cast<const bf16*>(a.out);
-                const bf16* yl = reinterpret_cast<const bf16*>(a.bnred_y);
-#pragma unroll
-                for (int g = 0; g < G::ACC; ++g) {
-                    size_t pix; bool valid;
-                    G::out_pixel(g, a, n, ty, tx, wave, col, pix, valid);
-                    const size_t e0 = pix * a.c_out + co_base + 8 * half;
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                        for (int s2 = 0; s2 < 2; ++s2) {
-                            if (rmw) old[g][nt][s2] = *reinterpret_cast<const u32x4*>(out + e0 + nt * 32 + 16 * s2);
-                            if (fuse_bnred) yraw[g][nt][s2] = *reinterpret_cast<const u32x4*>(yl + e0 + nt * 32 + 16 * s2);
-                        }
-                }
+            const bool rmw = rmw_any && last_slab;
+            if (pre_any && last_slab) {  // epilogue operands travel while the MFMAs run
+                if constexpr (DEEP) {
+                    if (tile + (int)gridDim.x < n_tiles) prefetch_epilogue(tile + (int)gridDim.x, old_n, yraw_n, rmw_any, fuse_bnred && DEEP_Y);
+                    if constexpr (!DEEP_Y) prefetch_epilogue(tile, old, yraw, false, fuse_bnred);
+                } else prefetch_epilogue(tile, old, yraw, rmw_any, fuse_bnred);
             }
             G::template mfma<NT>(acc, b, wb);
 #ifdef ANH_WS_PROFILE
@@ -1279,6 +1300,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
                     size_t pix; bool valid;
                     G::out_pixel(g, a, n, ty, tx, wave, col, pix, valid);
                     store_pixel_tiles_rmw<NT>(acc[g], a, pix, valid, half, co_base, old[g], rmw, stat, stat_mode, yraw[g], bnc);
+                }
+                if constexpr (DEEP) {
+                    if (pre_any) {
+#pragma unroll
+                        for (int g = 0; g < G::ACC; ++g)
+#pragma unroll
+                            for (int s2 = 0; s2 < 2; ++s2) {
+                                old[g][0][s2] = old_n[g][0][s2];
+                                if constexpr (DEEP_Y) yraw[g][0][s2] = yraw_n[g][0][s2];
+                            }
+                    }
                 }
             }
             TOCK(t_b);
