@@ -115,13 +115,13 @@ class Engine {
     void fold_running_stats();  // inference: scale/shift from running stats, computed on the host
     void ensure_training_buffers();
     void conv_dispatch(const ConvArgs& a, const char* tag, double flops, double bytes);
-    void wgrad_dispatch(WgradArgs& a, const char* tag, double flops, double bytes, hipStream_t on);
+    void wgrad_dispatch(WgradArgs& a, const char* tag, double flops, double bytes, hipStream_t on, DevBuf& scratch);
 
     std::vector<LayerState> ls;
     std::vector<ParamSegment> segments_host;
     DevBuf segments;
     DevBuf master, momentum, grad, w_tm_f32, w_km_f32, w_tm_bf16, w_km_bf16, running;
-    DevBuf bn_partials, wgrad_partials, loss_partials, coef, logits, dlogits, scalars, gains_dev, tile_out;
+    DevBuf bn_partials, wgrad_partials, wgrad_partials_main, loss_partials, coef, logits, dlogits, scalars, gains_dev, tile_out;
     double* loss_dev = nullptr;
     int* error_flag = nullptr;
     std::vector<float> host_params, host_running;  // mirror kept for inference folding / serialization

@@ -298,12 +298,12 @@ void Engine::conv_dispatch(const ConvArgs& a, const char* tag, double flops, dou
     prof.end(stream, tok);
 }
 
-void Engine::wgrad_dispatch(WgradArgs& a, const char* tag, double flops, double bytes, hipStream_t on) {
+void Engine::wgrad_dispatch(WgradArgs& a, const char* tag, double flops, double bytes, hipStream_t on, DevBuf& scratch) {
     const bool fast = wgrad_takes_mfma(a, dtype);
     const int64_t need = fast ? wgrad_mfma_scratch_floats(a) : wgrad_generic_scratch_floats(a);
-    wgrad_partials.reserve((size_t)need * 4);
-    a.partials = wgrad_partials.as<float>();
-    a.partials_capacity = (int64_t)(wgrad_partials.bytes / 4);
+    scratch.reserve((size_t)need * 4);
+    a.partials = scratch.as<float>();
+    a.partials_capacity = (int64_t)(scratch.bytes / 4);
     std::string name = std::string(fast ? "wgrad_mfma_bf16:" : (dtype == DT_BF16 ? "wgrad_generic_bf16:" : "wgrad_generic_f32:")) + tag;
     int splits = 0;
     a.splits_out = &splits;
@@ -556,14 +556,19 @@ void Engine::backward(const uint16_t* d_labels, const float* d_weights, double l
             }
             const double bytes = (double)p_in * L.cin * (L.in_a < 0 ? 1.0 : es) * (L.in_b >= 0 ? 2 : 1) + (double)p_out * L.cout * (L.has_bn ? es : 4.0) * (wgrad_computes_dy ? 2 : 1);
             hipStream_t on = stream;
-            if (two_streams) {
+            // A layer without backward-data conv (the stem, last in this loop) leaves the main stream with nothing else to
+            // do: its filter gradient runs THERE, beside the previous layer's filter gradient still on the second stream
+            // (own partials buffer), instead of queueing behind it.
+            static const bool tail_on_main = getenv("ANH_STEM_WGRAD_MAIN") ? atoi(getenv("ANH_STEM_WGRAD_MAIN")) != 0 : true;
+            const bool on_main = two_streams && !has_dgrad && tail_on_main;
+            if (two_streams && !on_main) {
                 if (!fused_apply) {   // dy of this layer is final on the main stream: let the second stream pick it up
                     HIP_CHECK(hipEventRecord(ev_dy_ready, stream));
                     HIP_CHECK(hipStreamWaitEvent(aux_stream, ev_dy_ready, 0));
                 }
                 on = aux_stream;
             }
-            wgrad_dispatch(g, (std::string("wgrad_") + layer_tag(L)).c_str(), flops, bytes, on);
+            wgrad_dispatch(g, (std::string("wgrad_") + layer_tag(L)).c_str(), flops, bytes, on, on_main ? wgrad_partials_main : wgrad_partials);
         }
         if (has_dgrad) {   // data gradient -> d(activation of the producing layers)
             LayerState& P = ls[L.in_a];
