@@ -537,6 +537,10 @@ __global__ __launch_bounds__(64) void bn_finalize_kernel(const double* partials,
                                                          float eps, float* mean, float* invstd, float* scale, float* shift, double* var_out,
                                                          float* rmean, float* rvar, double af, double unbias) {
     const int ch = blockIdx.x;
+    // this kernel is one dependent chain on the critical path of every layer: the scalar operands of its tail are
+    // requested up front, so the chain holds ONE memory round trip (the partials) and not two
+    const float gm = gamma[ch], bt = beta[ch];
+    const float rm0 = rmean ? rmean[ch] : 0.f, rv0 = rmean ? rvar[ch] : 0.f;
     double s = 0, q = 0;
     const double* ps = partials + (size_t)ch * 2 * blocks;  // [channel][sum | sum of squares][workgroup]: contiguous per channel
 #pragma unroll 8
@@ -548,12 +552,12 @@ __global__ __launch_bounds__(64) void bn_finalize_kernel(const double* partials,
     if (var < 0) var = 0;
     const float mf = (float)m;
     const float is = (float)(1.0 / sqrt(var + (double)eps));
-    const float sc = gamma[ch] * is;
-    mean[ch] = mf; invstd[ch] = is; scale[ch] = sc; shift[ch] = fmaf(-mf, sc, beta[ch]);
+    const float sc = gm * is;
+    mean[ch] = mf; invstd[ch] = is; scale[ch] = sc; shift[ch] = fmaf(-mf, sc, bt);
     var_out[ch] = var;
     if (rmean) {  // dlib bn_ updates its running statistics in the training forward
-        rmean[ch] = (float)((1.0 - af) * (double)rmean[ch] + af * (double)mf);
-        rvar[ch] = (float)((1.0 - af) * (double)rvar[ch] + af * unbias * var);
+        rmean[ch] = (float)((1.0 - af) * (double)rm0 + af * (double)mf);
+        rvar[ch] = (float)((1.0 - af) * (double)rv0 + af * unbias * var);
     }
 }
 
@@ -597,6 +601,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* da, const T
 __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const double* partials, int blocks, int64_t pixels, int c, const float* gamma, const float* invstd,
                                                              float* dgamma, float* dbeta, float* coef) {
     const int ch = blockIdx.x;
+    const float gi = gamma[ch] * invstd[ch];   // requested before the partials (see bn_finalize_kernel)
     double g = 0, b = 0;
     const double* ps = partials + (size_t)ch * 2 * blocks;
 #pragma unroll 8
@@ -604,7 +609,7 @@ __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const double* parti
     g = wave_sum(g); b = wave_sum(b);
     if (threadIdx.x != 0) return;
     dgamma[ch] = (float)g; dbeta[ch] = (float)b;
-    coef[ch] = gamma[ch] * invstd[ch];
+    coef[ch] = gi;
     coef[c + ch] = (float)(b / (double)pixels);
     coef[2 * c + ch] = (float)(g / (double)pixels);
 }
