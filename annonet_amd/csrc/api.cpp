@@ -790,6 +790,15 @@ int anh_random_rect_containing_point(uint32_t dx, uint32_t dy, long px, long py,
 int anh_outpaint(uint8_t* image, int nr, int nc, int channels, const anh_rect* inside) {
     return guarded([&] { ANH_REQUIRE(image && inside, "null argument"); outpaint(image, nr, nc, channels, *inside); });
 }
+int anh_ignore_large_nonzero_regions(uint16_t* labels, int nr, int nc, double by_area, double by_width, double by_height, int rf, int64_t* ignored) {
+    return guarded([&] {
+        ANH_REQUIRE(labels && nr > 0 && nc > 0 && rf > 0, "ignore_large_nonzero_regions: bad argument");
+        ANH_REQUIRE((int64_t)nr * nc < (int64_t)1 << 31, "ignore_large_nonzero_regions: image too large");
+        ANH_REQUIRE(!(by_area < 0) && !(by_width < 0) && !(by_height < 0), "ignore_large_nonzero_regions: negative threshold");
+        const int64_t n = ignore_large_nonzero_regions(labels, nr, nc, by_area, by_width, by_height, rf);
+        if (ignored) *ignored = n;
+    });
+}
 int64_t anh_count_steps_without_decrease(const double* values, int64_t n, double p) {
     if (!values && n > 0) return -1;
     return count_steps_without_decrease(values, n, p);

@@ -138,6 +138,47 @@ void outpaint(uint8_t* image, int nr, int nc, int channels, anh_rect in) {
     }
 }
 
+// ignore_large_nonzero_regions (annonet_train_main.cpp:434-502): 8-connected blobs of EQUAL label, background = label 0
+// or the ignore label (annonet.h:26-37); a blob whose pixel count exceeds by_area * rf^2, or whose bounding box is wider
+// than by_width * rf or taller than by_height * rf (rf = receptive-field side, GetRequiredInputDimension()), is relabelled
+// to the ignore label.  The reference's early returns (no annotations / background only / thresholds beyond the image,
+// :435-448) change nothing a blob test would not also leave alone, so they are not restated.  Returns the pixels ignored.
+int64_t ignore_large_nonzero_regions(uint16_t* labels, int nr, int nc, double by_area, double by_width, double by_height, int receptive_field_side) {
+    const double rf = (double)receptive_field_side;
+    const double max_points = by_area * rf * rf, max_width = by_width * rf, max_height = by_height * rf;
+    std::vector<uint8_t> seen((size_t)nr * nc, 0);
+    std::vector<int> stack, blob;
+    int64_t ignored = 0;
+    for (int r0 = 0; r0 < nr; ++r0)
+        for (int c0 = 0; c0 < nc; ++c0) {
+            const size_t i0 = (size_t)r0 * nc + c0;
+            const uint16_t label = labels[i0];
+            if (seen[i0] || label == 0 || label == ANH_LABEL_IGNORE) continue;
+            blob.clear(); stack.clear();
+            stack.push_back((int)i0); seen[i0] = 1;
+            int min_x = c0, max_x = c0, min_y = r0, max_y = r0;
+            while (!stack.empty()) {
+                const int i = stack.back(); stack.pop_back();
+                blob.push_back(i);
+                const int r = i / nc, c = i - r * nc;
+                min_x = std::min(min_x, c); max_x = std::max(max_x, c); min_y = std::min(min_y, r); max_y = std::max(max_y, r);
+                for (int dr = -1; dr <= 1; ++dr)
+                    for (int dc = -1; dc <= 1; ++dc) {
+                        const int rr = r + dr, cc = c + dc;
+                        if ((dr == 0 && dc == 0) || rr < 0 || rr >= nr || cc < 0 || cc >= nc) continue;
+                        const size_t j = (size_t)rr * nc + cc;
+                        if (!seen[j] && labels[j] == label) { seen[j] = 1; stack.push_back((int)j); }
+                    }
+            }
+            const bool too_large = (double)blob.size() > max_points || (double)(max_x - min_x + 1) > max_width || (double)(max_y - min_y + 1) > max_height;
+            if (too_large) {
+                for (int i : blob) labels[i] = ANH_LABEL_IGNORE;
+                ignored += (int64_t)blob.size();
+            }
+        }
+    return ignored;
+}
+
 // dlib count_steps_without_decrease [UPSTREAM-UNVERIFIED]: walk the history from newest to oldest, keep a least-squares
 // line through what has been seen, and remember the longest suffix for which "the loss is going down" is not
 // more likely than probability_of_decrease.

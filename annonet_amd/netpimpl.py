@@ -83,6 +83,14 @@ def outpaint(img, inside):
     return img
 
 
+def ignore_large_nonzero_regions(label_image, receptive_field_side, by_area=float("inf"), by_width=float("inf"), by_height=float("inf")):
+    """annonet_train_main.cpp:434-502: returns (label image with the too-large blobs set to LABEL_IGNORE, pixels ignored)."""
+    lab = np.ascontiguousarray(label_image, dtype=np.uint16).copy()
+    n = C.c_int64(0)
+    check(_lib.lib().anh_ignore_large_nonzero_regions(_ptr(lab), lab.shape[0], lab.shape[1], by_area, by_width, by_height, receptive_field_side, C.byref(n)))
+    return lab, n.value
+
+
 def count_steps_without_decrease(values, probability_of_decrease=0.51):
     v = np.ascontiguousarray(values, dtype=np.float64)
     return _lib.lib().anh_count_steps_without_decrease(_ptr(v), v.size, probability_of_decrease)

@@ -214,6 +214,11 @@ int anh_set_weights(const uint16_t* labels, int nr, int nc, double class_weight,
 int anh_random_rect_containing_point(uint32_t draw_x, uint32_t draw_y, long px, long py, long width, long height, anh_rect* out);
 /* outpaint() (annonet.h:74-120), in place on a u8 image with `channels` interleaved channels */
 int anh_outpaint(uint8_t* image, int nr, int nc, int channels, const anh_rect* inside);
+/* ignore_large_nonzero_regions (annonet_train_main.cpp:434-502), in place on a u16 label image: 8-connected blobs of equal
+   non-zero, non-ignored label larger than by_area * rf^2 pixels, wider than by_width * rf or taller than by_height * rf
+   become ANH_LABEL_IGNORE (infinity = that test off, as the CLI defaults :339-341).  *ignored = pixels relabelled. */
+int anh_ignore_large_nonzero_regions(uint16_t* labels, int nr, int nc, double by_area, double by_width, double by_height,
+                                     int receptive_field_side, int64_t* ignored);
 /* dlib count_steps_without_decrease, used by the learning-rate schedule */
 int64_t anh_count_steps_without_decrease(const double* values, int64_t n, double probability_of_decrease);
 

@@ -240,6 +240,28 @@ def get_tiles(width, height, max_w, max_h, ov_x, ov_y):
     return [(tuple(arr[i].full), tuple(arr[i].unique)) for i in range(n)]
 
 
+def ignore_large_nonzero_regions(labels, receptive_field_side, by_area=np.inf, by_width=np.inf, by_height=np.inf):
+    """annonet_train_main.cpp:434-502 restated with scipy.ndimage (per label value, 8-connectivity): blobs of equal label
+    (background = 0 or 65535, annonet.h:26-37) with more than by_area*rf^2 pixels, wider than by_width*rf or taller than
+    by_height*rf become 65535.  Returns (labels, pixels ignored)."""
+    from scipy import ndimage
+    lab = np.array(labels, dtype=np.uint16)
+    rf = float(receptive_field_side)
+    ignored = 0
+    for value in np.unique(lab):
+        if value == 0 or value == 65535:
+            continue
+        blobs, n = ndimage.label(lab == value, structure=np.ones((3, 3), dtype=int))
+        for b, sl in enumerate(ndimage.find_objects(blobs), start=1):
+            mask = blobs[sl] == b
+            count = int(mask.sum())
+            height, width = sl[0].stop - sl[0].start, sl[1].stop - sl[1].start
+            if count > by_area * rf * rf or width > by_width * rf or height > by_height * rf:
+                lab[sl][mask] = 65535
+                ignored += count
+    return lab, ignored
+
+
 def count_steps_without_decrease(values, probability_of_decrease=0.51):
     v = np.ascontiguousarray(values, dtype=np.float64)
     return lib().orc_count_steps_without_decrease(_p(v), v.size, probability_of_decrease)

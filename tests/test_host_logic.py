@@ -114,6 +114,56 @@ def test_outpaint_matches_oracle():
         np.testing.assert_array_equal(aa.outpaint(img, inside), orc.outpaint(img, inside))
 
 
+def test_ignore_large_nonzero_regions_hand_cases():
+    """annonet_train_main.cpp:434-502 on blobs whose fate can be read off the picture (rf = 4: area bar 16*by_area)."""
+    lab = np.zeros((12, 16), np.uint16)
+    lab[1:4, 1:9] = 2          # 3 x 8 = 24 pixels, width 8, height 3
+    lab[6:8, 2:4] = 1          # 2 x 2
+    lab[5:11, 12] = 3          # 1 x 6 column, height 6
+    lab[9, 5] = 2; lab[10, 6] = 2   # diagonal pair: ONE blob under 8-connectivity
+    lab[0, 15] = aa.LABEL_IGNORE
+    same, n = aa.ignore_large_nonzero_regions(lab, 4)                      # CLI defaults: every test off
+    assert n == 0 and (same == lab).all()
+    out, n = aa.ignore_large_nonzero_regions(lab, 4, by_width=1.5)         # wider than 6
+    assert n == 24 and (out[1:4, 1:9] == aa.LABEL_IGNORE).all() and (out[6:8, 2:4] == 1).all() and (out[5:11, 12] == 3).all()
+    out, n = aa.ignore_large_nonzero_regions(lab, 4, by_height=1.25)       # taller than 5
+    assert n == 6 and (out[5:11, 12] == aa.LABEL_IGNORE).all() and (out[1:4, 1:9] == 2).all()
+    out, n = aa.ignore_large_nonzero_regions(lab, 4, by_area=0.25)         # more than 4 pixels
+    assert n == 30 and (out[6:8, 2:4] == 1).all() and out[9, 5] == 2 and out[10, 6] == 2
+    out, n = aa.ignore_large_nonzero_regions(lab, 4, by_area=1.0 / 16)     # more than 1 pixel: the diagonal pair goes as one blob
+    assert out[9, 5] == aa.LABEL_IGNORE and out[10, 6] == aa.LABEL_IGNORE and n == 24 + 4 + 6 + 2
+    # equal-size is kept (strict '>'), and touching blobs of DIFFERENT labels stay separate
+    lab2 = np.zeros((4, 8), np.uint16); lab2[:, :4] = 1; lab2[:, 4:] = 2
+    out, n = aa.ignore_large_nonzero_regions(lab2, 4, by_area=1.0, by_width=1.0, by_height=1.0)
+    assert n == 0
+    out, n = aa.ignore_large_nonzero_regions(lab2, 4, by_width=0.75)
+    assert n == 32
+
+
+def test_ignore_large_nonzero_regions_matches_oracle():
+    rng = np.random.default_rng(8)
+    for case in range(30):
+        nr, nc = (int(v) for v in rng.integers(1, 60, 2))
+        # blobby label images: a coarse random field upsampled, a few classes, some ignored pixels
+        coarse = rng.integers(0, 4, ((nr + 4) // 5 + 1, (nc + 4) // 5 + 1))
+        lab = np.kron(coarse, np.ones((5, 5), dtype=np.int64))[:nr, :nc].astype(np.uint16)
+        lab[rng.random((nr, nc)) < 0.05] = aa.LABEL_IGNORE
+        lab[rng.random((nr, nc)) < 0.05] = 0
+        rf = int(rng.integers(3, 12))
+        a, w, h = (float(v) if rng.random() < 0.7 else float("inf") for v in rng.uniform(0.2, 3.0, 3))
+        got, n = aa.ignore_large_nonzero_regions(lab, rf, by_area=a, by_width=w, by_height=h)
+        want, wn = orc.ignore_large_nonzero_regions(lab, rf, by_area=a, by_width=w, by_height=h)
+        np.testing.assert_array_equal(got, want)
+        assert n == wn
+        assert ((got == lab) | (got == aa.LABEL_IGNORE)).all()       # pixels are only ever relabelled to "ignore"
+        again, n2 = aa.ignore_large_nonzero_regions(got, rf, by_area=a, by_width=w, by_height=h)
+        assert n2 == 0 and (again == got).all()                       # idempotent
+    with pytest.raises(aa.AnnonetHipError):
+        aa.ignore_large_nonzero_regions(np.zeros((3, 3), np.uint16), 0)
+    with pytest.raises(aa.AnnonetHipError):
+        aa.ignore_large_nonzero_regions(np.zeros((3, 3), np.uint16), 4, by_area=-1.0)
+
+
 def test_count_steps_without_decrease():
     rng = np.random.default_rng(3)
     down = np.linspace(2.0, 1.0, 300) + rng.normal(0, 0.01, 300)
