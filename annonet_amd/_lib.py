@@ -151,6 +151,9 @@ _SIGNATURES = {  # ConvDesc / OpInput are defined above
     "anh_set_weights": (C.c_int, [_P, C.c_int, C.c_int, C.c_double, C.c_double, _P]),
     "anh_random_rect_containing_point": (C.c_int, [C.c_uint32, C.c_uint32, C.c_long, C.c_long, C.c_long, C.c_long, C.POINTER(Rect)]),
     "anh_outpaint": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(Rect)]),
+    "anh_dnn_envelope_pack": (C.c_int, [C.c_char_p, C.c_size_t, C.c_double, _P, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "anh_dnn_envelope_unpack": (C.c_int, [_P, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_double),
+                                          C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "anh_ignore_large_nonzero_regions": (C.c_int, [_P, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.POINTER(C.c_int64)]),
     "anh_count_steps_without_decrease": (C.c_int64, [_P, C.c_int64, C.c_double]),
 }

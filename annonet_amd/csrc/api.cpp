@@ -799,6 +799,34 @@ int anh_ignore_large_nonzero_regions(uint16_t* labels, int nr, int nc, double by
         if (ignored) *ignored = n;
     });
 }
+static void* host_copy(const std::string& s) {
+    void* p = std::malloc(s.size() ? s.size() : 1);
+    if (!p) fail(ANH_ERR_OOM, "host allocation failed");
+    std::memcpy(p, s.data(), s.size());
+    return p;
+}
+int anh_dnn_envelope_pack(const char* classes_json, size_t json_size, double downscaling_factor, const void* net_blob, size_t net_size,
+                          void** file, size_t* file_size) {
+    return guarded([&] {
+        ANH_REQUIRE(file && file_size && (classes_json || json_size == 0) && (net_blob || net_size == 0), "null argument");
+        const std::string out = dnn_envelope_pack(std::string(classes_json ? classes_json : "", json_size), downscaling_factor,
+                                                  std::string(net_blob ? (const char*)net_blob : "", net_size));
+        *file = host_copy(out); *file_size = out.size();
+    });
+}
+int anh_dnn_envelope_unpack(const void* file, size_t file_size, char** classes_json, size_t* json_size, double* downscaling_factor,
+                            void** net_blob, size_t* net_size) {
+    return guarded([&] {
+        ANH_REQUIRE(file && classes_json && json_size && downscaling_factor && net_blob && net_size, "null argument");
+        std::string json, net;
+        double factor = 0;
+        dnn_envelope_unpack(std::string((const char*)file, file_size), json, factor, net);
+        void* j = host_copy(json);
+        void* n = nullptr;
+        try { n = host_copy(net); } catch (...) { std::free(j); throw; }
+        *classes_json = (char*)j; *json_size = json.size(); *downscaling_factor = factor; *net_blob = n; *net_size = net.size();
+    });
+}
 int64_t anh_count_steps_without_decrease(const double* values, int64_t n, double p) {
     if (!values && n > 0) return -1;
     return count_steps_without_decrease(values, n, p);

@@ -138,6 +138,85 @@ void outpaint(uint8_t* image, int nr, int nc, int channels, anh_rect in) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// annonet.dnn (annonet_train_main.cpp:557-565 writes, annonet_infer_main.cpp:340-351 reads):
+//     serialize("annonet.dnn") << anno_classes_json << downscaling_factor << serialized_runtime_net
+// i.e. dlib's stream serialization of (std::string, double, std::string), nothing else in the file.
+// dlib (github.com/reunanen/dlib, un-vendored submodule, no pinned SHA in the snapshot) is ABSENT: the framing below
+// restates dlib/serialize.h + dlib/float_details.h as published  [UPSTREAM-UNVERIFIED]:
+//   integer   : one control byte = number of value bytes that follow (1..8), bit 7 set for a negative value, then the
+//               magnitude, least-significant byte first, without leading zero bytes (zero = 01 00)
+//   string    : its length as an unsigned integer, then the raw bytes
+//   double    : (int64 mantissa, int16 exponent) as two integers with value = mantissa * 2^exponent; from frexp with
+//               53 digits, trailing zero BYTES of the mantissa shifted into the exponent (1.0 = mantissa 16, exponent -4);
+//               +inf / -inf / nan = mantissa 0 and exponent 32000 / 32001 / 32002
+// The third string is RuntimeNet::Serialize's opaque blob (anh_runtime_serialize here; dlib's net format there).
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+void put_int(std::string& out, long long v) {
+    unsigned char buf[9];
+    const bool neg = v < 0;
+    unsigned long long m = neg ? 0ull - (unsigned long long)v : (unsigned long long)v;
+    int n = 0;
+    do { buf[1 + n++] = (unsigned char)(m & 0xFF); m >>= 8; } while (m != 0 && n < 8);
+    buf[0] = (unsigned char)(n | (neg ? 0x80 : 0));
+    out.append(reinterpret_cast<const char*>(buf), (size_t)n + 1);
+}
+long long get_int(const std::string& in, size_t& pos, int max_bytes, const char* what) {
+    if (pos >= in.size()) fail(ANH_ERR_IO, std::string("annonet.dnn truncated while reading ") + what);
+    const unsigned char ctl = (unsigned char)in[pos++];
+    const int n = ctl & 0x0F;
+    if ((ctl & 0x70) != 0 || n < 1 || n > max_bytes) fail(ANH_ERR_IO, std::string("annonet.dnn: bad integer header in ") + what);
+    if (pos + (size_t)n > in.size()) fail(ANH_ERR_IO, std::string("annonet.dnn truncated while reading ") + what);
+    unsigned long long m = 0;
+    for (int i = n - 1; i >= 0; --i) m = (m << 8) | (unsigned char)in[pos + (size_t)i];
+    pos += (size_t)n;
+    return (ctl & 0x80) ? (long long)(0ull - m) : (long long)m;
+}
+void put_string(std::string& out, const std::string& s) { put_int(out, (long long)s.size()); out += s; }
+std::string get_string(const std::string& in, size_t& pos, const char* what) {
+    const long long n = get_int(in, pos, 8, what);
+    if (n < 0 || (unsigned long long)n > in.size() - pos) fail(ANH_ERR_IO, std::string("annonet.dnn truncated while reading ") + what);
+    std::string s = in.substr(pos, (size_t)n);
+    pos += (size_t)n;
+    return s;
+}
+void put_double(std::string& out, double v) {
+    long long mantissa = 0; int exponent = 0;
+    if (v == INFINITY) exponent = 32000;
+    else if (v == -INFINITY) exponent = 32001;
+    else if (v != v) exponent = 32002;
+    else {
+        int e;
+        mantissa = (long long)(std::frexp(v, &e) * 9007199254740992.0);   // 2^53
+        exponent = e - 53;
+        for (int i = 0; i < 8 && (mantissa & 0xFF) == 0; ++i) { mantissa >>= 8; exponent += 8; }
+    }
+    put_int(out, mantissa); put_int(out, exponent);
+}
+double get_double(const std::string& in, size_t& pos, const char* what) {
+    const long long mantissa = get_int(in, pos, 8, what);
+    const long long exponent = get_int(in, pos, 2, what);
+    if (exponent == 32000) return INFINITY;
+    if (exponent == 32001) return -INFINITY;
+    if (exponent == 32002) return NAN;
+    return std::ldexp((double)mantissa, (int)exponent);
+}
+}  // namespace
+
+std::string dnn_envelope_pack(const std::string& classes_json, double downscaling_factor, const std::string& net_blob) {
+    std::string out;
+    out.reserve(classes_json.size() + net_blob.size() + 40);
+    put_string(out, classes_json); put_double(out, downscaling_factor); put_string(out, net_blob);
+    return out;
+}
+void dnn_envelope_unpack(const std::string& file, std::string& classes_json, double& downscaling_factor, std::string& net_blob) {
+    size_t pos = 0;
+    classes_json = get_string(file, pos, "the class list");
+    downscaling_factor = get_double(file, pos, "the downscaling factor");
+    net_blob = get_string(file, pos, "the serialized net");
+}
+
 // ignore_large_nonzero_regions (annonet_train_main.cpp:434-502): 8-connected blobs of EQUAL label, background = label 0
 // or the ignore label (annonet.h:26-37); a blob whose pixel count exceeds by_area * rf^2, or whose bounding box is wider
 // than by_width * rf or taller than by_height * rf (rf = receptive-field side, GetRequiredInputDimension()), is relabelled

@@ -3,6 +3,7 @@
 #pragma once
 #include <cstdint>
 #include <deque>
+#include <string>
 #include <vector>
 
 #include "../../include/annonet_hip.h"
@@ -14,6 +15,9 @@ void set_weights(const uint16_t* labels, int nr, int nc, double class_weight, do
 anh_rect random_rect_containing_point(uint32_t draw_x, uint32_t draw_y, long px, long py, long w, long h);
 void outpaint(uint8_t* image, int nr, int nc, int channels, anh_rect inside);
 int64_t count_steps_without_decrease(const double* values, int64_t n, double probability_of_decrease);
+// annonet.dnn envelope: dlib serialize framing of (string classes_json, double downscaling_factor, string serialized_net)
+std::string dnn_envelope_pack(const std::string& classes_json, double downscaling_factor, const std::string& net_blob);
+void dnn_envelope_unpack(const std::string& file, std::string& classes_json, double& downscaling_factor, std::string& net_blob);
 int64_t ignore_large_nonzero_regions(uint16_t* labels, int nr, int nc, double by_area, double by_width, double by_height, int receptive_field_side);
 
 // Geometry of the net input cut around one tile (annonet_infer.cpp:46-66).

@@ -91,6 +91,31 @@ def ignore_large_nonzero_regions(label_image, receptive_field_side, by_area=floa
     return lab, n.value
 
 
+def dnn_envelope_pack(anno_classes_json, downscaling_factor, serialized_runtime_net):
+    """The bytes of annonet.dnn (annonet_train_main.cpp:557-565): dlib serialize of (string, double, string)."""
+    L = _lib.lib()
+    js = anno_classes_json.encode() if isinstance(anno_classes_json, str) else bytes(anno_classes_json)
+    net = bytes(serialized_runtime_net)
+    out, n = C.c_void_p(), C.c_size_t()
+    check(L.anh_dnn_envelope_pack(js, len(js), float(downscaling_factor), C.create_string_buffer(net, len(net)), len(net), C.byref(out), C.byref(n)))
+    try:
+        return C.string_at(out, n.value)
+    finally:
+        L.anh_free(out)
+
+
+def dnn_envelope_unpack(file_bytes):
+    """annonet_infer_main.cpp:340-351: (anno_classes_json bytes, downscaling factor, serialized RuntimeNet bytes)."""
+    L = _lib.lib()
+    data = bytes(file_bytes)
+    js, jn, f, net, nn = C.c_void_p(), C.c_size_t(), C.c_double(), C.c_void_p(), C.c_size_t()
+    check(L.anh_dnn_envelope_unpack(C.create_string_buffer(data, len(data)), len(data), C.byref(js), C.byref(jn), C.byref(f), C.byref(net), C.byref(nn)))
+    try:
+        return C.string_at(js, jn.value), f.value, C.string_at(net, nn.value)
+    finally:
+        L.anh_free(js); L.anh_free(net)
+
+
 def count_steps_without_decrease(values, probability_of_decrease=0.51):
     v = np.ascontiguousarray(values, dtype=np.float64)
     return _lib.lib().anh_count_steps_without_decrease(_ptr(v), v.size, probability_of_decrease)

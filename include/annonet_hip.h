@@ -219,6 +219,13 @@ int anh_outpaint(uint8_t* image, int nr, int nc, int channels, const anh_rect* i
    become ANH_LABEL_IGNORE (infinity = that test off, as the CLI defaults :339-341).  *ignored = pixels relabelled. */
 int anh_ignore_large_nonzero_regions(uint16_t* labels, int nr, int nc, double by_area, double by_width, double by_height,
                                      int receptive_field_side, int64_t* ignored);
+/* annonet.dnn = dlib serialize framing of (string anno_classes_json, double downscaling_factor, string serialized RuntimeNet)
+   (written annonet_train_main.cpp:557-565, read annonet_infer_main.cpp:340-351).  Both calls work on memory images of the
+   file; returned buffers are released with anh_free.  The net blob is what anh_runtime_serialize / _deserialize exchange. */
+int anh_dnn_envelope_pack(const char* classes_json, size_t json_size, double downscaling_factor, const void* net_blob, size_t net_size,
+                          void** file, size_t* file_size);
+int anh_dnn_envelope_unpack(const void* file, size_t file_size, char** classes_json, size_t* json_size, double* downscaling_factor,
+                            void** net_blob, size_t* net_size);
 /* dlib count_steps_without_decrease, used by the learning-rate schedule */
 int64_t anh_count_steps_without_decrease(const double* values, int64_t n, double probability_of_decrease);
 

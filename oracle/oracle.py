@@ -240,6 +240,56 @@ def get_tiles(width, height, max_w, max_h, ov_x, ov_y):
     return [(tuple(arr[i].full), tuple(arr[i].unique)) for i in range(n)]
 
 
+def _dlib_int(v):
+    """dlib/serialize.h integer framing [UPSTREAM-UNVERIFIED]: control byte = byte count | 0x80 if negative, magnitude little-endian."""
+    neg, m = v < 0, abs(int(v))
+    body = m.to_bytes(max(1, (m.bit_length() + 7) // 8), "little")
+    return bytes([len(body) | (0x80 if neg else 0)]) + body
+
+
+def _dlib_read_int(buf, pos):
+    ctl = buf[pos]
+    n = ctl & 0x0F
+    m = int.from_bytes(buf[pos + 1:pos + 1 + n], "little")
+    return (-m if ctl & 0x80 else m), pos + 1 + n
+
+
+def dnn_envelope_pack(classes_json, downscaling_factor, net_blob):
+    """annonet.dnn (annonet_train_main.cpp:557-565) restated in pure Python: dlib serialize of (string, double, string);
+    the double goes as (int64 mantissa, int16 exponent) from frexp with 53 digits, zero low bytes folded into the exponent."""
+    import math
+    v = float(downscaling_factor)
+    if v == math.inf:
+        man, ex = 0, 32000
+    elif v == -math.inf:
+        man, ex = 0, 32001
+    elif v != v:
+        man, ex = 0, 32002
+    else:
+        f, e = math.frexp(v)
+        man, ex = int(f * (1 << 53)), e - 53
+        for _ in range(8):
+            if man & 0xFF:
+                break
+            man >>= 8     # Python's >> on a negative int is arithmetic, like the int64 shift it restates
+            ex += 8
+    js, net = bytes(classes_json), bytes(net_blob)
+    return _dlib_int(len(js)) + js + _dlib_int(man) + _dlib_int(ex) + _dlib_int(len(net)) + net
+
+
+def dnn_envelope_unpack(data):
+    import math
+    n, pos = _dlib_read_int(data, 0)
+    js, pos = data[pos:pos + n], pos + n
+    man, pos = _dlib_read_int(data, pos)
+    ex, pos = _dlib_read_int(data, pos)
+    factor = {32000: math.inf, 32001: -math.inf, 32002: math.nan}.get(ex)
+    if factor is None:
+        factor = math.ldexp(float(man), ex)
+    n, pos = _dlib_read_int(data, pos)
+    return js, factor, data[pos:pos + n]
+
+
 def ignore_large_nonzero_regions(labels, receptive_field_side, by_area=np.inf, by_width=np.inf, by_height=np.inf):
     """annonet_train_main.cpp:434-502 restated with scipy.ndimage (per label value, 8-connectivity): blobs of equal label
     (background = 0 or 65535, annonet.h:26-37) with more than by_area*rf^2 pixels, wider than by_width*rf or taller than
