@@ -19,9 +19,9 @@ import sys
 from collections import defaultdict
 
 ENTRY_KERNELS = {
-    "wgrad_mfma_bf16:wgrad_con3x3s1": r"wgrad3x3_mfma_kernel<\d, \d, 0, 1>",
-    "wgrad_mfma_bf16:wgrad_con3x3s2": r"wgrad3x3_mfma_kernel<\d, \d, 0, 2>",
-    "wgrad_mfma_bf16:wgrad_cont3x3s2": r"wgrad3x3_mfma_kernel<\d, 0, [12], 2>",
+    "wgrad_mfma_bf16:wgrad_con3x3s1": r"wgrad3x3_(ws|mfma)_kernel<\d, \d, 0, 1(, false)?>",
+    "wgrad_mfma_bf16:wgrad_con3x3s2": r"wgrad3x3_(ws|mfma)_kernel<\d, \d, 0, 2(, false)?>",
+    "wgrad_mfma_bf16:wgrad_cont3x3s2": r"wgrad3x3_(ws|mfma)_kernel<\d, 0, [12], 2(, true)?>",
     "wgrad_mfma_bf16:wgrad_stem": r"wgrad_stem_mfma_kernel",
     "wgrad_reduce_partials": r"reduce_partials_kernel",
     "bn_bwd_reduce": r"bn_bwd_reduce",
