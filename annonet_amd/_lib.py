@@ -49,6 +49,11 @@ class Tile(C.Structure):
     _fields_ = [("full_rect", Rect), ("unique_rect", Rect)]
 
 
+class CropSpec(C.Structure):   # anh_crop_spec
+    _fields_ = [("image", C.c_int), ("left", C.c_long), ("top", C.c_long), ("flip_left_right", C.c_int), ("flip_upside_down", C.c_int),
+                ("brightness_change", C.c_double)]
+
+
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("type", "k", "stride", "pad", "cin", "cout")]
 
@@ -151,6 +156,11 @@ _SIGNATURES = {  # ConvDesc / OpInput are defined above
     "anh_set_weights": (C.c_int, [_P, C.c_int, C.c_int, C.c_double, C.c_double, _P]),
     "anh_random_rect_containing_point": (C.c_int, [C.c_uint32, C.c_uint32, C.c_long, C.c_long, C.c_long, C.c_long, C.POINTER(Rect)]),
     "anh_outpaint": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(Rect)]),
+    "anh_dataset_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "anh_dataset_destroy": (None, [C.c_void_p]),
+    "anh_dataset_add": (C.c_int, [C.c_void_p, _P, _P, C.c_int, C.c_int, C.POINTER(C.c_int)]),
+    "anh_dataset_crop_batch": (C.c_int, [C.c_void_p, C.POINTER(CropSpec), C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, _P, _P]),
+    "anh_trainer_step_crops": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CropSpec), C.c_int, C.c_int, C.c_double, C.c_double]),
     "anh_dnn_envelope_pack": (C.c_int, [C.c_char_p, C.c_size_t, C.c_double, _P, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "anh_dnn_envelope_unpack": (C.c_int, [_P, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_double),
                                           C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),

@@ -138,6 +138,65 @@ struct anh_trainer {
     }
 };
 
+// Full images of a dataset, resident in HBM, plus the scratch of the device crop path.
+struct anh_dataset {
+    int channels = 3;
+    struct Item { DevBuf image, labels; int height = 0, width = 0; };
+    std::vector<Item> items;
+    hipStream_t stream = nullptr;
+    DevBuf d_specs, d_hist, d_first, d_table, d_bad;
+    void* pinned = nullptr; size_t pinned_bytes = 0;
+    DevBuf out;   // outputs of the host-array form
+    ~anh_dataset() {
+        if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
+        if (pinned) (void)hipHostFree(pinned);
+    }
+    // Cuts n crops into device arrays on `stream`.  One host round trip inside: the per-crop label histograms come back,
+    // set_weights' table is computed with the host's own arithmetic (bit-identical to set_weights on the crop) and goes up.
+    void crop_batch(const anh_crop_spec* specs, int n, int dim, int classes, double cw, double iw, uint8_t* d_images, uint16_t* d_labels, float* d_weights) {
+        ANH_REQUIRE(specs && n >= 1 && dim >= 1 && dim <= 32768, "crop batch: bad argument");
+        ANH_REQUIRE(classes >= 1 && classes <= kCropMaxClasses, "crop batch: class count must be 1..64");
+        const size_t spec_bytes = (size_t)n * sizeof(CropSource), tab = (size_t)n * kCropMaxClasses * 4;
+        const size_t need = spec_bytes + 3 * tab + 64;
+        if (need > pinned_bytes) {
+            HIP_CHECK(hipStreamSynchronize(stream));
+            if (pinned) HIP_CHECK(hipHostFree(pinned));
+            pinned = nullptr; pinned_bytes = 0;
+            HIP_CHECK(hipHostMalloc(&pinned, need, hipHostMallocDefault));
+            pinned_bytes = need;
+        }
+        d_specs.reserve(spec_bytes); d_hist.reserve(tab); d_first.reserve(tab); d_table.reserve(tab); d_bad.reserve(4);
+        char* pin = static_cast<char*>(pinned);
+        CropSource* hs = reinterpret_cast<CropSource*>(pin);
+        unsigned* h_hist = reinterpret_cast<unsigned*>(pin + spec_bytes);
+        unsigned* h_first = reinterpret_cast<unsigned*>(pin + spec_bytes + tab);
+        float* h_table = reinterpret_cast<float*>(pin + spec_bytes + 2 * tab);
+        int* h_bad = reinterpret_cast<int*>(pin + spec_bytes + 3 * tab);
+        for (int i = 0; i < n; ++i) {
+            const anh_crop_spec& c = specs[i];
+            ANH_REQUIRE(c.image >= 0 && (size_t)c.image < items.size(), "crop batch: image index out of range");
+            ANH_REQUIRE(c.left > -(1L << 30) && c.left < (1L << 30) && c.top > -(1L << 30) && c.top < (1L << 30), "crop batch: rectangle out of range");
+            ANH_REQUIRE(c.brightness_change >= 0, "crop batch: negative brightness change");
+            const Item& it = items[(size_t)c.image];
+            hs[i] = CropSource{it.image.as<uint8_t>(), it.labels.as<uint16_t>(), it.height, it.width, (int)c.left, (int)c.top,
+                               c.flip_left_right ? 1 : 0, c.flip_upside_down ? 1 : 0, c.brightness_change};
+        }
+        HIP_CHECK(hipMemcpyAsync(d_specs.p, hs, spec_bytes, hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipMemsetAsync(d_bad.p, 0, 4, stream));
+        launch_crop_pixels(d_specs.as<CropSource>(), n, dim, channels, d_images, d_labels, d_hist.as<unsigned>(), d_first.as<unsigned>(), d_bad.as<int>(), classes, stream);
+        HIP_CHECK(hipMemcpyAsync(h_hist, d_hist.p, tab, hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipMemcpyAsync(h_first, d_first.p, tab, hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipMemcpyAsync(h_bad, d_bad.p, 4, hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        ANH_REQUIRE(*h_bad == 0, "label value exceeds the class count");
+        for (int i = 0; i < n; ++i)
+            set_weights_table(h_hist + (size_t)i * kCropMaxClasses, h_first + (size_t)i * kCropMaxClasses, kCropMaxClasses, (long long)dim * dim, cw, iw,
+                              h_table + (size_t)i * kCropMaxClasses);
+        HIP_CHECK(hipMemcpyAsync(d_table.p, h_table, tab, hipMemcpyHostToDevice, stream));
+        launch_crop_weights(d_labels, d_table.as<float>(), n, dim, d_weights, stream);
+    }
+};
+
 extern "C" {
 
 const char* anh_last_error(void) { return g_error.c_str(); }
@@ -789,6 +848,84 @@ int anh_random_rect_containing_point(uint32_t dx, uint32_t dy, long px, long py,
 }
 int anh_outpaint(uint8_t* image, int nr, int nc, int channels, const anh_rect* inside) {
     return guarded([&] { ANH_REQUIRE(image && inside, "null argument"); outpaint(image, nr, nc, channels, *inside); });
+}
+int anh_dataset_create(int channels, anh_dataset** out) {
+    return guarded([&] {
+        ANH_REQUIRE(out, "null argument");
+        ANH_REQUIRE(channels == 1 || channels == 3, "input channels must be 1 or 3");
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || count == 0) { (void)hipGetLastError(); fail(ANH_ERR_DEVICE, "no MI355X / HIP device visible"); }
+        auto d = std::make_unique<anh_dataset>();
+        d->channels = channels;
+        HIP_CHECK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+        *out = d.release();
+    });
+}
+void anh_dataset_destroy(anh_dataset* d) { delete d; }
+int anh_dataset_add(anh_dataset* d, const uint8_t* image_hwc, const uint16_t* labels, int height, int width, int* index) {
+    return guarded([&] {
+        ANH_REQUIRE(d && image_hwc && labels, "null argument");
+        ANH_REQUIRE(height >= 1 && width >= 1 && (int64_t)height * width < ((int64_t)1 << 31), "bad image size");
+        anh_dataset::Item it;
+        const size_t px = (size_t)height * width;
+        it.image.reserve(px * d->channels); it.labels.reserve(px * 2);
+        it.height = height; it.width = width;
+        HIP_CHECK(hipMemcpy(it.image.p, image_hwc, px * d->channels, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(it.labels.p, labels, px * 2, hipMemcpyHostToDevice));
+        d->items.push_back(std::move(it));
+        if (index) *index = (int)d->items.size() - 1;
+    });
+}
+int anh_dataset_crop_batch(anh_dataset* d, const anh_crop_spec* specs, int n, int dim, int classes, double class_weight, double image_weight,
+                           uint8_t* images, anh_wlabel* labels) {
+    return guarded([&] {
+        ANH_REQUIRE(d && specs && images && labels && n >= 1 && dim >= 1, "crop batch: bad argument");
+        const size_t plane = (size_t)dim * dim, img = (size_t)n * plane * d->channels;
+        const size_t lab_off = (img + 255) / 256 * 256, w_off = (lab_off + (size_t)n * plane * 2 + 255) / 256 * 256;
+        d->out.reserve(w_off + (size_t)n * plane * 4);
+        uint8_t* base = d->out.as<uint8_t>();
+        d->crop_batch(specs, n, dim, classes, class_weight, image_weight, base, reinterpret_cast<uint16_t*>(base + lab_off), reinterpret_cast<float*>(base + w_off));
+        std::vector<uint16_t> hl((size_t)n * plane);
+        std::vector<float> hw((size_t)n * plane);
+        HIP_CHECK(hipMemcpyAsync(images, base, img, hipMemcpyDeviceToHost, d->stream));
+        HIP_CHECK(hipMemcpyAsync(hl.data(), base + lab_off, hl.size() * 2, hipMemcpyDeviceToHost, d->stream));
+        HIP_CHECK(hipMemcpyAsync(hw.data(), base + w_off, hw.size() * 4, hipMemcpyDeviceToHost, d->stream));
+        HIP_CHECK(hipStreamSynchronize(d->stream));
+        for (size_t i = 0; i < hl.size(); ++i) { labels[i].label = hl[i]; labels[i].weight = hw[i]; }
+    });
+}
+int anh_trainer_step_crops(anh_trainer* h, anh_dataset* d, const anh_crop_spec* specs, int n, int dim, double class_weight, double image_weight) {
+    return guarded([&] {
+        ANH_REQUIRE(h && d && specs, "null argument");
+        ANH_REQUIRE(n >= 1 && dim >= 1, "empty mini-batch");
+        Engine& e = h->engine();
+        const int C = e.spec.cfg.in_channels, K = e.spec.cfg.classes;
+        ANH_REQUIRE(C == d->channels, "the dataset's channel count differs from the net's");
+        const size_t plane = (size_t)dim * dim, img_bytes = (size_t)n * plane * C, lab_off = (img_bytes + 255) / 256 * 256;
+        const size_t w_off = (lab_off + (size_t)n * plane * 2 + 255) / 256 * 256, total = w_off + (size_t)n * plane * 4;
+        anh_trainer::StageSet& st = h->stage[h->host_steps & 1];
+        if (!st.uploaded) {
+            HIP_CHECK(hipEventCreateWithFlags(&st.uploaded, hipEventDisableTiming));
+            HIP_CHECK(hipEventCreateWithFlags(&st.consumed, hipEventDisableTiming));
+        }
+        if (total > st.dev.bytes) {
+            if (st.in_flight) HIP_CHECK(hipEventSynchronize(st.consumed));
+            st.dev.reserve(total);
+        }
+        // the crops of step k are cut on the dataset's stream while the trainer's stream still runs step k-1
+        if (st.in_flight) HIP_CHECK(hipStreamWaitEvent(d->stream, st.consumed, 0));
+        uint8_t* dbase = st.dev.as<uint8_t>();
+        d->crop_batch(specs, n, dim, K, class_weight, image_weight, dbase, reinterpret_cast<uint16_t*>(dbase + lab_off), reinterpret_cast<float*>(dbase + w_off));
+        HIP_CHECK(hipEventRecord(st.uploaded, d->stream));
+        HIP_CHECK(hipStreamWaitEvent(e.stream, st.uploaded, 0));
+        int rc = anh_trainer_forward_backward_device(h, dbase, reinterpret_cast<uint16_t*>(dbase + lab_off), reinterpret_cast<float*>(dbase + w_off), n, dim, dim, (double)n);
+        if (rc != ANH_OK) fail(rc, g_error);
+        rc = anh_trainer_apply_update(h, 1.0);
+        if (rc != ANH_OK) fail(rc, g_error);
+        HIP_CHECK(hipEventRecord(st.consumed, e.stream));
+        st.in_flight = true;
+        ++h->host_steps;
+    });
 }
 int anh_ignore_large_nonzero_regions(uint16_t* labels, int nr, int nc, double by_area, double by_width, double by_height, int rf, int64_t* ignored) {
     return guarded([&] {

@@ -79,16 +79,8 @@ TileWindow tile_window(const anh_tile& t, int levels) {
 // the weights sum to total * (nr*nc/total)^image_weight.  "avg" divides by the histogram's *allocated* length
 // (index*2+16 growth, annonet_train.h:29-34); it cancels in the normalisation but is kept for fidelity.
 // ---------------------------------------------------------------------------------------------------
-void set_weights(const uint16_t* labels, int nr, int nc, double class_weight, double image_weight, anh_wlabel* out) {
-    ANH_REQUIRE(nr >= 0 && nc >= 0, "negative label image size");
-    const size_t n = (size_t)nr * nc;
-    std::vector<size_t> histogram;
-    for (size_t i = 0; i < n; ++i) {
-        const uint16_t l = labels[i];
-        if (l == ANH_LABEL_IGNORE) continue;
-        if (l >= histogram.size()) histogram.resize((size_t)l * 2 + 16);
-        ++histogram[l];
-    }
+// the arithmetic of set_weights on a finished histogram (its LENGTH is part of the arithmetic: see above)
+static std::vector<double> weights_from_histogram(const std::vector<size_t>& histogram, long long pixels, double class_weight, double image_weight) {
     size_t labelled = 0;
     for (size_t c : histogram) labelled += c;
     std::vector<double> weight_of(histogram.size(), 0.0);
@@ -100,13 +92,44 @@ void set_weights(const uint16_t* labels, int nr, int nc, double class_weight, do
             weight_of[l] = std::pow(mean_count / histogram[l], class_weight);
             raw_total += histogram[l] * weight_of[l];
         }
-        const double wanted_total = labelled * std::pow(nr * nc / (double)labelled, image_weight);
+        const double wanted_total = labelled * std::pow(pixels / (double)labelled, image_weight);
         for (double& w : weight_of) w *= wanted_total / raw_total;
     }
+    return weight_of;
+}
+
+void set_weights(const uint16_t* labels, int nr, int nc, double class_weight, double image_weight, anh_wlabel* out) {
+    ANH_REQUIRE(nr >= 0 && nc >= 0, "negative label image size");
+    const size_t n = (size_t)nr * nc;
+    std::vector<size_t> histogram;
+    for (size_t i = 0; i < n; ++i) {
+        const uint16_t l = labels[i];
+        if (l == ANH_LABEL_IGNORE) continue;
+        if (l >= histogram.size()) histogram.resize((size_t)l * 2 + 16);
+        ++histogram[l];
+    }
+    const std::vector<double> weight_of = weights_from_histogram(histogram, (long long)nr * nc, class_weight, image_weight);
     for (size_t i = 0; i < n; ++i) {
         out[i].label = labels[i];
         out[i].weight = labels[i] == ANH_LABEL_IGNORE ? 0.0f : (float)weight_of[labels[i]];
     }
+}
+
+// set_weights' per-label weight table from a histogram gathered elsewhere (the device crop path): `counts[l]` pixels carry
+// label l < n_labels and its first row-major position is `first_position[l]` (unused where the count is 0).  The
+// histogram's allocated length grows to 2 l + 16 whenever a label l >= the current length is met (annonet_train.h:29-34);
+// only FIRST occurrences can trigger that, so replaying them in position order reproduces the length exactly.
+void set_weights_table(const unsigned* counts, const unsigned* first_position, int n_labels, long long pixels, double class_weight,
+                       double image_weight, float* table) {
+    std::vector<std::pair<unsigned, int>> firsts;
+    for (int l = 0; l < n_labels; ++l) if (counts[l]) firsts.emplace_back(first_position[l], l);
+    std::sort(firsts.begin(), firsts.end());
+    size_t length = 0;
+    for (const auto& f : firsts) if ((size_t)f.second >= length) length = (size_t)f.second * 2 + 16;
+    std::vector<size_t> histogram(length, 0);
+    for (int l = 0; l < n_labels; ++l) if (counts[l]) histogram[l] = counts[l];
+    const std::vector<double> weight_of = weights_from_histogram(histogram, pixels, class_weight, image_weight);
+    for (int l = 0; l < n_labels; ++l) table[l] = (size_t)l < weight_of.size() ? (float)weight_of[l] : 0.f;
 }
 
 // random_rect_containing_point (annonet_train.h:85-105)

@@ -12,6 +12,8 @@ namespace anh {
 
 std::vector<anh_tile> make_tiles(int width, int height, const anh_tiling_params& p);
 void set_weights(const uint16_t* labels, int nr, int nc, double class_weight, double image_weight, anh_wlabel* out);
+void set_weights_table(const unsigned* counts, const unsigned* first_position, int n_labels, long long pixels, double class_weight,
+                       double image_weight, float* table);
 anh_rect random_rect_containing_point(uint32_t draw_x, uint32_t draw_y, long px, long py, long w, long h);
 void outpaint(uint8_t* image, int nr, int nc, int channels, anh_rect inside);
 int64_t count_steps_without_decrease(const double* values, int64_t n, double probability_of_decrease);

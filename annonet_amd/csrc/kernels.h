@@ -182,6 +182,23 @@ void launch_argmax(const float* blended, int k, int64_t pixels, const double* ga
 void launch_argmax_range(const float* blended, int k, int64_t pixels, int64_t p0, int64_t p1, const double* gains_or_null, uint16_t* labels, hipStream_t s);
 
 void launch_fill_zero(void* p, size_t bytes, hipStream_t s);
+
+// Training crops cut on the device from full images resident in HBM (randomly_crop_image, annonet_train_main.cpp:110-232,
+// for further_downscaling_factor = 1 and given draws).  kCropMaxClasses bounds the label values the histogram covers.
+constexpr int kCropMaxClasses = 64;
+struct CropSource {
+    const uint8_t* image; const uint16_t* labels;   // full image u8 HWC and its label image, device pointers
+    int height, width;
+    int left, top;                                  // crop rectangle = [left, left+dim) x [top, top+dim), may leave the image
+    int flip_lr, flip_ud;
+    double gain;                                    // multiplicative brightness change (the reference's double); 1 = none
+};
+// pass 1: pixels (clamp-to-edge = extract_image_chip at scale 1 + outpaint), labels (ignore outside the image), flips and
+// brightness; per crop a histogram of the UNFLIPPED labels and the first row-major position of every label value
+void launch_crop_pixels(const CropSource* d_specs, int n, int dim, int channels, uint8_t* d_images, uint16_t* d_labels,
+                        unsigned* d_hist, unsigned* d_firstpos, int* d_bad_label, int classes, hipStream_t s);
+// pass 2: weights[p] = table[crop][label] (0 for ignored pixels); table from set_weights' arithmetic on the histograms
+void launch_crop_weights(const uint16_t* d_labels, const float* d_table, int n, int dim, float* d_weights, hipStream_t s);
 // detection-level filter of annonet_infer() on the device (kernels_generic.hip)
 void run_detection_filter(const float* d_blended, uint16_t* d_labels, int k, int h, int w, const double* d_det, uint8_t* d_flags, int* d_changed,
                           hipStream_t s);

@@ -1545,6 +1545,75 @@ void launch_argmax_range(const float* blended, int k, int64_t pixels, int64_t p0
     HIP_CHECK(hipGetLastError());
 }
 
+// ---------------------------------------------------------------------------------------------------
+// training crops from HBM-resident full images
+// ---------------------------------------------------------------------------------------------------
+// One workgroup walks a strip of one crop in UNFLIPPED row-major order (that is the order set_weights scans in, and the
+// order the first-occurrence positions refer to); flips only move where a pixel is written.
+__global__ __launch_bounds__(256) void crop_pixels_kernel(const CropSource* specs, int dim, int channels, uint8_t* out_img, uint16_t* out_lab,
+                                                          unsigned* hist, unsigned* firstpos, int* bad_label, int classes) {
+    __shared__ unsigned sh_hist[kCropMaxClasses], sh_first[kCropMaxClasses];
+    const int crop = blockIdx.y;
+    const CropSource sp = specs[crop];
+    for (int i = threadIdx.x; i < kCropMaxClasses; i += blockDim.x) { sh_hist[i] = 0; sh_first[i] = 0xFFFFFFFFu; }
+    __syncthreads();
+    const int plane = dim * dim;
+    uint8_t* oi = out_img + (size_t)crop * plane * channels;
+    uint16_t* ol = out_lab + (size_t)crop * plane;
+    const double gain = sp.gain;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < plane; p += gridDim.x * blockDim.x) {
+        const int r = p / dim, c = p - r * dim;
+        const int sy = sp.top + r, sx = sp.left + c;
+        const int cy = min(max(sy, 0), sp.height - 1), cx = min(max(sx, 0), sp.width - 1);
+        const bool inside = sy == cy && sx == cx;
+        const size_t src = (size_t)cy * sp.width + cx;
+        const uint16_t label = inside ? sp.labels[src] : (uint16_t)ANH_LABEL_IGNORE;
+        if (label != ANH_LABEL_IGNORE) {
+            if (label < classes) { atomicAdd(&sh_hist[label], 1u); atomicMin(&sh_first[label], (unsigned)p); }
+            else *bad_label = 1;
+        }
+        const int fr = sp.flip_ud ? dim - 1 - r : r, fc = sp.flip_lr ? dim - 1 - c : c;
+        const size_t dst = (size_t)fr * dim + fc;
+        ol[dst] = label;
+        for (int ch = 0; ch < channels; ++ch) {
+            const uint8_t v = sp.image[src * channels + ch];
+            // tuc::round<unsigned char>(tuc::clamp(value * change, 0.0, 255.0)) (annonet_train_main.cpp:203-205), in double
+            oi[dst * channels + ch] = gain == 1.0 ? v : (uint8_t)floor(fmin(fmax((double)v * gain, 0.0), 255.0) + 0.5);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < classes; i += blockDim.x) {   // integer atomics: the sums do not depend on the order
+        if (sh_hist[i]) { atomicAdd(&hist[(size_t)crop * kCropMaxClasses + i], sh_hist[i]); atomicMin(&firstpos[(size_t)crop * kCropMaxClasses + i], sh_first[i]); }
+    }
+}
+
+__global__ __launch_bounds__(256) void crop_weights_kernel(const uint16_t* labels, const float* table, int plane, float* weights) {
+    const int crop = blockIdx.y;
+    const uint16_t* l = labels + (size_t)crop * plane;
+    float* w = weights + (size_t)crop * plane;
+    const float* t = table + (size_t)crop * kCropMaxClasses;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < plane; p += gridDim.x * blockDim.x) {
+        const uint16_t v = l[p];
+        w[p] = (v == ANH_LABEL_IGNORE || v >= kCropMaxClasses) ? 0.f : t[v];
+    }
+}
+
+void launch_crop_pixels(const CropSource* d_specs, int n, int dim, int channels, uint8_t* d_images, uint16_t* d_labels,
+                        unsigned* d_hist, unsigned* d_firstpos, int* d_bad_label, int classes, hipStream_t s) {
+    ANH_REQUIRE(classes >= 1 && classes <= kCropMaxClasses, "crop: class count out of range");
+    HIP_CHECK(hipMemsetAsync(d_hist, 0, (size_t)n * kCropMaxClasses * sizeof(unsigned), s));
+    HIP_CHECK(hipMemsetAsync(d_firstpos, 0xFF, (size_t)n * kCropMaxClasses * sizeof(unsigned), s));
+    const int blocks = std::max(1, std::min((dim * dim + 255) / 256, 64));
+    hipLaunchKernelGGL(crop_pixels_kernel, dim3(blocks, n), dim3(256), 0, s, d_specs, dim, channels, d_images, d_labels, d_hist, d_firstpos, d_bad_label, classes);
+    HIP_CHECK(hipGetLastError());
+}
+
+void launch_crop_weights(const uint16_t* d_labels, const float* d_table, int n, int dim, float* d_weights, hipStream_t s) {
+    const int blocks = std::max(1, std::min((dim * dim + 255) / 256, 64));
+    hipLaunchKernelGGL(crop_weights_kernel, dim3(blocks, n), dim3(256), 0, s, d_labels, d_table, dim * dim, d_weights);
+    HIP_CHECK(hipGetLastError());
+}
+
 void launch_fill_zero(void* p, size_t bytes, hipStream_t s) {
     if (bytes) HIP_CHECK(hipMemsetAsync(p, 0, bytes, s));
 }

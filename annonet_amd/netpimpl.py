@@ -60,10 +60,13 @@ class tiling:
             L.anh_free(arr)
 
 
+WLABEL = np.dtype([("label", np.uint16), ("weight", np.float32)], align=True)   # NetPimpl::training_label_type's element
+
+
 def set_weights(unweighted_label_image, class_weight, image_weight):
     """set_weights() (annonet_train.h:20-83) -> (labels u16, weights f32) = NetPimpl::training_label_type."""
     lab = np.ascontiguousarray(unweighted_label_image, dtype=np.uint16)
-    out = np.zeros(lab.shape, dtype=np.dtype([("label", np.uint16), ("weight", np.float32)], align=True))
+    out = np.zeros(lab.shape, dtype=WLABEL)
     assert out.itemsize == C.sizeof(_lib.WLabel)
     check(_lib.lib().anh_set_weights(_ptr(lab), lab.shape[0], lab.shape[1], class_weight, image_weight, _ptr(out)))
     return out
@@ -89,6 +92,47 @@ def ignore_large_nonzero_regions(label_image, receptive_field_side, by_area=floa
     n = C.c_int64(0)
     check(_lib.lib().anh_ignore_large_nonzero_regions(_ptr(lab), lab.shape[0], lab.shape[1], by_area, by_width, by_height, receptive_field_side, C.byref(n)))
     return lab, n.value
+
+
+class Dataset:
+    """Full images + label images resident in HBM; training crops are cut on the device (randomly_crop_image,
+    annonet_train_main.cpp:110-232, further_downscaling_factor = 1, draws supplied by the caller).
+    A crop spec is (image index, left, top, flip_left_right, flip_upside_down, brightness_change)."""
+
+    def __init__(self, channels=3):
+        self.L = _lib.lib()
+        self.channels = channels
+        self.h = C.c_void_p()
+        check(self.L.anh_dataset_create(channels, C.byref(self.h)))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.anh_dataset_destroy(self.h)
+            self.h = None
+
+    def add(self, image, labels):
+        img = np.ascontiguousarray(image, dtype=np.uint8)
+        lab = np.ascontiguousarray(labels, dtype=np.uint16)
+        assert img.shape[:2] == lab.shape and (img.ndim == 2) == (self.channels == 1)
+        idx = C.c_int()
+        check(self.L.anh_dataset_add(self.h, _ptr(img), _ptr(lab), lab.shape[0], lab.shape[1], C.byref(idx)))
+        return idx.value
+
+    @staticmethod
+    def _specs(specs):
+        arr = (_lib.CropSpec * len(specs))()
+        for a, s in zip(arr, specs):
+            a.image, a.left, a.top, a.flip_left_right, a.flip_upside_down, a.brightness_change = int(s[0]), int(s[1]), int(s[2]), int(s[3]), int(s[4]), float(s[5])
+        return arr
+
+    def crop_batch(self, specs, dim, classes, class_weight=0.5, image_weight=0.5):
+        """-> (images n x dim x dim [x 3] u8, labels n x dim x dim u16, weights n x dim x dim f32)"""
+        n = len(specs)
+        shape = (n, dim, dim) if self.channels == 1 else (n, dim, dim, self.channels)
+        img = np.empty(shape, dtype=np.uint8)
+        wl = np.empty((n, dim, dim), dtype=WLABEL)
+        check(self.L.anh_dataset_crop_batch(self.h, self._specs(specs), n, dim, classes, class_weight, image_weight, _ptr(img), _ptr(wl)))
+        return img, wl["label"].copy(), wl["weight"].copy()
 
 
 def dnn_envelope_pack(anno_classes_json, downscaling_factor, serialized_runtime_net):
@@ -357,6 +401,10 @@ class TrainingNet(_Profiled):
         check(self.L.anh_trainer_step(self.h, ip, lp, n, h, w))
 
     # ---- device-resident, data-parallel-friendly form ----
+    def StartTrainingOnCrops(self, dataset, specs, dim, class_weight=0.5, image_weight=0.5):
+        """StartTraining on crops cut on the device from `dataset` (no host mini-batch)."""
+        check(self.L.anh_trainer_step_crops(self.h, dataset.h, Dataset._specs(specs), len(specs), dim, class_weight, image_weight))
+
     def forward_backward_device(self, d_images, d_labels, d_weights, n, h, w, loss_scale_n):
         check(self.L.anh_trainer_forward_backward_device(self.h, d_images, d_labels, d_weights, n, h, w, float(loss_scale_n)))
 

@@ -214,6 +214,26 @@ int anh_set_weights(const uint16_t* labels, int nr, int nc, double class_weight,
 int anh_random_rect_containing_point(uint32_t draw_x, uint32_t draw_y, long px, long py, long width, long height, anh_rect* out);
 /* outpaint() (annonet.h:74-120), in place on a u8 image with `channels` interleaved channels */
 int anh_outpaint(uint8_t* image, int nr, int nc, int channels, const anh_rect* inside);
+/* ---- training crops cut on the device ----
+   The reference cuts every training crop on the CPU (randomly_crop_image, annonet_train_main.cpp:110-232, in loader threads)
+   and hands StartTraining host matrices.  Here the full images of the dataset live in HBM (288 GB) and a mini-batch of
+   crops is produced there: extract_image_chip at scale 1 + outpaint (= clamp-to-edge crop, :160-176), labels set to
+   "ignore" outside the image (:150-158), set_weights (:178), flips (:183-194) and the multiplicative brightness change
+   (:196-216), for further_downscaling_factor = 1.  The random draws stay with the caller (dlib::rand is the host's): a
+   crop is described by its rectangle (random_rect_containing_point), the two flip decisions and the brightness factor.
+   Not covered: further downscaling, add_random_noise, apply_random_color_offset (dlib routines, absent from the snapshot). */
+typedef struct anh_dataset anh_dataset;
+typedef struct { int image; long left, top; int flip_left_right, flip_upside_down; double brightness_change; /* 1 = none */ } anh_crop_spec;
+int anh_dataset_create(int channels, anh_dataset** out);
+void anh_dataset_destroy(anh_dataset* d);
+/* uploads one full image (u8, HWC, `channels` interleaved) and its label image (u16) and keeps them resident; *index = its number */
+int anh_dataset_add(anh_dataset* d, const uint8_t* image_hwc, const uint16_t* labels, int height, int width, int* index);
+/* n crops of dim x dim into host arrays: images n*dim*dim*channels u8, weighted labels n*dim*dim (tests, non-resident hosts) */
+int anh_dataset_crop_batch(anh_dataset* d, const anh_crop_spec* specs, int n, int dim, int classes, double class_weight, double image_weight,
+                           uint8_t* images, anh_wlabel* labels);
+/* StartTraining on n crops cut on the device: the mini-batch never exists on the host */
+int anh_trainer_step_crops(anh_trainer* h, anh_dataset* d, const anh_crop_spec* specs, int n, int dim, double class_weight, double image_weight);
+
 /* ignore_large_nonzero_regions (annonet_train_main.cpp:434-502), in place on a u16 label image: 8-connected blobs of equal
    non-zero, non-ignored label larger than by_area * rf^2 pixels, wider than by_width * rf or taller than by_height * rf
    become ANH_LABEL_IGNORE (infinity = that test off, as the CLI defaults :339-341).  *ignored = pixels relabelled. */

@@ -240,6 +240,35 @@ def get_tiles(width, height, max_w, max_h, ov_x, ov_y):
     return [(tuple(arr[i].full), tuple(arr[i].unique)) for i in range(n)]
 
 
+def crop_sample(image, labels, left, top, dim, flip_lr, flip_ud, brightness_change, class_weight, image_weight):
+    """randomly_crop_image (annonet_train_main.cpp:110-232) for further_downscaling_factor = 1 and given draws, composed from
+    the oracle's own pieces: integer-rect chip, outpaint (annonet.h:74-120), labels "ignore" outside the image (:150-158),
+    set_weights (:178), flips (:183-194), multiplicative brightness (:196-216; tuc::round taken as round-half-up
+    [UPSTREAM-UNVERIFIED: tuc is not in the snapshot]).  -> (image u8, labels u16, weights f32)"""
+    image = np.asarray(image, dtype=np.uint8)
+    labels = np.asarray(labels, dtype=np.uint16)
+    H, W = labels.shape
+    chip = np.zeros((dim, dim) + image.shape[2:], dtype=np.uint8)
+    lab = np.full((dim, dim), 65535, dtype=np.uint16)
+    y0, y1, x0, x1 = max(top, 0), min(top + dim, H), max(left, 0), min(left + dim, W)   # valid_rect_in_full_image
+    if y0 < y1 and x0 < x1:
+        chip[y0 - top:y1 - top, x0 - left:x1 - left] = image[y0:y1, x0:x1]
+        lab[y0 - top:y1 - top, x0 - left:x1 - left] = labels[y0:y1, x0:x1]
+        chip = outpaint(chip, (x0 - left, y0 - top, x1 - left - 1, y1 - top - 1))
+    else:   # the rectangle misses the image entirely: the device clamps to the nearest edge pixel
+        ys = np.clip(np.arange(top, top + dim), 0, H - 1)
+        xs = np.clip(np.arange(left, left + dim), 0, W - 1)
+        chip = image[np.ix_(ys, xs)]
+    weights = set_weights(lab, class_weight, image_weight)
+    if flip_lr:
+        chip, lab, weights = chip[:, ::-1], lab[:, ::-1], weights[:, ::-1]
+    if flip_ud:
+        chip, lab, weights = chip[::-1], lab[::-1], weights[::-1]
+    if brightness_change != 1.0:
+        chip = np.floor(np.clip(chip.astype(np.float64) * float(brightness_change), 0.0, 255.0) + 0.5).astype(np.uint8)
+    return np.ascontiguousarray(chip), np.ascontiguousarray(lab), np.ascontiguousarray(weights)
+
+
 def _dlib_int(v):
     """dlib/serialize.h integer framing [UPSTREAM-UNVERIFIED]: control byte = byte count | 0x80 if negative, magnitude little-endian."""
     neg, m = v < 0, abs(int(v))
