@@ -5,7 +5,7 @@ The compute lives in annonet_amd/lib/libannonet_hip.so (hand-written HIP, C ABI 
 is the thin host-side mirror used by tests and bench.py.  There is no CPU fallback.
 """
 from ._lib import ANH_BF16, ANH_FP32, LABEL_IGNORE, AnnonetHipError, build, lib  # noqa: F401
-from .netpimpl import (Dataset, RuntimeNet, TrainingNet, annonet_infer, annonet_infer_device, count_steps_without_decrease, dnn_envelope_pack, dnn_envelope_unpack,  # noqa: F401
+from .netpimpl import (Dataset, RuntimeNet, TrainingNet, argmax_device, annonet_infer, annonet_infer_device, count_steps_without_decrease, dnn_envelope_pack, dnn_envelope_unpack,  # noqa: F401
                        ignore_large_nonzero_regions,
                        net_config, net_layers,
                        op_conv_backward_data, op_conv_backward_data_bn, op_conv_backward_filter, op_conv_backward_filter_bn,

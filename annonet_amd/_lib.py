@@ -102,7 +102,9 @@ _SIGNATURES = {  # ConvDesc / OpInput are defined above
     "anh_runtime_forward_device": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "anh_infer": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, C.POINTER(TilingParams), _P, _P]),
     "anh_infer_device": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.POINTER(TilingParams), C.POINTER(Tile), C.c_size_t, _P, _P]),
+    "anh_argmax_device": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "anh_runtime_set_stream": (C.c_int, [_P, _P]),
+    "anh_runtime_get_stream": (C.c_int, [_P, C.POINTER(C.c_void_p)]),
     "anh_runtime_synchronize": (C.c_int, [_P]),
     "anh_trainer_create": (C.c_int, [C.POINTER(_P)]),
     "anh_trainer_destroy": (None, [_P]),
@@ -138,6 +140,7 @@ _SIGNATURES = {  # ConvDesc / OpInput are defined above
     "anh_trainer_save_state": (C.c_int, [_P, C.c_char_p]),
     "anh_trainer_load_state": (C.c_int, [_P, C.c_char_p]),
     "anh_trainer_set_stream": (C.c_int, [_P, _P]),
+    "anh_trainer_get_stream": (C.c_int, [_P, C.POINTER(C.c_void_p)]),
     "anh_trainer_synchronize": (C.c_int, [_P]),
     "anh_trainer_layer_tensor": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int64, C.POINTER(C.c_int)]),
     "anh_profile_enable": (C.c_int, [_P, C.c_int, C.c_int]),

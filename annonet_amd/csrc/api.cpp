@@ -359,6 +359,16 @@ int anh_infer_device(anh_runtime* h, const uint8_t* d_image, int height, int wid
     });
 }
 
+int anh_argmax_device(anh_runtime* h, const float* d_blended, int height, int width, int row0, int row1, const double* gains, uint16_t* d_result) {
+    return guarded([&] {
+        ANH_REQUIRE(h && d_blended && d_result, "null argument");
+        ANH_REQUIRE(height >= 1 && width >= 1 && row0 >= 0 && row0 <= row1 && row1 <= height, "argmax: bad row range");
+        Engine& e = *h->eng;
+        const double* d_gains = e.upload_gains(gains);
+        launch_argmax_range(d_blended, e.spec.cfg.classes, (int64_t)height * width, (int64_t)row0 * width, (int64_t)row1 * width, d_gains, d_result, e.stream);
+    });
+}
+
 namespace {
 void ring_reserve(anh_runtime::Pinned& b, size_t bytes) {
     if (!b.done) HIP_CHECK(hipEventCreateWithFlags(&b.done, hipEventDisableTiming));
@@ -500,6 +510,7 @@ int anh_infer(anh_runtime* h, const uint8_t* image, int height, int width, const
 }
 
 int anh_runtime_set_stream(anh_runtime* h, void* s) { return guarded([&] { ANH_REQUIRE(h, "null handle"); h->eng->set_stream((hipStream_t)s); }); }
+int anh_runtime_get_stream(anh_runtime* h, void** s) { return guarded([&] { ANH_REQUIRE(h && s, "null argument"); *s = (void*)h->eng->stream; }); }
 int anh_runtime_synchronize(anh_runtime* h) { return guarded([&] { ANH_REQUIRE(h, "null handle"); h->eng->synchronize(); }); }
 
 // ---- TrainingNet ----
@@ -783,6 +794,7 @@ int anh_trainer_load_state(anh_trainer* h, const char* path) {
 }
 
 int anh_trainer_set_stream(anh_trainer* h, void* s) { return guarded([&] { ANH_REQUIRE(h, "null handle"); h->engine().set_stream((hipStream_t)s); }); }
+int anh_trainer_get_stream(anh_trainer* h, void** s) { return guarded([&] { ANH_REQUIRE(h && s, "null argument"); *s = (void*)h->engine().stream; }); }
 int anh_trainer_synchronize(anh_trainer* h) {
     return guarded([&] {
         ANH_REQUIRE(h, "null handle");

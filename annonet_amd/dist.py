@@ -21,13 +21,28 @@ def grad_bucket_tensor(trainer):
     return device_tensor(ptr, n)
 
 
-def data_parallel_step(trainer, bucket, d_images, d_labels, d_weights, n, h, w, world_size, group=None, force_collective=False):
+def handle_stream(handle):
+    """The handle's HIP stream as a torch stream: torch work issued under `with torch.cuda.stream(handle_stream(h))` is
+    ordered with the handle's own kernels (torch.distributed orders a collective against the CURRENT stream: the
+    all-reduce then starts after backward and the update starts after the all-reduce)."""
+    import torch
+    return torch.cuda.ExternalStream(handle.stream_ptr(), device=torch.device("cuda", torch.cuda.current_device()))
+
+
+def data_parallel_step(trainer, bucket, d_images, d_labels, d_weights, n, h, w, world_size, group=None, force_collective=False, stream=None):
     """One optimiser step of a data-parallel job.  The loss scale uses the GLOBAL batch (n * world_size), so the
-    all-reduce is a plain SUM and every rank then applies the identical update."""
+    all-reduce is a plain SUM and every rank then applies the identical update.  The collective is
+    enqueued on the trainer's own stream (`stream` = handle_stream(trainer), made once by the caller): backward ->
+    all-reduce -> SGD is one stream-ordered chain with no host synchronisation."""
     trainer.forward_backward_device(d_images, d_labels, d_weights, n, h, w, n * world_size)
     if world_size > 1 or force_collective:
+        import torch
         import torch.distributed as dist
-        dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=group)
+        if bucket.is_cuda:
+            with torch.cuda.stream(stream if stream is not None else handle_stream(trainer)):
+                dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=group)
+        else:   # CPU rehearsal of the same logic over gloo (tests/test_dist_gloo.py)
+            dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=group)
     trainer.apply_update(1.0)
 
 
@@ -37,6 +52,91 @@ def shard_tiles(tiles, rank, world_size):
     lo = (n * rank) // world_size
     hi = (n * (rank + 1)) // world_size
     return tiles[lo:hi]
+
+
+def tile_owner(n_tiles, world_size):
+    """rank of every tile under shard_tiles' contiguous chunks"""
+    owner = [0] * n_tiles
+    for r in range(world_size):
+        for i in range((n_tiles * r) // world_size, (n_tiles * (r + 1)) // world_size):
+            owner[i] = r
+    return owner
+
+
+def cross_rank_overlaps(tiles, world_size, width, height):
+    """The rectangles (left, top, right, bottom; inclusive, clipped to the image) in which tiles of DIFFERENT ranks overlap:
+    the only places where a rank's blended planes hold partial sums (annonet_infer.cpp:116-164 adds the ramps of every tile
+    covering a pixel).  The same sorted list on every rank.  Overlaps are a few tens of pixels wide (overlap = receptive
+    field), so this is a few percent of the image."""
+    owner = tile_owner(len(tiles), world_size)
+    rects = set()
+    for i, (fi, _) in enumerate(tiles):
+        for j in range(i + 1, len(tiles)):
+            if owner[i] == owner[j]:
+                continue
+            fj = tiles[j][0]
+            l, t = max(fi[0], fj[0], 0), max(fi[1], fj[1], 0)
+            r, b = min(fi[2], fj[2], width - 1), min(fi[3], fj[3], height - 1)
+            if l <= r and t <= b:
+                rects.add((l, t, r, b))
+    return sorted(rects)
+
+
+class OverlapExchange:
+    """Gather / scatter of the cross-rank overlap pixels of blended planes [K, H, W] (torch, on the GPU): ONE index tensor
+    of the unique pixel positions, built once per (tile list, world size), so an exchange is one gather, one all-reduce of
+    a [K, n] buffer and one scatter — not a launch per rectangle."""
+
+    def __init__(self, tiles, world_size, width, height, device):
+        import torch
+        self.rects = cross_rank_overlaps(tiles, world_size, width, height) if world_size > 1 else []
+        if self.rects:
+            parts = [(np.arange(t, b + 1, dtype=np.int64)[:, None] * width + np.arange(l, r + 1, dtype=np.int64)[None, :]).ravel() for (l, t, r, b) in self.rects]
+            self.index = torch.from_numpy(np.unique(np.concatenate(parts))).to(device)
+        else:
+            self.index = None
+
+    def pixels(self):
+        return 0 if self.index is None else int(self.index.numel())
+
+    def pack(self, blended):
+        return blended.reshape(blended.shape[0], -1).index_select(1, self.index)
+
+    def unpack(self, blended, packed):
+        blended.view(blended.shape[0], -1).index_copy_(1, self.index, packed)   # unique positions: deterministic
+
+    def run(self, blended, group=None):
+        if self.index is None:
+            return
+        import torch.distributed as dist
+        packed = self.pack(blended)
+        dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+        self.unpack(blended, packed)
+
+
+def sharded_infer(net, image, labels, blended, tiles, rank, world_size, exchange, tiling_parameters=None, gains=None, group=None, stream=None):
+    """annonet_infer() with the tile list sharded over the ranks of a job (image, labels [H, W] int16 and blended [K, H, W]
+    float32 are torch tensors on this rank's GPU; `exchange` = OverlapExchange(tiles, world_size, W, H, device)).
+      1. this rank's tiles are blended into its own planes;
+      2. the ONE exchange step of the path: the plane sums at the pixels where tiles of different ranks overlap are
+         all-reduced (nothing is exchanged at world size 1);
+      3. find_label over the rows this rank's tiles cover.
+    Returns that row range (row0, row1), the rank's share of the label map: every pixel of it that one of this rank's tiles
+    covers now carries the complete sum, hence the same label on every rank that covers it."""
+    import torch
+    from . import netpimpl as nn
+    height, width = int(blended.shape[1]), int(blended.shape[2])
+    mine = shard_tiles(tiles, rank, world_size)
+    nn.annonet_infer_device(net, image.data_ptr(), height, width, 0, blended.data_ptr(), gains=gains, tiling_parameters=tiling_parameters, tiles=mine)
+    if exchange.index is not None:
+        with torch.cuda.stream(stream if stream is not None else handle_stream(net)):   # gather / all-reduce / scatter on the net's own stream
+            exchange.run(blended, group)
+    if not mine:
+        return 0, 0
+    row0 = max(0, min(t[0][1] for t in mine))
+    row1 = min(height, max(t[0][3] for t in mine) + 1)
+    nn.argmax_device(net, blended.data_ptr(), height, width, row0, row1, labels.data_ptr(), gains=gains)
+    return row0, row1
 
 
 def reduce_shard_planes(blended_np_list):

@@ -267,7 +267,14 @@ class RuntimeNet(_Profiled):
         check(self.L.anh_runtime_synchronize(self.h))
 
     def set_stream(self, stream_ptr):
-        check(self.L.anh_runtime_set_stream(self.h, stream_ptr))
+        """Launch on the caller's (non-default) HIP stream.  The legacy default stream (0) cannot be named through this call:
+        0 / None means "back to a stream of the handle's own".  To order torch work with the handle, use stream_ptr()."""
+        check(self.L.anh_runtime_set_stream(self.h, stream_ptr or None))
+
+    def stream_ptr(self):
+        s = C.c_void_p()
+        check(self.L.anh_runtime_get_stream(self.h, C.byref(s)))
+        return s.value or 0
 
 
 def annonet_infer(net, input_image, gains=None, detection_levels=None, tiling_parameters=None, want_blended=False):
@@ -303,6 +310,12 @@ def annonet_infer_device(net, d_image_ptr, height, width, d_labels_ptr, d_blende
             arr[i].full_rect = _lib.Rect(*full)
             arr[i].unique_rect = _lib.Rect(*uniq)
     check(net.L.anh_infer_device(net.h, d_image_ptr, height, width, _ptr(g), C.byref(tp) if tp is not None else None, arr, n, d_labels_ptr, d_blended_ptr))
+
+
+def argmax_device(net, d_blended_ptr, height, width, row0, row1, d_labels_ptr, gains=None):
+    """find_label (annonet_infer.cpp:170-185) over rows [row0, row1) of device-resident blended planes."""
+    g = np.ascontiguousarray(gains, dtype=np.float64) if gains is not None else None
+    check(net.L.anh_argmax_device(net.h, d_blended_ptr, height, width, row0, row1, _ptr(g), d_labels_ptr))
 
 
 class TrainingNet(_Profiled):
@@ -456,7 +469,13 @@ class TrainingNet(_Profiled):
         check(self.L.anh_trainer_synchronize(self.h))
 
     def set_stream(self, stream_ptr):
-        check(self.L.anh_trainer_set_stream(self.h, stream_ptr))
+        """As RuntimeNet.set_stream: 0 / None = a stream of the handle's own, never the legacy default stream."""
+        check(self.L.anh_trainer_set_stream(self.h, stream_ptr or None))
+
+    def stream_ptr(self):
+        s = C.c_void_p()
+        check(self.L.anh_trainer_get_stream(self.h, C.byref(s)))
+        return s.value or 0
 
     def layer_tensor(self, layer, which=0):
         dims = (C.c_int * 4)()

@@ -81,8 +81,9 @@ def cpu_baseline(sample_tiles=4):
 
 
 def bench_infer(args, aa, aad, torch, dist, prec, rank, local_rank, world, use_dist):
-    """BASELINE.json configs[2] / [4]: tiled sliding-window inference over one synthetic image, tiles sharded across ranks
-    (no collective in the data path).  Timed: tile cut + forward + blend + argmax, image and label map resident in HBM."""
+    """BASELINE.json configs[2] / [4]: tiled sliding-window inference over one synthetic image, tiles sharded across ranks.
+    Timed: tile cut + forward + blend, the exchange of the cross-rank overlap sums (one RCCL all-reduce of ~2 % of the
+    planes; nothing at one GPU) and argmax; image and label map resident in HBM."""
     side = args.image_side
     dev = torch.device("cuda", local_rank)
     cfg = aa.net_config(LEVELS, 3, CLASSES, WIDTH, 1, prec)
@@ -90,8 +91,7 @@ def bench_infer(args, aa, aad, torch, dist, prec, rank, local_rank, world, use_d
     tr.SetNetWidth(WIDTH, 1); tr.SetClassCount(CLASSES); tr.Initialize()
     net = tr.GetRuntimeNet(prec)
     del tr
-    stream = torch.cuda.current_stream()
-    net.set_stream(stream.cuda_stream)
+    net_stream = aad.handle_stream(net)   # torch's view of the net's own stream: the exchange step is enqueued there
     rng = np.random.default_rng(3)
     image = torch.from_numpy(rng.integers(0, 256, (side, side, 3), dtype=np.uint8)).to(dev)
     labels = torch.empty((side, side), dtype=torch.int16, device=dev)
@@ -101,9 +101,11 @@ def bench_infer(args, aa, aad, torch, dist, prec, rank, local_rank, world, use_d
     tp = aa.tiling.parameters(1024, 1024, ov, ov)  # GPU defaults of the reference (annonet_infer_main.cpp:300-303,423-427)
     tiles = aa.tiling.get_tiles(side, side, tp)
     mine = aad.shard_tiles(tiles, rank, world)
+    exchange = aad.OverlapExchange(tiles, world, side, side, dev)   # the pixels where tiles of different ranks overlap (none at world 1)
 
     def run():
-        aa.annonet_infer_device(net, image.data_ptr(), side, side, labels.data_ptr(), blended.data_ptr(), tiling_parameters=tp, tiles=mine)
+        # blend this rank's tiles -> all-reduce the plane sums of the cross-rank overlaps -> label this rank's rows
+        aad.sharded_infer(net, image, labels, blended, tiles, rank, world, exchange, tiling_parameters=tp, stream=net_stream)
 
     def fence():
         torch.cuda.synchronize()
@@ -127,7 +129,7 @@ def bench_infer(args, aa, aad, torch, dist, prec, rank, local_rank, world, use_d
         out = {"metric": f"Mpixels/s tiled inference, {side}x{side} image, 1024^2 tiles, overlap {ov}", "value": side * side * args.steps / elapsed / 1e6,
                "unit": "Mpx/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-               "config": {"workload": f"annonet_infer(): {len(tiles)} tiles ({len(mine)} on rank 0), levels={LEVELS} width={WIDTH} K={CLASSES}", "parallelism": f"tile-shard{world}"}}
+               "config": {"workload": f"annonet_infer(): {len(tiles)} tiles ({len(mine)} on rank 0), levels={LEVELS} width={WIDTH} K={CLASSES}", "parallelism": f"tile-shard{world}", "exchanged_pixels": exchange.pixels()}}
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
@@ -171,8 +173,7 @@ def main():
     t.SetClassCount(CLASSES)
     t.Initialize()
     t.SetLearningRate(0.1)
-    stream = torch.cuda.current_stream()
-    t.set_stream(stream.cuda_stream)
+    t_stream = aad.handle_stream(t)       # torch's view of the trainer's own stream: the all-reduce is enqueued there
     bucket = aad.grad_bucket_tensor(t)
 
     img, lab, w = synthetic_batch(rank)
@@ -182,7 +183,7 @@ def main():
     d_w = torch.from_numpy(w).to(dev)
 
     def step():
-        aad.data_parallel_step(t, bucket, d_img.data_ptr(), d_lab.data_ptr(), d_w.data_ptr(), BATCH, TILE, TILE, world, force_collective=use_dist)
+        aad.data_parallel_step(t, bucket, d_img.data_ptr(), d_lab.data_ptr(), d_w.data_ptr(), BATCH, TILE, TILE, world, force_collective=use_dist, stream=t_stream)
 
     def fence():
         torch.cuda.synchronize()

@@ -118,7 +118,14 @@ int anh_infer(anh_runtime* h, const uint8_t* image_hwc, int height, int width,
 int anh_infer_device(anh_runtime* h, const uint8_t* d_image_hwc, int height, int width,
                      const double* gains, const anh_tiling_params* tiling,
                      const anh_tile* tiles, size_t n_tiles, uint16_t* d_result_labels, float* d_blended);
-int anh_runtime_set_stream(anh_runtime* h, void* hip_stream); /* NULL = the handle's own stream */
+/* label rows [row0, row1) of device-resident blended planes (find_label, annonet_infer.cpp:170-185): the second half of a
+   sharded annonet_infer(), run after the ranks have exchanged the plane sums of their overlapping tiles */
+int anh_argmax_device(anh_runtime* h, const float* d_blended, int height, int width, int row0, int row1, const double* gains, uint16_t* d_result);
+/* A handle launches on ONE stream (its own, non-blocking, unless set).  NULL returns the handle to a stream of its own — it does
+   NOT mean the legacy default stream.  A host that mixes its own GPU work with the handle's (torch.distributed's all-reduce of the
+   gradient bucket, torch kernels on the blended planes) takes the handle's stream with _get_stream and enqueues that work on it. */
+int anh_runtime_set_stream(anh_runtime* h, void* hip_stream);
+int anh_runtime_get_stream(anh_runtime* h, void** hip_stream);
 int anh_runtime_synchronize(anh_runtime* h);
 
 /* ---- TrainingNet (annonet_train_main.cpp:396-410) ---- */
@@ -163,6 +170,7 @@ int anh_trainer_snapshot_runtime(anh_trainer* h, int precision, anh_runtime** ou
 int anh_trainer_save_state(anh_trainer* h, const char* path); /* trainer synchronization file */
 int anh_trainer_load_state(anh_trainer* h, const char* path);
 int anh_trainer_set_stream(anh_trainer* h, void* hip_stream);
+int anh_trainer_get_stream(anh_trainer* h, void** hip_stream);
 int anh_trainer_synchronize(anh_trainer* h);
 /* debugging / parity taps: raw conv output (which=0) or gradient w.r.t. the layer's activation (which=1), as fp32 NHWC */
 int anh_trainer_layer_tensor(anh_trainer* h, int layer, int which, float* out, int64_t capacity, int dims4[4]);

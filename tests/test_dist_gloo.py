@@ -104,6 +104,24 @@ def test_two_rank_data_parallel_step_over_gloo():
     assert abs(out["bucket"][-1] - want_loss) < 1e-6
 
 
+def test_cross_rank_overlaps_are_exactly_the_pixels_shared_between_ranks():
+    """The exchange step of sharded inference moves the plane sums of these pixels and no others."""
+    W, H = 301, 230
+    tiles = orc.get_tiles(W, H, 96, 112, 19, 19)
+    for world in (1, 2, 3, 7):
+        owner = aad.tile_owner(len(tiles), world)
+        assert owner == sorted(owner) and [owner.count(r) for r in range(world)] == [len(aad.shard_tiles(tiles, r, world)) for r in range(world)]
+        ranks_at = [np.zeros((H, W), dtype=bool) for _ in range(world)]
+        for (full, _), r in zip(tiles, owner):
+            ranks_at[r][max(full[1], 0):min(full[3], H - 1) + 1, max(full[0], 0):min(full[2], W - 1) + 1] = True
+        shared = np.sum(ranks_at, axis=0) >= 2
+        mask = np.zeros((H, W), dtype=bool)
+        for (l, t, r, b) in aad.cross_rank_overlaps(tiles, world, W, H):
+            mask[t:b + 1, l:r + 1] = True
+        np.testing.assert_array_equal(mask, shared)
+        assert (world == 1) == (not mask.any())
+
+
 def test_tile_sharding_partitions_the_tile_list():
     tiles = orc.get_tiles(4096, 3000, 1024, 1024, 35, 35)
     for world in (1, 2, 3, 8, 40):

@@ -383,7 +383,6 @@ def test_grad_bucket_is_a_live_view_and_all_reduce_runs_on_it():
     img, lab, w, _ = make_batch(rng, 2, d, 3, 3)
     dev = torch.device("cuda:0")
     timg, tlab, tw = (torch.from_numpy(a).to(dev) for a in (img, lab.view(np.int16), w))
-    t.set_stream(torch.cuda.current_stream().cuda_stream)
     bucket = aad.grad_bucket_tensor(t)
     assert bucket.numel() == o.n_params + 1 and bucket.is_cuda
     t.forward_backward_device(timg.data_ptr(), tlab.data_ptr(), tw.data_ptr(), 2, d, d, 2)
@@ -398,7 +397,8 @@ def test_grad_bucket_is_a_live_view_and_all_reduce_runs_on_it():
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     try:
         before = bucket.clone()
-        dist.all_reduce(bucket, op=dist.ReduceOp.SUM)
+        with torch.cuda.stream(aad.handle_stream(t)):    # the collective is ordered on the trainer's own stream
+            dist.all_reduce(bucket, op=dist.ReduceOp.SUM)
         torch.cuda.synchronize()
         assert torch.equal(before, bucket)
         t.apply_update(1.0)

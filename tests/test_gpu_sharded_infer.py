@@ -1,0 +1,101 @@
+"""Multi-GPU inference, rehearsed on one GPU: the tile list is sharded over W "ranks" that run one after the other, the
+all-reduce of the exchange step is replaced by the sum of the ranks' packed buffers, and the assembled label map must be
+the single-process annonet_infer() result (planes to float summation-order tolerance; labels equal except exact near-ties)."""
+import numpy as np
+import pytest
+
+import annonet_amd as aa
+from annonet_amd import dist as aad
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("world", [2, 3, 5])
+def test_sharded_inference_assembles_the_single_process_result(world):
+    import torch
+    dev = torch.device("cuda:0")
+    t = aa.TrainingNet(1, 3, aa.ANH_FP32, seed=4)
+    t.SetNetWidth(0.5, 4); t.SetClassCount(3); t.Initialize()
+    net = t.GetRuntimeNet(aa.ANH_FP32)
+    stream = aad.handle_stream(net)   # torch work below is enqueued on the net's own stream
+    rng = np.random.default_rng(world)
+    H, W = 230, 301
+    ov = t.GetRequiredInputDimension()
+    tp = aa.tiling.parameters(96, 112, ov, ov)
+    tiles = aa.tiling.get_tiles(W, H, tp)
+    assert len(tiles) >= 2 * world
+    image = torch.from_numpy(rng.integers(0, 256, (H, W, 3), dtype=np.uint8)).to(dev)
+    gains = [0.0, 0.01, -0.02]
+
+    torch.cuda.synchronize()
+    with torch.cuda.stream(stream):   # one stream for the net's kernels and the torch kernels of the rehearsal
+        want_lab = torch.zeros((H, W), dtype=torch.int16, device=dev)
+        want_pl = torch.zeros((3, H, W), dtype=torch.float32, device=dev)
+        aa.annonet_infer_device(net, image.data_ptr(), H, W, want_lab.data_ptr(), want_pl.data_ptr(), gains=gains, tiling_parameters=tp)
+
+        ex = aad.OverlapExchange(tiles, world, W, H, dev)
+        assert 0 < ex.pixels() < H * W // 2
+        planes, packed = [], []
+        for r in range(world):       # step 1 on every "rank": blend its own tiles (no labels yet)
+            pl = torch.zeros((3, H, W), dtype=torch.float32, device=dev)
+            aa.annonet_infer_device(net, image.data_ptr(), H, W, 0, pl.data_ptr(), gains=gains, tiling_parameters=tp, tiles=aad.shard_tiles(tiles, r, world))
+            planes.append(pl); packed.append(ex.pack(pl))
+        total = packed[0].clone()
+        for p in packed[1:]:
+            total += p                # what dist.all_reduce(SUM) leaves on every rank
+        owner = aad.tile_owner(len(tiles), world)
+        got_lab = np.full((H, W), -1, dtype=np.int64)
+        got_pl = np.zeros((3, H, W), dtype=np.float32)
+        for r in range(world):       # steps 2b + 3: scatter the sums back, label the rank's rows
+            ex.unpack(planes[r], total)
+            lab = torch.zeros((H, W), dtype=torch.int16, device=dev)
+            mine = aad.shard_tiles(tiles, r, world)
+            row0, row1 = max(0, min(x[0][1] for x in mine)), min(H, max(x[0][3] for x in mine) + 1)
+            aa.argmax_device(net, planes[r].data_ptr(), H, W, row0, row1, lab.data_ptr(), gains=gains)
+            torch.cuda.synchronize()
+            lab_np, pl_np = lab.cpu().numpy().view(np.uint16), planes[r].cpu().numpy()
+            for i, (full, _) in enumerate(tiles):   # a rank answers for the pixels its tiles cover
+                if owner[i] != r:
+                    continue
+                l, tp_, rr, b = max(full[0], 0), max(full[1], 0), min(full[2], W - 1), min(full[3], H - 1)
+                sub = got_lab[tp_:b + 1, l:rr + 1]
+                new = lab_np[tp_:b + 1, l:rr + 1].astype(np.int64)
+                assert ((sub == -1) | (sub == new)).all()      # ranks that share a pixel agree on its label
+                got_lab[tp_:b + 1, l:rr + 1] = new
+                got_pl[:, tp_:b + 1, l:rr + 1] = pl_np[:, tp_:b + 1, l:rr + 1]
+    assert (got_lab >= 0).all()
+    want_pl_np, want_lab_np = want_pl.cpu().numpy(), want_lab.cpu().numpy().view(np.uint16).astype(np.int64)
+    span = float(want_pl_np.max() - want_pl_np.min())
+    np.testing.assert_allclose(got_pl, want_pl_np, rtol=0, atol=2e-6 * span)      # (a+b)+(c+d) vs ((a+b)+c)+d in four-tile corners
+    diff = got_lab != want_lab_np
+    if diff.any():
+        g = np.asarray(gains, dtype=np.float32)[:, None, None]
+        srt = np.sort(want_pl_np + g, axis=0)
+        assert ((srt[-1] - srt[-2])[diff] <= 4e-6 * span).all()
+    assert diff.mean() < 1e-4
+
+
+def test_exchange_is_empty_for_one_rank():
+    import torch
+    tiles = aa.tiling.get_tiles(300, 200, aa.tiling.parameters(96, 112, 19, 19))
+    ex = aad.OverlapExchange(tiles, 1, 300, 200, torch.device("cuda:0"))
+    assert ex.pixels() == 0
+    ex.run(torch.zeros((3, 200, 300), device="cuda:0"))     # no process group needed
+
+
+def test_the_default_stream_cannot_be_named_by_set_stream():
+    """torch's default stream has the handle 0, which set_stream reads as "a stream of your own": ordering torch work with a
+    handle goes through handle_stream() instead (the data-parallel all-reduce and the overlap exchange rely on it)."""
+    import torch
+    t = aa.TrainingNet(1, 3, aa.ANH_FP32, seed=1)
+    t.SetNetWidth(0.25, 4); t.SetClassCount(2); t.Initialize()
+    own = t.stream_ptr()
+    assert own != 0
+    t.set_stream(torch.cuda.current_stream().cuda_stream)        # 0 on the default stream
+    assert t.stream_ptr() != 0
+    side = torch.cuda.Stream()
+    t.set_stream(side.cuda_stream)
+    assert t.stream_ptr() == side.cuda_stream
+    assert aad.handle_stream(t).cuda_stream == side.cuda_stream
+    t.set_stream(None)
+    assert t.stream_ptr() not in (0, side.cuda_stream)
