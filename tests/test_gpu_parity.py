@@ -158,6 +158,36 @@ def test_fp32_training_step_matches_oracle(levels, in_ch, classes, scaler, minf)
         np.testing.assert_allclose(got, want, rtol=1e-3, atol=1e-4 * np.abs(want).max())
 
 
+@pytest.mark.parametrize("classes", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("precision", [aa.ANH_FP32, aa.ANH_BF16])
+def test_fused_head_kernel_for_every_class_count(classes, precision):
+    """Full-width nets end in a 32-channel layer, which takes the fused head kernel (1x1 head + loss + head backward in one
+    pass): one exact instantiation each for 2, 3 and 4 classes, the run-time-count body for 1 class, and the unfused
+    kernels beyond 4 — all against the oracle (fp32 tight; bf16 against the bf16-restating oracle)."""
+    o, t = trainer_pair(1, 3, classes, 1.0, 1, precision)
+    rng = np.random.default_rng(40 + classes)
+    d = o.recommended_input_dim(21)
+    img, lab, w, wl = make_batch(rng, 3, d, 3, classes)
+    if precision == aa.ANH_BF16:
+        o.set_bf16_emulation(True)
+    want_loss = o.train_step(img, lab, w)
+    t.StartTraining(list(img), wl)
+    got_loss = t.get_last_loss()
+    head = o.layers[-1]
+    hw = slice(head.w_off, head.w_off + head.cin * head.cout)
+    hb = slice(head.b_off, head.b_off + head.cout)
+    g, gw = t.get_grads(), o.grads
+    if precision == aa.ANH_FP32:
+        assert abs(got_loss - want_loss) <= 2e-5 * max(1.0, abs(want_loss))
+        np.testing.assert_allclose(g, gw, rtol=2e-3, atol=2e-5 * np.abs(gw).max())
+        p, _ = t.get_params()
+        np.testing.assert_allclose(p, o.params, rtol=1e-4, atol=2e-6)
+    else:
+        assert abs(got_loss - want_loss) <= 2e-3 * max(1.0, abs(want_loss))
+        for sl in (hw, hb):   # the head's own gradients come straight out of the fused kernel
+            np.testing.assert_allclose(g[sl], gw[sl], rtol=3e-2, atol=3e-3 * max(np.abs(gw[sl]).max(), 1e-12))
+
+
 def test_fp32_multi_step_training_tracks_oracle():
     o, t = trainer_pair(1, 3, 3, 0.25, 4, aa.ANH_FP32, lr=0.02)
     rng = np.random.default_rng(5)
