@@ -2,7 +2,7 @@
 """Throughput of training on crops cut on the device (anh_trainer_step_crops): the dataset's full images are resident in
 HBM, every step hands 32 crop SPECS (image, rectangle, flips, brightness) to the library — no mini-batch on the host, no
 per-step PCIe upload.  Also times the reference-shaped alternative on the same crops: cut + weighted on the host by the
-CPU oracle's pieces (numpy + set_weights), then StartTraining."""
+same steps done with numpy + the library's host set_weights, then StartTraining."""
 import os
 import sys
 import time
