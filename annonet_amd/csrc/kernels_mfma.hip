@@ -1066,7 +1066,7 @@ struct GeoUp {
 // global-load latency and the MFMA/LDS-read work of a CU overlap instead of adding up.
 // ---------------------------------------------------------------------------------------------------------------
 template <class G, int NT, int KIND>
-__global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tiles_x, int tiles_y, int flip, long long* prof) {
+__global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tiles_x, int tiles_y, int flip, long long* prof, int wres) {
     // per-phase wall-clock accounting, compiled in with -DANH_WS_PROFILE (ANH_WS_PROF=1 then prints one line per launch)
 #ifdef ANH_WS_PROFILE
     long long t_a = 0, t_b = 0, t_c = 0, t0_;
@@ -1079,7 +1079,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
     constexpr int C_OUT = NT * 32, NP = (G::RECS * 4 + 255) / 256, W_ITEMS = 9 * C_OUT * 4, NW = (W_ITEMS + 255) / 256;
     constexpr int X_BYTES_ = G::RECS * 64, W_BYTES = 9 * C_OUT * 64, BUF = X_BYTES_ + W_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* tab = reinterpret_cast<float*>(smem + 2 * BUF);  // [a_scale | a_shift | b_scale | b_shift][c_red]
+    // LDS layout.  Streaming form: [X | W] [X | W] tables — the filter slab of every item travels with its patch.
+    // Resident form (wres; the filter slabs of ALL reduction slabs fit beside two patches, i.e. 64 reduction channels):
+    // [X] [X] [W slab 0] [W slab 1] ... tables — the producers stage the filter once and then move patches only.
+    const int n_slabs_l = a.c_red >> 5;
+    const int x_stride = wres ? X_BYTES_ : BUF;                                   // between the two patch buffers
+    const int tab_off = wres ? 2 * X_BYTES_ + n_slabs_l * W_BYTES : 2 * BUF;
+    float* tab = reinterpret_cast<float*>(smem + tab_off);  // [a_scale | a_shift | b_scale | b_shift][c_red]
 
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const bool producer = wave >= 4;
@@ -1144,7 +1150,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
             const int tl = rec / C_OUT, co = rec - tl * C_OUT;
             const int tap = flip ? 8 - tl : tl;
             wsrc_off[j] = (tap * a.c_out + co_base + co) * c_red + c16 * 8;
-            wdst[j] = X_BYTES_ + rec * 64 + ((c16 ^ ((co >> 2) & 3)) << 4);
+            wdst[j] = rec * 64 + ((c16 ^ ((co >> 2) & 3)) << 4);   // within a filter slab
         }
         RawChunk<KIND> praw[NP];
         u32x4 wraw[NW];  // a native vector type: hipcc keeps a HIP uint4 that is only copied (never unpacked) in scratch
@@ -1168,14 +1174,24 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
                 for (int j = 0; j < NW; ++j) wraw[j] = *reinterpret_cast<const u32x4*>(wsrc + wsrc_off[j] + cc);
             }
         };
-        if (tile < n_tiles) fetch(tile, 0, true);
+        if (wres && tile < n_tiles) {   // resident form: every filter slab goes to its own LDS block once
+            for (int sl = 0; sl < n_slabs; ++sl) {
+#pragma unroll
+                for (int j = 0; j < NW; ++j) wraw[j] = *reinterpret_cast<const u32x4*>(wsrc + wsrc_off[j] + sl * 32);
+#pragma unroll
+                for (int j = 0; j < NW; ++j)
+                    if ((tid >> 2) + 64 * j < 9 * C_OUT) *reinterpret_cast<u32x4*>(smem + 2 * X_BYTES_ + sl * W_BYTES + wdst[j]) = wraw[j];
+            }
+        }
+        if (tile < n_tiles) fetch(tile, 0, !wres);
         while (tile < n_tiles) {
             int ntile = tile, nslab = slab + 1;
             if (nslab == n_slabs) { nslab = 0; ntile += gridDim.x; }
-            char* lbuf = smem + (it & 1) * BUF;
+            char* lbuf = smem + (it & 1) * x_stride;
+            char* wbuf = lbuf + X_BYTES_;     // streaming form only
             TICK();
             // a single-slab layer's filter block goes into both buffers once (its registers are not refetched)
-            const bool stage_w = it < 2 || n_slabs > 1;
+            const bool stage_w = !wres && (it < 2 || n_slabs > 1);
             {
                 float sa[8], ta[8], sb[8], tb[8], q0[8], q1[8], q2[8];
                 if (KIND != SRC_RAW) {
@@ -1199,7 +1215,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
                 if (stage_w) {
 #pragma unroll
                     for (int j = 0; j < NW; ++j)
-                        if ((tid >> 2) + 64 * j < 9 * C_OUT) *reinterpret_cast<u32x4*>(lbuf + wdst[j]) = wraw[j];
+                        if ((tid >> 2) + 64 * j < 9 * C_OUT) *reinterpret_cast<u32x4*>(wbuf + wdst[j]) = wraw[j];
                 }
             }
 #ifdef ANH_WS_PROFILE
@@ -1207,7 +1223,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
 #endif
             TOCK(t_a);
             TICK();
-            if (ntile < n_tiles) fetch(ntile, nslab, n_slabs > 1);
+            if (ntile < n_tiles) fetch(ntile, nslab, !wres && n_slabs > 1);
             TOCK(t_b);
             TICK();
             __syncthreads();  // buffer it & 1 is full; the consumers are done with buffer (it + 1) & 1
@@ -1219,7 +1235,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
         G::init(b0, smem, wave, col, half);
         const char* wb0[2];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) wb0[ks] = swz_addr(smem + X_BYTES_, col, col >> 2, ks, half);
+        for (int ks = 0; ks < 2; ++ks) wb0[ks] = swz_addr(smem, col, col >> 2, ks, half);   // + the slab's block offset per item
         f32x16 acc[G::ACC][NT];
         u32x4 old[G::ACC][NT][2];   // prefetched old values of a read-modify-write destination (GeoUp)
         u32x4 yraw[G::ACC][NT][2];  // prefetched raw outputs y of the layer whose da is written (fused bn backward reduction)
@@ -1260,13 +1276,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
         while (tile < n_tiles) {
             int ntile = tile, nslab = slab + 1;
             if (nslab == n_slabs) { nslab = 0; ntile += gridDim.x; }
-            const int boff = (it & 1) * BUF;
+            const int boff = (it & 1) * x_stride;
+            const int woff = wres ? 2 * X_BYTES_ + slab * W_BYTES : boff + X_BYTES_;
             typename G::Bases b;
 #pragma unroll
             for (int i = 0; i < G::NB; ++i)
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) b.x[i][ks] = b0.x[i][ks] + boff;
-            const char* wb[2] = {wb0[0] + boff, wb0[1] + boff};
+            const char* wb[2] = {wb0[0] + woff, wb0[1] + woff};
             if (slab == 0) {
 #pragma unroll
                 for (int g = 0; g < G::ACC; ++g)
@@ -1365,16 +1382,24 @@ template <class G, int NT>
 void launch_ws(const ConvArgs& a, int tiles_x, int tiles_y, int flip, hipStream_t s) {
     const int n_tiles = tiles_x * tiles_y * a.n, groups = a.c_out / (NT * 32);
     const dim3 grid((unsigned)std::max(1, std::min(n_tiles, ws_target_wgs() / groups)), (unsigned)groups), block(512);
-    const size_t lds = 2 * ((size_t)G::RECS * 64 + (size_t)9 * NT * 32 * 64) + (size_t)a.c_red * (a.src.kind == SRC_BNBWD ? 28 : 16) + (size_t)NT * 32 * 16;
+    const size_t tables = (size_t)a.c_red * (a.src.kind == SRC_BNBWD ? 28 : 16) + (size_t)NT * 32 * 16;
+    const size_t x_bytes = (size_t)G::RECS * 64, w_bytes = (size_t)9 * NT * 32 * 64;
+    // filter-resident form: two reduction slabs (64 channels) whose filter blocks fit beside two patches; the end-of-kernel
+    // statistics reduction borrows 32 NT KiB from the start of the buffer
+    static const bool resident_on = !(getenv("ANH_WS_WEIGHT_RESIDENT") && atoi(getenv("ANH_WS_WEIGHT_RESIDENT")) == 0);
+    const int n_slabs = a.c_red >> 5;
+    const size_t resident_lds = 2 * x_bytes + (size_t)n_slabs * w_bytes + tables;
+    const int wres = resident_on && n_slabs >= 2 && resident_lds <= 160 * 1024 && 2 * x_bytes + (size_t)n_slabs * w_bytes >= (size_t)32 * 1024 * NT;
+    const size_t lds = wres ? resident_lds : 2 * (x_bytes + w_bytes) + tables;
     auto launch = [&](auto kernel) {
         ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), lds);
 #ifndef ANH_WS_PROFILE
-        hipLaunchKernelGGL(kernel, grid, block, lds, s, a, tiles_x, tiles_y, flip, (long long*)nullptr);
+        hipLaunchKernelGGL(kernel, grid, block, lds, s, a, tiles_x, tiles_y, flip, (long long*)nullptr, wres);
 #else
         static const int prof_on = getenv("ANH_WS_PROF") ? atoi(getenv("ANH_WS_PROF")) : 0;
         static long long* prof = nullptr;
         if (prof_on && !prof) HIP_CHECK(hipMalloc(&prof, 1024 * 8 * 4 * sizeof(long long)));
-        hipLaunchKernelGGL(kernel, grid, block, lds, s, a, tiles_x, tiles_y, flip, prof_on ? prof : nullptr);
+        hipLaunchKernelGGL(kernel, grid, block, lds, s, a, tiles_x, tiles_y, flip, prof_on ? prof : nullptr, wres);
         if (prof_on) {
             HIP_CHECK(hipStreamSynchronize(s));
             const int nwg = grid.x * grid.y;

@@ -4,7 +4,8 @@ The switches are environment variables read once per process
 tests/helpers/run_train_steps.py in its own process: 3 bf16 steps on a seeded batch of 6 tiles 99x99.
   * variants that only move work between streams or kernels WITHOUT changing any summation order are bit-identical to
     the default: one stream instead of two; the bn + relu backward applied in the backward-data conv's prologue; the
-    stem's filter gradient queued on the second stream instead of the main one;
+    stem's filter gradient queued on the second stream instead of the main one; the conv filter slabs streamed through LDS
+    with every patch instead of staying resident;
   * variants that change a summation order (bn statistics / bn backward sums in a conv epilogue vs. the separate
     kernels; the classic one-tile conv kernels; dy materialised for the stem) agree to bf16-training tolerance.
 """
@@ -38,6 +39,7 @@ def default_run(tmp_path_factory):
     ("one_stream", {"ANH_CONCURRENT_WGRAD": "0"}),
     ("bn_backward_in_conv_prologue", {"ANH_FUSE_BN_BWD_APPLY": "1"}),
     ("stem_filter_gradient_on_second_stream", {"ANH_STEM_WGRAD_MAIN": "0"}),
+    ("conv_filters_streamed_with_every_patch", {"ANH_WS_WEIGHT_RESIDENT": "0"}),
 ])
 def test_schedule_is_bit_identical(tmp_path, default_run, name, env):
     got = run_variant(tmp_path, name, env)
