@@ -148,6 +148,30 @@ class RuntimeNet {
     OutputTensor out_;
 };
 
+// Extension (no counterpart in dlib-dnn-pimpl-wrapper): the dataset's full images resident in HBM, so that the loader
+// threads of annonet_train_main.cpp:504-553 push crop SPECS (rectangle, flips, brightness — their own dlib::rand draws) instead
+// of crops, and TrainingNet::StartTrainingOnCrops cuts the mini-batch on the device (randomly_crop_image, :110-232).
+class Dataset {
+  public:
+    Dataset() { check(anh_dataset_create(kInputChannels, &h_)); }
+    Dataset(const Dataset&) = delete;
+    Dataset& operator=(const Dataset&) = delete;
+    ~Dataset() { if (h_) anh_dataset_destroy(h_); }
+    // full image + its label image (sample.input_image, sample.label_image); returns the index crop specs refer to
+    template <typename label_image_type>
+    int Add(const input_type& image, const label_image_type& label_image) {
+        if (image.nr() != label_image.nr() || image.nc() != label_image.nc()) throw std::runtime_error("annonet_hip: image and label image sizes differ");
+        int index = -1;
+        check(anh_dataset_add(h_, reinterpret_cast<const uint8_t*>(&*image.begin()), reinterpret_cast<const uint16_t*>(&*label_image.begin()),
+                              (int)image.nr(), (int)image.nc(), &index));
+        return index;
+    }
+    anh_dataset* handle() const { return h_; }
+
+  private:
+    anh_dataset* h_ = nullptr;
+};
+
 class TrainingNet {
   public:
     TrainingNet() { check(anh_trainer_create(&h_)); check(anh_trainer_set_levels(h_, DLIB_DNN_PIMPL_WRAPPER_LEVEL_COUNT)); check(anh_trainer_set_input_channels(h_, kInputChannels)); }
@@ -186,6 +210,11 @@ class TrainingNet {
             lp[i] = reinterpret_cast<const anh_wlabel*>(&*labels[i].begin());
         }
         check(anh_trainer_step(h_, ip.data(), lp.data(), (int)samples.size(), (int)nr, (int)nc));
+    }
+    // Extension: one optimiser step on crops cut on the device from `dataset` (see Dataset); dim = crop side (:382)
+    void StartTrainingOnCrops(const Dataset& dataset, const std::vector<anh_crop_spec>& crops, int dim, double class_weight, double image_weight) {
+        if (crops.empty()) throw std::runtime_error("annonet_hip: empty mini-batch");
+        check(anh_trainer_step_crops(h_, dataset.handle(), crops.data(), (int)crops.size(), dim, class_weight, image_weight));
     }
     RuntimeNet GetRuntimeNet(int precision = ANH_BF16) const {  // :558, by value
         anh_runtime* rt = nullptr;

@@ -58,6 +58,25 @@ int main() {
     }
     for (int step = 0; step < 3; ++step) training_net.StartTraining(samples, labels);
     REQUIRE(training_net.GetLearningRate() == 0.1);
+    {   // the device-side data path: a full image resident in HBM, a step from crop specs (no host mini-batch)
+        NetPimpl::Dataset dataset;
+        NetPimpl::input_type full;
+        dlib::matrix<uint16_t> full_labels;
+        full.set_size(120, 150);
+        full_labels.set_size(120, 150);
+        for (long r = 0; r < 120; ++r)
+            for (long c = 0; c < 150; ++c) {
+                seed = seed * 1664525u + 1013904223u;
+                full(r, c) = dlib::rgb_pixel{(unsigned char)(seed >> 8), (unsigned char)(seed >> 16), (unsigned char)(seed >> 24)};
+                full_labels(r, c) = (uint16_t)((r / 16 + c / 16) % 3);
+            }
+        REQUIRE(dataset.Add(full, full_labels) == 0);
+        std::vector<anh_crop_spec> crops = {{0, 10, 5, 0, 0, 1.0}, {0, -7, 90, 1, 0, 1.1}, {0, 120, -3, 0, 1, 1.0}, {0, 60, 60, 1, 1, 0.9}};
+        training_net.StartTrainingOnCrops(dataset, crops, dim, 0.5, 0.5);
+        bool bad = false;
+        try { crops[0].image = 3; training_net.StartTrainingOnCrops(dataset, crops, dim, 0.5, 0.5); } catch (const std::exception&) { bad = true; }
+        REQUIRE(bad);
+    }
     const NetPimpl::RuntimeNet runtime_net = training_net.GetRuntimeNet();
     std::ostringstream serialized;
     runtime_net.Serialize(serialized);
