@@ -1065,7 +1065,9 @@ struct GeoUp {
 // One workgroup barrier per item hands a filled buffer over and releases the other one, so the staging VALU work, the
 // global-load latency and the MFMA/LDS-read work of a CU overlap instead of adding up.
 // ---------------------------------------------------------------------------------------------------------------
-template <class G, int NT, int KIND>
+// FWD: the forward-only form — no prefetched epilogue operands (old values of an accumulating destination, y of the
+// layer behind `out`), whose registers the four-accumulator-group geometry at NT = 2 needs for its bn statistics sums.
+template <class G, int NT, int KIND, bool FWD = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tiles_x, int tiles_y, int flip, long long* prof, int wres) {
     // per-phase wall-clock accounting, compiled in with -DANH_WS_PROFILE (ANH_WS_PROF=1 then prints one line per launch)
 #ifdef ANH_WS_PROFILE
@@ -1094,9 +1096,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
     const int co_base = blockIdx.y * C_OUT;
     const int H = a.h_in, W = a.w_in, c_red = a.c_red;
     const int n_slabs = c_red >> 5, n_tiles = tiles_x * tiles_y * a.n;
-    constexpr bool CAN_STATS = G::ACC * NT <= 4;  // register budget of the consumer waves
+    constexpr bool CAN_STATS = G::ACC * NT <= 4 || FWD;  // register budget of the consumer waves
     const bool fuse_stats = CAN_STATS && a.stat_partials != nullptr;   // forward: bn statistics of the output
-    const bool fuse_bnred = CAN_STATS && a.bnred_partials != nullptr;  // backward-data: dgamma / dbeta sums of the layer `out` belongs to
+    const bool fuse_bnred = !FWD && CAN_STATS && a.bnred_partials != nullptr;  // backward-data: dgamma / dbeta sums of the layer `out` belongs to
     const int stat_mode = fuse_stats ? 1 : fuse_bnred ? 2 : 0;
     float* bnc = tab + c_red * (KIND == SRC_BNBWD ? 7 : 4);            // [scale | shift | mean | invstd][C_OUT] of this workgroup's channels
 
@@ -1237,15 +1239,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) wb0[ks] = swz_addr(smem, col, col >> 2, ks, half);   // + the slab's block offset per item
         f32x16 acc[G::ACC][NT];
-        u32x4 old[G::ACC][NT][2];   // prefetched old values of a read-modify-write destination (GeoUp)
-        u32x4 yraw[G::ACC][NT][2];  // prefetched raw outputs y of the layer whose da is written (fused bn backward reduction)
+        u32x4 old[FWD ? 1 : G::ACC][NT][2];   // prefetched old values of a read-modify-write destination (GeoUp)
+        u32x4 yraw[FWD ? 1 : G::ACC][NT][2];  // prefetched raw outputs y of the layer whose da is written (fused bn backward reduction)
         // The 32-channel read-modify-write kernel (GeoUp, NT = 1: HBM-bound, short MFMA phase) keeps the old values a whole
         // tile ahead: those of tile t + 1 are requested while tile t runs, so their latency is covered by a full item and
         // not by the MFMA phase alone (measured: 133 -> 120 us on the 32x64 stride-2 backward-data; the same depth for the
         // y operand of the stride-1 kernels measured slower, 93 -> 105 us, and is not compiled).
-        constexpr bool DEEP = NT == 1 && G::RMW_PREFETCH, DEEP_Y = false;
+        constexpr bool DEEP = !FWD && NT == 1 && G::RMW_PREFETCH, DEEP_Y = false;
         u32x4 old_n[DEEP ? G::ACC : 1][NT][2], yraw_n[DEEP_Y ? G::ACC : 1][NT][2];
-        const bool rmw_any = G::RMW_PREFETCH && a.out_accumulate;
+        const bool rmw_any = !FWD && G::RMW_PREFETCH && a.out_accumulate;
         const bool pre_any = rmw_any || fuse_bnred;
         auto prefetch_epilogue = [&](int t, auto& o, auto& y, bool want_old, bool want_y) __attribute__((always_inline)) {
             const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, n = t / (tiles_x * tiles_y);
@@ -1260,8 +1262,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                     for (int s2 = 0; s2 < 2; ++s2) {
-                        if (want_old) o[g][nt][s2] = *reinterpret_cast<const u32x4*>(out + e0 + nt * 32 + 16 * s2);
-                        if (want_y) y[g][nt][s2] = *reinterpret_cast<const u32x4*>(yl + e0 + nt * 32 + 16 * s2);
+                        if constexpr (!FWD) {
+                            if (want_old) o[g][nt][s2] = *reinterpret_cast<const u32x4*>(out + e0 + nt * 32 + 16 * s2);
+                            if (want_y) y[g][nt][s2] = *reinterpret_cast<const u32x4*>(yl + e0 + nt * 32 + 16 * s2);
+                        }
                     }
             }
         };
@@ -1316,7 +1320,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
                 for (int g = 0; g < G::ACC; ++g) {
                     size_t pix; bool valid;
                     G::out_pixel(g, a, n, ty, tx, wave, col, pix, valid);
-                    store_pixel_tiles_rmw<NT>(acc[g], a, pix, valid, half, co_base, old[g], rmw, stat, stat_mode, yraw[g], bnc);
+                    store_pixel_tiles_rmw<NT>(acc[g], a, pix, valid, half, co_base, old[FWD ? 0 : g], rmw, stat, stat_mode, yraw[FWD ? 0 : g], bnc);
                 }
                 if constexpr (DEEP) {
                     if (pre_any) {
@@ -1417,6 +1421,22 @@ void launch_ws(const ConvArgs& a, int tiles_x, int tiles_y, int flip, hipStream_
         }
 #endif
     };
+    // the forward-only form exists where it buys something: four accumulator groups at NT = 2 (cont forward), whose bn
+    // statistics sums take the registers the backward forms spend on prefetched epilogue operands
+    constexpr bool HAS_FWD_FORM = G::ACC * NT > 4;
+    const bool fwd_form = HAS_FWD_FORM && a.stat_partials && !a.bnred_partials && !a.out_accumulate && !a.out2;
+    if constexpr (HAS_FWD_FORM) {
+        if (fwd_form) {
+            switch (a.src.kind) {
+                case SRC_RAW: launch(conv3x3_ws_kernel<G, NT, SRC_RAW, true>); break;
+                case SRC_ACT: launch(conv3x3_ws_kernel<G, NT, SRC_ACT, true>); break;
+                case SRC_ACT2: launch(conv3x3_ws_kernel<G, NT, SRC_ACT2, true>); break;
+                default: fail(ANH_ERR_INTERNAL, "conv_ws: no forward-only form for this source kind");
+            }
+            HIP_CHECK(hipGetLastError());
+            return;
+        }
+    }
     switch (a.src.kind) {
         case SRC_RAW: launch(conv3x3_ws_kernel<G, NT, SRC_RAW>); break;
         case SRC_ACT: launch(conv3x3_ws_kernel<G, NT, SRC_ACT>); break;
@@ -2061,7 +2081,8 @@ int conv_fused_stat_blocks(const ConvArgs& a) {
     if (stem_mfma_ok(a)) return on && !a.out_accumulate && !a.out2 ? stem_mfma_blocks(a) : 0;
     const ConvPlan p = conv_plan(a);
     const int acc = p.geo == 0 ? 2 : p.geo == 1 ? 1 : 4;
-    if (!on || p.form != 2 || acc * p.nt > 4 || a.out_accumulate || a.out2) return 0;
+    if (!on || p.form != 2 || a.out_accumulate || a.out2) return 0;
+    if (acc * p.nt > 4 && a.src.kind != SRC_RAW && a.src.kind != SRC_ACT && a.src.kind != SRC_ACT2) return 0;   // (the forward-only form)
     return p.grid_x;
 }
 
