@@ -104,6 +104,51 @@ def test_two_rank_data_parallel_step_over_gloo():
     assert abs(out["bucket"][-1] - want_loss) < 1e-6
 
 
+def exchange_worker(rank, world, port, out):
+    """The exchange step of sharded inference over a real process group: every rank holds planes that are non-zero only
+    inside its own tiles (stand-ins for its blended partial sums); after OverlapExchange.run the pixels shared with other
+    ranks hold the sum over ranks, every other pixel is untouched."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    W, H, K = 301, 230, 3
+    tiles = orc.get_tiles(W, H, 96, 112, 19, 19)
+    owner = aad.tile_owner(len(tiles), world)
+    planes = np.zeros((K, H, W), dtype=np.float32)
+    rng = np.random.default_rng(7 + rank)
+    for (full, _), r in zip(tiles, owner):
+        if r == rank:
+            t, b, l, rr = max(full[1], 0), min(full[3], H - 1), max(full[0], 0), min(full[2], W - 1)
+            planes[:, t:b + 1, l:rr + 1] += rng.normal(size=(K, b - t + 1, rr - l + 1)).astype(np.float32)
+    before = planes.copy()
+    tens = torch.from_numpy(planes)
+    ex = aad.OverlapExchange(tiles, world, W, H, torch.device("cpu"))
+    ex.run(tens)
+    gathered = [torch.zeros((K, H, W)) for _ in range(world)]
+    dist.all_gather(gathered, torch.from_numpy(before))
+    if rank == 0:
+        out["after"] = tens.numpy().copy()
+        out["before"] = [g.numpy() for g in gathered]
+        out["pixels"] = ex.pixels()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_overlap_exchange_over_gloo():
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(exchange_worker, args=(2, free_port(), out), nprocs=2, join=True)
+    W, H = 301, 230
+    tiles = orc.get_tiles(W, H, 96, 112, 19, 19)
+    shared = np.zeros((H, W), dtype=bool)
+    for (l, t, r, b) in aad.cross_rank_overlaps(tiles, 2, W, H):
+        shared[t:b + 1, l:r + 1] = True
+    assert out["pixels"] == int(shared.sum()) > 0
+    b0, b1 = out["before"]
+    want = np.where(shared[None], b0 + b1, b0)      # rank 0's planes: sums where shared, its own values elsewhere
+    np.testing.assert_array_equal(out["after"], want)
+
+
 def test_cross_rank_overlaps_are_exactly_the_pixels_shared_between_ranks():
     """The exchange step of sharded inference moves the plane sums of these pixels and no others."""
     W, H = 301, 230
