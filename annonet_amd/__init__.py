@@ -10,4 +10,4 @@ from .netpimpl import (Dataset, RuntimeNet, TrainingNet, argmax_device, annonet_
                        net_config, net_layers,
                        op_conv_backward_data, op_conv_backward_data_bn, op_conv_backward_filter, op_conv_backward_filter_bn,
                        op_conv_forward, op_conv_forward_stats, outpaint,
-                       random_rect_containing_point, set_weights, tiling)
+                       random_rect_containing_point, set_devices, set_weights, shard_range, cross_replica_overlaps, tiling)

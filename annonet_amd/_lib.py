@@ -148,6 +148,12 @@ _SIGNATURES = {  # ConvDesc / OpInput are defined above
     "anh_profile_set_sampling": (C.c_int, [_P, C.c_int, C.c_int]),
     "anh_profile_reset": (C.c_int, [_P, C.c_int]),
     "anh_profile_count": (C.c_int, [_P, C.c_int]),
+    "anh_trainer_replica_params": (C.c_int, [_P, C.c_int, _P, C.c_int64]),
+    "anh_set_devices": (C.c_int, [C.POINTER(C.c_int), C.c_int]),
+    "anh_handle_replicas": (C.c_int, [_P, C.c_int]),
+    "anh_shard_range": (C.c_int, [C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "anh_cross_replica_overlaps": (C.c_int, [C.POINTER(Tile), C.c_size_t, C.c_int, C.c_int, C.c_int, C.POINTER(C.POINTER(Rect)), C.POINTER(C.c_size_t)]),
+    "anh_profile_launch_order": (C.c_int, [_P, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "anh_profile_entry": (C.c_int, [_P, C.c_int, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "anh_op_conv_forward": (C.c_int, [C.c_int, C.POINTER(ConvDesc), C.c_int, C.c_int, C.c_int, C.POINTER(OpInput), C.POINTER(OpInput), _P, _P, _P, C.POINTER(C.c_int)]),
     "anh_op_conv_backward_data": (C.c_int, [C.c_int, C.POINTER(ConvDesc), C.c_int, C.c_int, C.c_int, _P, _P, _P, C.POINTER(C.c_int)]),

@@ -15,6 +15,7 @@
 #include "common.h"
 #include "engine.h"
 #include "hostlogic.h"
+#include "multidev.h"
 
 using namespace anh;
 
@@ -30,7 +31,7 @@ int guarded(F&& f) {
 }
 
 const char kRuntimeMagic[8] = {'A', 'N', 'H', 'R', 'T', '0', '0', '1'};
-const char kStateMagic[8] = {'A', 'N', 'H', 'T', 'S', '0', '0', '1'};
+const char kStateMagic[8] = {'A', 'N', 'H', 'T', 'S', '0', '0', '2'};   // 002: + bn update counters, schedule counter, unrecorded losses
 
 struct BlobHeader {
     char magic[8];
@@ -43,7 +44,28 @@ struct BlobHeader {
 namespace anh { void set_last_error(const std::string& message) { g_error = message; } }
 
 struct anh_runtime {
-    std::unique_ptr<Engine> eng;
+    std::unique_ptr<Engine> eng;          // replica 0 (the only one unless anh_set_devices named several devices)
+    // anh_set_devices: one process drives several GPUs.  Replica r lives on devices[r]; every replica holds the same weights;
+    // annonet_infer() shards its tile list over them (infer_multi below).  Empty list = the creating thread's current device.
+    std::vector<int> devices;
+    struct Replica { std::unique_ptr<Engine> eng; };
+    std::vector<Replica> extra;           // replicas 1 .. R-1
+    std::unique_ptr<Collective> coll;
+    struct Exchange { DevBuf packed, rects, offsets; };
+    std::vector<Exchange> exchange;       // per replica: scratch of the overlap exchange
+    size_t replicas() const { return 1 + extra.size(); }
+    int device_of(size_t r) const { return devices.empty() ? -1 : devices[r]; }
+    Engine& replica(size_t r) { return r == 0 ? *eng : *extra[r - 1].eng; }
+    void build(const anh_net_config& cfg) {
+        devices = selected_devices();
+        { DeviceScope scope(device_of(0)); eng = std::make_unique<Engine>(cfg, false); }
+        for (size_t r = 1; r < devices.size(); ++r) { DeviceScope scope(devices[r]); extra.push_back(Replica{std::make_unique<Engine>(cfg, false)}); }
+        if (devices.size() > 1) coll = std::make_unique<Collective>(devices);
+        exchange.resize(replicas());
+    }
+    void set_params_all(const float* params, const float* running) {
+        for (size_t r = 0; r < replicas(); ++r) { DeviceScope scope(device_of(r)); replica(r).set_params(params, running); }
+    }
     // host-buffer annonet_infer(): image strips go up and label strips come down through small pinned rings while the tiles
     // compute, so that neither transfer is exposed (anh_infer below)
     static constexpr int kRing = 3;
@@ -60,6 +82,7 @@ struct anh_runtime {
         for (auto ev : strip_events) (void)hipEventDestroy(ev);
         if (copy_up) (void)hipStreamDestroy(copy_up);
         if (copy_down) (void)hipStreamDestroy(copy_down);
+        for (size_t r = extra.size(); r-- > 0;) { DeviceScope scope(device_of(r + 1)); extra[r].eng.reset(); exchange[r + 1] = Exchange{}; }
     }
 };
 
@@ -76,12 +99,17 @@ struct anh_trainer {
     bool verbose = false;
     unsigned long steps = 0;
     double last_loss = 0;
-    // losses travel back asynchronously: pinned slots + events, consumed in order
+    // Losses travel back asynchronously (pinned slots + events) and enter the learning-rate schedule at a FIXED lag: the
+    // update of step k first records the loss of step k - kLossLag (waiting for it if it has not arrived).  Which loss drives
+    // which lr decision therefore does not depend on GPU / host timing: runs are reproducible and the ranks of a data-parallel
+    // job (who all see the same all-reduced loss) shrink their rate at the same step.
+    static constexpr unsigned long kLossLag = 4;
     float* loss_ring = nullptr;
-    struct PendingLoss { hipEvent_t ev; int slot; };
-    std::deque<PendingLoss> pending;
+    struct PendingLoss { hipEvent_t ev; int slot; unsigned long step; bool arrived; double value; };
+    std::deque<PendingLoss> pending;   // step order; not yet recorded into the schedule
     std::vector<hipEvent_t> free_events;
     int next_slot = 0;
+    bool resume_pending = false;       // SetSynchronizationFile named a file: resume from it once the net structure is final
     // Host-buffer steps (StartTraining): two staging sets, each a pinned host block + a device block holding
     // [images | labels u16 | weights f32].  Step k packs into set k&1 while the GPU still runs step k-1, uploads it on a copy
     // stream and chains the compute behind the upload with events; the call returns once the inputs are packed
@@ -95,6 +123,18 @@ struct anh_trainer {
     StageSet stage[2];
     hipStream_t copy_stream = nullptr;
     unsigned long host_steps = 0;
+    // anh_set_devices: data-parallel training from ONE process (annonet_train_main.cpp:583-614 stays as it is).  Replica r lives on
+    // devices[r] with its own staging sets; StartTraining splits the mini-batch along N, one all-reduce (RCCL) sums the flat
+    // gradient buckets, every replica applies the identical update.  Batch-norm statistics are per replica.
+    std::vector<int> devices;
+    struct Replica { std::unique_ptr<Engine> eng; StageSet stage[2]; hipStream_t copy_stream = nullptr; };
+    std::vector<std::unique_ptr<Replica>> extra;   // replicas 1 .. R-1
+    std::unique_ptr<Collective> coll;
+    size_t replicas() const { return devices.size() > 1 ? devices.size() : 1; }
+    int device_of(size_t r) const { return devices.empty() ? -1 : devices[r]; }
+    Engine& replica(size_t r) { return r == 0 ? *eng : *extra[r - 1]->eng; }
+    StageSet* stage_of(size_t r) { return r == 0 ? stage : extra[r - 1]->stage; }
+    hipStream_t& copy_stream_of(size_t r) { return r == 0 ? copy_stream : extra[r - 1]->copy_stream; }
 
     bool initialized = false, dirty = false;
     // The reference configures AFTER Initialize() (annonet_train_main.cpp:400-410: Initialize, SetNetWidth, ..., SetClassCount);
@@ -103,30 +143,50 @@ struct anh_trainer {
         if (!initialized) fail(ANH_ERR_INVALID, "TrainingNet::Initialize has not been called");
         if (!eng || dirty) {
             if (steps > 0) fail(ANH_ERR_INVALID, "the net structure cannot change once training has started");
-            eng = std::make_unique<Engine>(cfg, true);
-            eng->random_init(seed);
+            { DeviceScope scope(device_of(0)); eng = std::make_unique<Engine>(cfg, true); eng->random_init(seed); }
+            extra.clear();
+            for (size_t r = 1; r < replicas(); ++r) {   // same seed: every replica starts from the same weights
+                DeviceScope scope(device_of(r));
+                auto rep = std::make_unique<Replica>();
+                rep->eng = std::make_unique<Engine>(cfg, true);
+                rep->eng->random_init(seed);
+                extra.push_back(std::move(rep));
+            }
+            if (replicas() > 1 && !coll) coll = std::make_unique<Collective>(devices);
             dirty = false;
+        }
+        if (resume_pending) {   // the reference names the file BEFORE SetClassCount (annonet_train_main.cpp:400-405): resume on first use
+            resume_pending = false;
+            std::ifstream probe(sync_path, std::ios::binary);
+            if (probe.good()) { probe.close(); resume(); }
         }
         return *eng;
     }
+    void resume();
     void structural_change() { if (steps > 0) fail(ANH_ERR_INVALID, "the net structure cannot change once training has started"); dirty = true; }
-    void consume(bool wait) {
-        while (!pending.empty()) {
-            PendingLoss p = pending.front();
-            if (wait) HIP_CHECK(hipEventSynchronize(p.ev));
-            else {
-                hipError_t q = hipEventQuery(p.ev);
-                if (q == hipErrorNotReady) { (void)hipGetLastError(); break; }
-                HIP_CHECK(q);
-            }
+    void arrive(PendingLoss& p) {   // blocks until the loss of that step is on the host
+        if (p.arrived) return;
+        HIP_CHECK(hipEventSynchronize(p.ev));
+        p.value = (double)loss_ring[p.slot];
+        p.arrived = true;
+        free_events.push_back(p.ev);
+        p.ev = nullptr;
+    }
+    // records the losses of steps <= upto into the schedule, oldest first
+    void record_until(unsigned long upto) {
+        while (!pending.empty() && pending.front().step <= upto) {
+            arrive(pending.front());
+            sched.record(pending.front().value);
             pending.pop_front();
-            free_events.push_back(p.ev);
-            last_loss = (double)loss_ring[p.slot];
-            sched.record(last_loss);
         }
     }
+    // waits for every loss in flight (host queries: GetLastLoss, state file) WITHOUT recording any of them early
+    void fetch_all() {
+        for (auto& p : pending) arrive(p);
+        if (!pending.empty()) last_loss = pending.back().value;
+    }
     ~anh_trainer() {
-        for (auto& p : pending) (void)hipEventDestroy(p.ev);
+        for (auto& p : pending) if (p.ev) (void)hipEventDestroy(p.ev);
         for (auto e : free_events) (void)hipEventDestroy(e);
         if (loss_ring) (void)hipHostFree(loss_ring);
         for (auto& st : stage) {
@@ -135,6 +195,18 @@ struct anh_trainer {
             if (st.consumed) (void)hipEventDestroy(st.consumed);
         }
         if (copy_stream) (void)hipStreamDestroy(copy_stream);
+        for (size_t r = extra.size(); r-- > 0;) {
+            DeviceScope scope(device_of(r + 1));
+            Replica& rep = *extra[r];
+            rep.eng.reset();
+            for (auto& st : rep.stage) {
+                st.dev.release();
+                if (st.pinned) (void)hipHostFree(st.pinned);
+                if (st.uploaded) (void)hipEventDestroy(st.uploaded);
+                if (st.consumed) (void)hipEventDestroy(st.consumed);
+            }
+            if (rep.copy_stream) (void)hipStreamDestroy(rep.copy_stream);
+        }
     }
 };
 
@@ -210,6 +282,26 @@ int anh_device_count(void) {
 int anh_set_device(int device) {
     return guarded([&] { HIP_CHECK(hipSetDevice(device)); });
 }
+int anh_set_devices(const int* devices, int n) {
+    return guarded([&] { select_devices(devices, n); if (n >= 1) HIP_CHECK(hipSetDevice(devices[0])); });
+}
+int anh_handle_replicas(void* handle, int is_trainer) {
+    if (!handle) return 0;
+    return is_trainer ? (int)((anh_trainer*)handle)->replicas() : (int)((anh_runtime*)handle)->replicas();
+}
+int anh_shard_range(int64_t n, int world, int rank, int64_t* lo, int64_t* hi) {
+    return guarded([&] { ANH_REQUIRE(lo && hi && world >= 1 && rank >= 0 && rank < world && n >= 0, "shard range: bad argument"); shard_range(n, world, rank, *lo, *hi); });
+}
+int anh_cross_replica_overlaps(const anh_tile* tiles, size_t n_tiles, int world, int width, int height, anh_rect** rects, size_t* count) {
+    return guarded([&] {
+        ANH_REQUIRE((tiles || n_tiles == 0) && rects && count && world >= 1, "null argument");
+        const std::vector<anh_rect> r = cross_replica_overlaps(std::vector<anh_tile>(tiles, tiles + n_tiles), world, width, height);
+        anh_rect* out = (anh_rect*)std::malloc(std::max<size_t>(1, r.size()) * sizeof(anh_rect));
+        if (!out) fail(ANH_ERR_OOM, "host allocation failed");
+        std::copy(r.begin(), r.end(), out);
+        *rects = out; *count = r.size();
+    });
+}
 
 // ---- dimension maths / spec ----
 int anh_required_input_dim(const anh_net_config* cfg) {
@@ -250,7 +342,7 @@ int anh_runtime_create(const anh_net_config* cfg, anh_runtime** out) {
     return guarded([&] {
         ANH_REQUIRE(cfg && out, "null argument");
         auto h = std::make_unique<anh_runtime>();
-        h->eng = std::make_unique<Engine>(*cfg, false);
+        h->build(*cfg);
         *out = h.release();
     });
 }
@@ -262,19 +354,21 @@ int anh_runtime_set_params(anh_runtime* h, const float* params, int64_t n_params
     return guarded([&] {
         ANH_REQUIRE(h && params && running, "null argument");
         ANH_REQUIRE(n_params == h->eng->spec.n_params && n_running == h->eng->spec.n_running, "parameter blob size mismatch");
-        h->eng->set_params(params, running);
+        h->set_params_all(params, running);
     });
 }
 int anh_runtime_get_params(const anh_runtime* h, float* params, int64_t n_params, float* running, int64_t n_running) {
     return guarded([&] {
         ANH_REQUIRE(h, "null handle");
         ANH_REQUIRE((!params || n_params == h->eng->spec.n_params) && (!running || n_running == h->eng->spec.n_running), "parameter blob size mismatch");
+        DeviceScope scope(h->device_of(0));
         h->eng->get_params(params, running);
     });
 }
 int anh_runtime_serialize(const anh_runtime* h, void** blob, size_t* size) {
     return guarded([&] {
         ANH_REQUIRE(h && blob && size, "null argument");
+        DeviceScope scope(h->device_of(0));
         const Spec& s = h->eng->spec;
         const size_t bytes = sizeof(BlobHeader) + (size_t)(s.n_params + s.n_running) * 4;
         char* p = (char*)std::malloc(bytes);
@@ -301,9 +395,9 @@ int anh_runtime_deserialize(const void* blob, size_t size, int precision, anh_ru
         if (s.n_params != hd.n_params || s.n_running != hd.n_running || size != sizeof hd + (size_t)(hd.n_params + hd.n_running) * 4)
             fail(ANH_ERR_IO, "runtime blob does not match its header");
         auto h = std::make_unique<anh_runtime>();
-        h->eng = std::make_unique<Engine>(cfg, false);
+        h->build(cfg);
         const float* f = (const float*)((const char*)blob + sizeof hd);
-        h->eng->set_params(f, f + hd.n_params);
+        h->set_params_all(f, f + hd.n_params);
         *out = h.release();
     });
 }
@@ -311,6 +405,7 @@ int anh_runtime_deserialize(const void* blob, size_t size, int precision, anh_ru
 int anh_runtime_forward_device(anh_runtime* h, const uint8_t* d_image, int n, int height, int width, float* d_out_nchw) {
     return guarded([&] {
         ANH_REQUIRE(h && d_image && d_out_nchw, "null argument");
+        DeviceScope scope(h->device_of(0));
         Src img;
         img.kind = SRC_IMAGE; img.img = d_image; img.img_h = height; img.img_w = width;
         img.img_sample_stride = (int64_t)height * width * h->eng->spec.cfg.in_channels;
@@ -322,6 +417,7 @@ int anh_runtime_forward(anh_runtime* h, const uint8_t* image, int n, int height,
     return guarded([&] {
         ANH_REQUIRE(h && image && out, "null argument");
         ANH_REQUIRE(n >= 1 && height >= 1 && width >= 1, "empty input");
+        DeviceScope scope(h->device_of(0));
         Engine& e = *h->eng;
         const int K = e.spec.cfg.classes, C = e.spec.cfg.in_channels;
         const size_t in_bytes = (size_t)n * height * width * C, out_elems = (size_t)n * K * height * width;
@@ -354,6 +450,7 @@ int anh_infer_device(anh_runtime* h, const uint8_t* d_image, int height, int wid
                      const anh_tile* tiles, size_t n_tiles, uint16_t* d_result, float* d_blended) {
     return guarded([&] {
         ANH_REQUIRE(h && d_image && d_blended, "null argument");
+        DeviceScope scope(h->device_of(0));
         std::vector<anh_tile> list = tiles ? std::vector<anh_tile>(tiles, tiles + n_tiles) : tiles_for(tiling, width, height);
         h->eng->infer_device(d_image, height, width, gains, list, d_result, d_blended);
     });
@@ -363,6 +460,7 @@ int anh_argmax_device(anh_runtime* h, const float* d_blended, int height, int wi
     return guarded([&] {
         ANH_REQUIRE(h && d_blended && d_result, "null argument");
         ANH_REQUIRE(height >= 1 && width >= 1 && row0 >= 0 && row0 <= row1 && row1 <= height, "argmax: bad row range");
+        DeviceScope scope(h->device_of(0));
         Engine& e = *h->eng;
         const double* d_gains = e.upload_gains(gains);
         launch_argmax_range(d_blended, e.spec.cfg.classes, (int64_t)height * width, (int64_t)row0 * width, (int64_t)row1 * width, d_gains, d_result, e.stream);
@@ -475,11 +573,81 @@ void infer_streamed(anh_runtime* h, const uint8_t* image, int H, int W, const do
 }
 }  // namespace
 
+namespace {
+// annonet_infer() on a handle with several replicas (anh_set_devices): the tile list is split into contiguous row-major chunks
+// (tiles are independent, annonet_infer.cpp:46-165, except for the additive blended_output), every replica blends its chunk
+// into planes of its own, ONE all-reduce sums the planes inside the rectangles where tiles of different replicas overlap
+// (strips one receptive field wide), every replica labels the rows its tiles cover, and the host label map is assembled tile
+// by tile from the owner of each tile (in an overlap both owners hold the same sums, hence the same labels).
+void infer_multi(anh_runtime* h, const uint8_t* image, int H, int W, const double* gains, const std::vector<anh_tile>& tiles, uint16_t* result, float* blended_out) {
+    const size_t R = h->replicas();
+    const int K = h->eng->spec.cfg.classes, C = h->eng->spec.cfg.in_channels;
+    const size_t plane = (size_t)H * W;
+    const RectTable table = make_rect_table(cross_replica_overlaps(tiles, (int)R, W, H));
+    const int64_t total = table.total();
+    std::vector<float*> packed(R, nullptr);
+    std::vector<hipStream_t> streams(R);
+    std::vector<int64_t> lo(R), hi(R);
+    for (size_t r = 0; r < R; ++r) {
+        DeviceScope scope(h->device_of(r));
+        Engine& e = h->replica(r);
+        shard_range((int64_t)tiles.size(), (int)R, (int)r, lo[r], hi[r]);
+        e.stage_image.reserve(plane * C);
+        e.stage_blended.reserve(plane * K * 4);
+        e.stage_result.reserve(plane * 2);
+        HIP_CHECK(hipMemcpyAsync(e.stage_image.p, image, plane * C, hipMemcpyHostToDevice, e.stream));
+        const std::vector<anh_tile> mine(tiles.begin() + lo[r], tiles.begin() + hi[r]);
+        e.infer_device(e.stage_image.as<uint8_t>(), H, W, gains, mine, nullptr, e.stage_blended.as<float>());
+        streams[r] = e.stream;
+        if (total > 0) {
+            anh_runtime::Exchange& x = h->exchange[r];
+            x.packed.reserve((size_t)K * total * 4);
+            x.rects.reserve(table.rects.size() * sizeof(anh_rect));
+            x.offsets.reserve(table.offset.size() * sizeof(int64_t));
+            HIP_CHECK(hipMemcpyAsync(x.rects.p, table.rects.data(), table.rects.size() * sizeof(anh_rect), hipMemcpyHostToDevice, e.stream));
+            HIP_CHECK(hipMemcpyAsync(x.offsets.p, table.offset.data(), table.offset.size() * sizeof(int64_t), hipMemcpyHostToDevice, e.stream));
+            launch_pack_rects(e.stage_blended.as<float>(), K, H, W, x.rects.as<anh_rect>(), x.offsets.as<int64_t>(), (int)table.rects.size(), total, x.packed.as<float>(), e.stream);
+            packed[r] = x.packed.as<float>();
+        }
+    }
+    // the table's host vectors must outlive the async uploads: every replica's stream passes the uploads before the collective returns control below
+    if (total > 0) h->coll->all_reduce_sum(packed, (size_t)K * total, streams);   // the ONE exchange step of the path
+    for (size_t r = 0; r < R; ++r) {
+        DeviceScope scope(h->device_of(r));
+        Engine& e = h->replica(r);
+        if (hi[r] == lo[r]) continue;
+        if (total > 0) {
+            anh_runtime::Exchange& x = h->exchange[r];
+            launch_unpack_rects(e.stage_blended.as<float>(), K, H, W, x.rects.as<anh_rect>(), x.offsets.as<int64_t>(), (int)table.rects.size(), total, x.packed.as<float>(), e.stream);
+        }
+        long top = H, bottom = -1;
+        for (int64_t i = lo[r]; i < hi[r]; ++i) { top = std::min(top, tiles[(size_t)i].full_rect.top); bottom = std::max(bottom, tiles[(size_t)i].full_rect.bottom); }
+        const int row0 = (int)std::max(0L, top), row1 = (int)std::min((long)H, bottom + 1);
+        const double* d_gains = e.upload_gains(gains);
+        launch_argmax_range(e.stage_blended.as<float>(), K, (int64_t)plane, (int64_t)row0 * W, (int64_t)row1 * W, d_gains, e.stage_result.as<uint16_t>(), e.stream);
+        for (int64_t i = lo[r]; i < hi[r]; ++i) {   // this replica's share of the host label map (and planes): its tiles' full rectangles
+            const anh_rect& f = tiles[(size_t)i].full_rect;
+            const long l = std::max(0L, f.left), t = std::max(0L, f.top), rt = std::min((long)W - 1, f.right), b = std::min((long)H - 1, f.bottom);
+            if (l > rt || t > b) continue;
+            const size_t off = (size_t)t * W + l;
+            HIP_CHECK(hipMemcpy2DAsync(result + off, (size_t)W * 2, e.stage_result.as<uint16_t>() + off, (size_t)W * 2, (size_t)(rt - l + 1) * 2, (size_t)(b - t + 1),
+                                       hipMemcpyDeviceToHost, e.stream));
+            if (blended_out)
+                for (int k = 0; k < K; ++k)
+                    HIP_CHECK(hipMemcpy2DAsync(blended_out + k * plane + off, (size_t)W * 4, e.stage_blended.as<float>() + k * plane + off, (size_t)W * 4,
+                                               (size_t)(rt - l + 1) * 4, (size_t)(b - t + 1), hipMemcpyDeviceToHost, e.stream));
+        }
+    }
+    for (size_t r = 0; r < R; ++r) { DeviceScope scope(h->device_of(r)); h->replica(r).synchronize(); }
+}
+}  // namespace
+
 int anh_infer(anh_runtime* h, const uint8_t* image, int height, int width, const double* gains, const double* detection_levels,
               const anh_tiling_params* tiling, uint16_t* result, float* blended_out) {
     return guarded([&] {
         ANH_REQUIRE(h && image && result, "null argument");
         ANH_REQUIRE(height >= 1 && width >= 1, "empty image");
+        DeviceScope scope(h->device_of(0));
         Engine& e = *h->eng;
         const int K = e.spec.cfg.classes, C = e.spec.cfg.in_channels;
         const size_t plane = (size_t)height * width;
@@ -489,6 +657,9 @@ int anh_infer(anh_runtime* h, const uint8_t* image, int height, int width, const
         e.stage_result.reserve(plane * 2);
         bool use_det = false;
         if (detection_levels) for (int k = 0; k < K; ++k) { ANH_REQUIRE(detection_levels[k] >= 0.0, "detection levels must be >= 0"); if (detection_levels[k] > 0.0) use_det = true; }
+        // several replicas: shard the tile list (the detection-level filter walks connected blobs of the WHOLE label map: it runs on
+        // replica 0 alone, as does an image with fewer tiles than replicas would gain nothing)
+        if (h->replicas() > 1 && !use_det && tiles.size() >= 2) { infer_multi(h, image, height, width, gains, tiles, result, blended_out); return; }
         static const bool streamed = !(getenv("ANH_INFER_STREAMED") && atoi(getenv("ANH_INFER_STREAMED")) == 0);
         if (streamed && !use_det && !blended_out) { infer_streamed(h, image, height, width, gains, tiles, result); return; }
         HIP_CHECK(hipMemcpyAsync(e.stage_image.p, image, plane * C, hipMemcpyHostToDevice, e.stream));
@@ -509,13 +680,15 @@ int anh_infer(anh_runtime* h, const uint8_t* image, int height, int width, const
     });
 }
 
-int anh_runtime_set_stream(anh_runtime* h, void* s) { return guarded([&] { ANH_REQUIRE(h, "null handle"); h->eng->set_stream((hipStream_t)s); }); }
+int anh_runtime_set_stream(anh_runtime* h, void* s) { return guarded([&] { ANH_REQUIRE(h, "null handle"); ANH_REQUIRE(h->replicas() == 1, "a handle that drives several devices keeps its own streams"); h->eng->set_stream((hipStream_t)s); }); }
 int anh_runtime_get_stream(anh_runtime* h, void** s) { return guarded([&] { ANH_REQUIRE(h && s, "null argument"); *s = (void*)h->eng->stream; }); }
-int anh_runtime_synchronize(anh_runtime* h) { return guarded([&] { ANH_REQUIRE(h, "null handle"); h->eng->synchronize(); }); }
+int anh_runtime_synchronize(anh_runtime* h) {
+    return guarded([&] { ANH_REQUIRE(h, "null handle"); for (size_t r = 0; r < h->replicas(); ++r) { DeviceScope scope(h->device_of(r)); h->replica(r).synchronize(); } });
+}
 
 // ---- TrainingNet ----
 int anh_trainer_create(anh_trainer** out) {
-    return guarded([&] { ANH_REQUIRE(out, "null argument"); *out = new anh_trainer(); });
+    return guarded([&] { ANH_REQUIRE(out, "null argument"); auto h = std::make_unique<anh_trainer>(); h->devices = selected_devices(); *out = h.release(); });
 }
 void anh_trainer_destroy(anh_trainer* h) { delete h; }
 
@@ -559,22 +732,20 @@ int anh_trainer_set_synchronization_file(anh_trainer* h, const char* path, doubl
         ANH_REQUIRE(h && path, "null argument");
         h->sync_path = path; h->sync_seconds = seconds;
         h->last_sync = std::chrono::steady_clock::now();
-        std::ifstream probe(path, std::ios::binary);
-        if (probe.good() && h->initialized) {  // dlib's trainer resumes from an existing synchronization file
-            probe.close();
-            const int rc = anh_trainer_load_state(h, path);
-            if (rc != ANH_OK) fail(rc, g_error);
-        }
+        // dlib's trainer resumes from an existing synchronization file.  The reference calls this BEFORE SetClassCount
+        // (annonet_train_main.cpp:400-405), so the file is read on the first use of the net, once every structural setter ran.
+        h->resume_pending = h->steps == 0;
     });
 }
 double anh_trainer_get_learning_rate(const anh_trainer* h) {
     if (!h) return 0;
-    try { const_cast<anh_trainer*>(h)->consume(false); } catch (...) {}
-    return h->sched.lr;
+    // a pending resume may change the rate: the host polls this in its loop condition before the first step (annonet_train_main.cpp:583)
+    if (h->resume_pending && h->initialized) { try { (void)const_cast<anh_trainer*>(h)->engine(); } catch (...) {} }
+    return h->sched.lr;   // changes only inside apply_update, at the fixed loss lag: no timing-dependent polling
 }
 double anh_trainer_get_last_loss(anh_trainer* h) {
     double v = NAN;
-    guarded([&] { ANH_REQUIRE(h, "null handle"); h->engine().synchronize(); h->consume(true); v = h->steps ? h->last_loss : h->engine().read_loss(); });
+    guarded([&] { ANH_REQUIRE(h, "null handle"); h->engine().synchronize(); h->fetch_all(); v = h->steps ? h->last_loss : h->engine().read_loss(); });
     return v;
 }
 unsigned long anh_trainer_get_step_count(const anh_trainer* h) { return h ? h->steps : 0; }
@@ -585,6 +756,8 @@ int anh_trainer_forward_backward_device(anh_trainer* h, const uint8_t* d_images,
     return guarded([&] {
         ANH_REQUIRE(h && d_images && d_labels && d_weights, "null argument");
         ANH_REQUIRE(loss_scale_n > 0, "loss scale batch must be positive");
+        ANH_REQUIRE(h->replicas() == 1, "device-resident steps drive ONE device: a handle over several devices takes host mini-batches (anh_trainer_step)");
+        DeviceScope scope(h->device_of(0));
         Engine& e = h->engine();
         Src img;
         img.kind = SRC_IMAGE; img.img = d_images; img.img_h = height; img.img_w = width;
@@ -599,10 +772,12 @@ int anh_trainer_apply_update(anh_trainer* h, double grad_scale) {
     return guarded([&] {
         ANH_REQUIRE(h, "null handle");
         Engine& e = h->engine();
-        h->consume(false);
+        // this is step h->steps + 1: its rate is decided by the losses of steps <= h->steps + 1 - kLossLag (deterministic lag)
+        if (h->steps + 1 > anh_trainer::kLossLag) h->record_until(h->steps + 1 - anh_trainer::kLossLag);
+        for (size_t r = 1; r < h->replicas(); ++r) { DeviceScope scope(h->device_of(r)); h->replica(r).apply_update(h->sched.lr, h->weight_decay, h->momentum, grad_scale, h->bn_window); }
+        DeviceScope scope0(h->device_of(0));
         e.apply_update(h->sched.lr, h->weight_decay, h->momentum, grad_scale, h->bn_window);
         // ship this step's loss (gradient bucket's trailing slot: already all-reduced under data parallelism)
-        if (h->pending.size() >= 200) h->consume(true);
         hipEvent_t ev;
         if (!h->free_events.empty()) { ev = h->free_events.back(); h->free_events.pop_back(); }
         else HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
@@ -610,10 +785,10 @@ int anh_trainer_apply_update(anh_trainer* h, double grad_scale) {
         h->next_slot = (h->next_slot + 1) % 256;
         HIP_CHECK(hipMemcpyAsync(h->loss_ring + slot, e.grad_bucket() + e.spec.n_params, sizeof(float), hipMemcpyDeviceToHost, e.stream));
         HIP_CHECK(hipEventRecord(ev, e.stream));
-        h->pending.push_back({ev, slot});
         ++h->steps;
+        h->pending.push_back({ev, slot, h->steps, false, 0.0});
         if (h->verbose && h->steps % 100 == 0) {
-            h->consume(false);
+            if (!h->pending.empty()) { h->arrive(h->pending.front()); h->last_loss = h->pending.front().value; }   // the oldest loss in flight
             std::printf("step#: %lu  learning rate: %g  loss: %g  steps without apparent progress: %lu\n", h->steps, h->sched.lr, h->last_loss,
                         h->sched.steps_without_progress);
             std::fflush(stdout);
@@ -629,64 +804,96 @@ int anh_trainer_apply_update(anh_trainer* h, double grad_scale) {
     });
 }
 
+namespace {
+// Packs samples of a host mini-batch into one of a replica's two pinned staging sets, uploads them on the replica's copy stream
+// and enqueues forward + backward behind the upload.  Returns once the inputs are packed (the host refills its vectors right
+// after StartTraining returns, annonet_train_main.cpp:585-586); packing step k+1 overlaps the GPU work of step k.
+anh_trainer::StageSet& stage_and_run(anh_trainer* h, Engine& e, anh_trainer::StageSet* sets, hipStream_t& copy_stream, const uint8_t* const* images,
+                                     const anh_wlabel* const* labels, int n, int height, int width, double loss_scale_n) {
+    const int C = e.spec.cfg.in_channels, K = e.spec.cfg.classes;
+    const size_t plane = (size_t)height * width;
+    const size_t img_bytes = (size_t)n * plane * C, lab_off = (img_bytes + 255) / 256 * 256, lab_bytes = (size_t)n * plane * 2;
+    const size_t w_off = (lab_off + lab_bytes + 255) / 256 * 256, total = w_off + (size_t)n * plane * 4;
+    anh_trainer::StageSet& st = sets[h->host_steps & 1];
+    if (!copy_stream) HIP_CHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+    if (!st.uploaded) {
+        HIP_CHECK(hipEventCreateWithFlags(&st.uploaded, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&st.consumed, hipEventDisableTiming));
+    }
+    if (st.in_flight) HIP_CHECK(hipEventSynchronize(st.uploaded));   // the pinned block is free again (upload of step k-2 done)
+    if (total > st.pinned_bytes) {
+        if (st.in_flight) HIP_CHECK(hipEventSynchronize(st.consumed));
+        if (st.pinned) HIP_CHECK(hipHostFree(st.pinned));
+        st.pinned = nullptr; st.pinned_bytes = 0;
+        HIP_CHECK(hipHostMalloc(&st.pinned, total, hipHostMallocDefault));
+        st.pinned_bytes = total;
+        st.dev.reserve(total);
+    }
+    // ---- pack: images as they are, weighted labels split into a u16 and an f32 plane; labels validated on the way ----
+    uint8_t* base = static_cast<uint8_t*>(st.pinned);
+    uint16_t* plab = reinterpret_cast<uint16_t*>(base + lab_off);
+    float* pw = reinterpret_cast<float*>(base + w_off);
+    bool bad_label = false;
+    for (int i = 0; i < n; ++i) {
+        std::memcpy(base + (size_t)i * plane * C, images[i], plane * C);
+        const anh_wlabel* src = labels[i];
+        uint16_t* dl = plab + (size_t)i * plane;
+        float* dw = pw + (size_t)i * plane;
+        unsigned worst = 0;
+        for (size_t p = 0; p < plane; ++p) {
+            const uint16_t l = src[p].label;
+            dl[p] = l; dw[p] = src[p].weight;
+            worst |= (unsigned)(l != ANH_LABEL_IGNORE && l >= K);
+        }
+        bad_label = bad_label || worst != 0;
+    }
+    ANH_REQUIRE(!bad_label, "label value exceeds the class count");
+    // ---- upload behind the step that last read this device block, compute behind the upload ----
+    if (st.in_flight) HIP_CHECK(hipStreamWaitEvent(copy_stream, st.consumed, 0));
+    HIP_CHECK(hipMemcpyAsync(st.dev.p, st.pinned, total, hipMemcpyHostToDevice, copy_stream));
+    HIP_CHECK(hipEventRecord(st.uploaded, copy_stream));
+    HIP_CHECK(hipStreamWaitEvent(e.stream, st.uploaded, 0));
+    uint8_t* dbase = st.dev.as<uint8_t>();
+    Src img;
+    img.kind = SRC_IMAGE; img.img = dbase; img.img_h = height; img.img_w = width;
+    img.img_sample_stride = (int64_t)height * width * C;
+    e.bn_window = h->bn_window;
+    e.forward_training(img, n, height, width);
+    e.backward(reinterpret_cast<uint16_t*>(dbase + lab_off), reinterpret_cast<float*>(dbase + w_off), loss_scale_n);
+    return st;
+}
+}  // namespace
+
 int anh_trainer_step(anh_trainer* h, const uint8_t* const* images, const anh_wlabel* const* labels, int n, int height, int width) {
     return guarded([&] {
         ANH_REQUIRE(h && images && labels, "null argument");
         ANH_REQUIRE(n >= 1 && height >= 1 && width >= 1, "empty mini-batch");
-        Engine& e = h->engine();
-        const int C = e.spec.cfg.in_channels, K = e.spec.cfg.classes;
-        const size_t plane = (size_t)height * width;
-        const size_t img_bytes = (size_t)n * plane * C, lab_off = (img_bytes + 255) / 256 * 256, lab_bytes = (size_t)n * plane * 2;
-        const size_t w_off = (lab_off + lab_bytes + 255) / 256 * 256, total = w_off + (size_t)n * plane * 4;
         for (int i = 0; i < n; ++i) ANH_REQUIRE(images[i] && labels[i], "null sample");
-
-        anh_trainer::StageSet& st = h->stage[h->host_steps & 1];
-        if (!h->copy_stream) HIP_CHECK(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
-        if (!st.uploaded) {
-            HIP_CHECK(hipEventCreateWithFlags(&st.uploaded, hipEventDisableTiming));
-            HIP_CHECK(hipEventCreateWithFlags(&st.consumed, hipEventDisableTiming));
+        (void)h->engine();   // builds every replica on first use
+        const size_t R = h->replicas();
+        ANH_REQUIRE((size_t)n >= R, "mini-batch smaller than the number of devices");
+        // data parallel (annonet_train_main.cpp:583-614): replica r takes samples [n r / R, n (r+1) / R); the loss
+        // scale 1/(N nr nc) uses the WHOLE batch, so the exchange step is a plain sum of the gradient buckets
+        std::vector<anh_trainer::StageSet*> used(R, nullptr);
+        for (size_t r = 0; r < R; ++r) {
+            DeviceScope scope(h->device_of(r));
+            int64_t lo, hi;
+            shard_range(n, (int)R, (int)r, lo, hi);
+            used[r] = &stage_and_run(h, h->replica(r), h->stage_of(r), h->copy_stream_of(r), images + lo, labels + lo, (int)(hi - lo), height, width, (double)n);
         }
-        if (st.in_flight) HIP_CHECK(hipEventSynchronize(st.uploaded));   // the pinned block is free again (upload of step k-2 done)
-        if (total > st.pinned_bytes) {
-            if (st.in_flight) HIP_CHECK(hipEventSynchronize(st.consumed));
-            if (st.pinned) HIP_CHECK(hipHostFree(st.pinned));
-            st.pinned = nullptr; st.pinned_bytes = 0;
-            HIP_CHECK(hipHostMalloc(&st.pinned, total, hipHostMallocDefault));
-            st.pinned_bytes = total;
-            st.dev.reserve(total);
+        if (R > 1) {
+            std::vector<float*> buckets(R);
+            std::vector<hipStream_t> streams(R);
+            for (size_t r = 0; r < R; ++r) { buckets[r] = h->replica(r).grad_bucket(); streams[r] = h->replica(r).stream; }
+            h->coll->all_reduce_sum(buckets, (size_t)h->eng->spec.n_params + 1, streams);   // the trailing slot carries the loss
         }
-        // ---- pack: images as they are, weighted labels split into a u16 and an f32 plane; labels validated on the way ----
-        uint8_t* base = static_cast<uint8_t*>(st.pinned);
-        uint16_t* plab = reinterpret_cast<uint16_t*>(base + lab_off);
-        float* pw = reinterpret_cast<float*>(base + w_off);
-        bool bad_label = false;
-        for (int i = 0; i < n; ++i) {
-            std::memcpy(base + (size_t)i * plane * C, images[i], plane * C);
-            const anh_wlabel* src = labels[i];
-            uint16_t* dl = plab + (size_t)i * plane;
-            float* dw = pw + (size_t)i * plane;
-            unsigned worst = 0;
-            for (size_t p = 0; p < plane; ++p) {
-                const uint16_t l = src[p].label;
-                dl[p] = l; dw[p] = src[p].weight;
-                worst |= (unsigned)(l != ANH_LABEL_IGNORE && l >= K);
-            }
-            bad_label = bad_label || worst != 0;
-        }
-        ANH_REQUIRE(!bad_label, "label value exceeds the class count");
-        // ---- upload behind the step that last read this device block, compute behind the upload ----
-        if (st.in_flight) HIP_CHECK(hipStreamWaitEvent(h->copy_stream, st.consumed, 0));
-        HIP_CHECK(hipMemcpyAsync(st.dev.p, st.pinned, total, hipMemcpyHostToDevice, h->copy_stream));
-        HIP_CHECK(hipEventRecord(st.uploaded, h->copy_stream));
-        HIP_CHECK(hipStreamWaitEvent(e.stream, st.uploaded, 0));
-        uint8_t* dbase = st.dev.as<uint8_t>();
-        int rc = anh_trainer_forward_backward_device(h, dbase, reinterpret_cast<uint16_t*>(dbase + lab_off), reinterpret_cast<float*>(dbase + w_off), n, height,
-                                                     width, (double)n);
+        const int rc = anh_trainer_apply_update(h, 1.0);
         if (rc != ANH_OK) fail(rc, g_error);
-        rc = anh_trainer_apply_update(h, 1.0);
-        if (rc != ANH_OK) fail(rc, g_error);
-        HIP_CHECK(hipEventRecord(st.consumed, e.stream));
-        st.in_flight = true;
+        for (size_t r = 0; r < R; ++r) {
+            DeviceScope scope(h->device_of(r));
+            HIP_CHECK(hipEventRecord(used[r]->consumed, h->replica(r).stream));
+            used[r]->in_flight = true;
+        }
         ++h->host_steps;
     });
 }
@@ -707,8 +914,17 @@ int anh_trainer_set_params(anh_trainer* h, const float* params, int64_t n_params
         ANH_REQUIRE(h && params && running, "null argument");
         Engine& e = h->engine();
         ANH_REQUIRE(n_params == e.spec.n_params && n_running == e.spec.n_running, "parameter blob size mismatch");
-        e.synchronize();
-        e.set_params(params, running);
+        for (size_t r = 0; r < h->replicas(); ++r) { DeviceScope scope(h->device_of(r)); h->replica(r).synchronize(); h->replica(r).set_params(params, running); }
+    });
+}
+int anh_trainer_replica_params(anh_trainer* h, int replica, float* params, int64_t n_params) {
+    return guarded([&] {
+        ANH_REQUIRE(h && params, "null argument");
+        (void)h->engine();
+        ANH_REQUIRE(replica >= 0 && (size_t)replica < h->replicas(), "replica index out of range");
+        ANH_REQUIRE(n_params == h->eng->spec.n_params, "size mismatch");
+        DeviceScope scope(h->device_of((size_t)replica));
+        h->replica((size_t)replica).get_params(params, nullptr);
     });
 }
 int anh_trainer_get_grads(anh_trainer* h, float* grads, int64_t n_params) {
@@ -718,7 +934,11 @@ int anh_trainer_get_momentum(anh_trainer* h, float* m, int64_t n_params) {
     return guarded([&] { ANH_REQUIRE(h && m, "null argument"); ANH_REQUIRE(n_params == h->engine().spec.n_params, "size mismatch"); h->engine().get_momentum(m); });
 }
 int anh_trainer_set_momentum(anh_trainer* h, const float* m, int64_t n_params) {
-    return guarded([&] { ANH_REQUIRE(h && m, "null argument"); ANH_REQUIRE(n_params == h->engine().spec.n_params, "size mismatch"); h->engine().set_momentum(m); });
+    return guarded([&] {
+        ANH_REQUIRE(h && m, "null argument");
+        ANH_REQUIRE(n_params == h->engine().spec.n_params, "size mismatch");
+        for (size_t r = 0; r < h->replicas(); ++r) { DeviceScope scope(h->device_of(r)); h->replica(r).set_momentum(m); }
+    });
 }
 
 int anh_trainer_snapshot_runtime(anh_trainer* h, int precision, anh_runtime** out) {
@@ -730,8 +950,8 @@ int anh_trainer_snapshot_runtime(anh_trainer* h, int precision, anh_runtime** ou
         anh_net_config cfg = e.spec.cfg;
         cfg.precision = precision;
         auto rt = std::make_unique<anh_runtime>();
-        rt->eng = std::make_unique<Engine>(cfg, false);
-        rt->eng->set_params(p.data(), r.data());
+        rt->build(cfg);
+        rt->set_params_all(p.data(), r.data());
         *out = rt.release();
     });
 }
@@ -741,11 +961,12 @@ int anh_trainer_save_state(anh_trainer* h, const char* path) {
         ANH_REQUIRE(h && path, "null argument");
         Engine& e = h->engine();
         e.synchronize();
-        h->consume(true);
+        h->fetch_all();   // the losses still ahead of the schedule's lag are stored as such: a resumed run records them when an uninterrupted one would
         const Spec& s = e.spec;
         std::vector<float> p((size_t)s.n_params), m((size_t)s.n_params), r((size_t)s.n_running);
         e.get_params(p.data(), r.data());
         e.get_momentum(m.data());
+        const std::vector<double> updates = e.get_running_updates();
         const std::string tmp = std::string(path) + ".tmp";
         {
             std::ofstream f(tmp, std::ios::binary | std::ios::trunc);
@@ -755,9 +976,16 @@ int anh_trainer_save_state(anh_trainer* h, const char* path) {
             hd.levels = s.cfg.levels; hd.in_channels = s.cfg.in_channels; hd.classes = s.cfg.classes; hd.min_filters = s.cfg.min_filters;
             hd.width_scaler = s.cfg.width_scaler; hd.n_params = s.n_params; hd.n_running = s.n_running;
             f.write((const char*)&hd, sizeof hd);
-            const uint64_t steps = h->steps, nh = h->sched.history.size(), budget = h->sched.check_budget;
-            f.write((const char*)&steps, 8); f.write((const char*)&h->sched.lr, 8); f.write((const char*)&budget, 8); f.write((const char*)&nh, 8);
+            const uint64_t steps = h->steps, nh = h->sched.history.size(), budget = h->sched.check_budget, swp = h->sched.steps_without_progress;
+            const uint64_t n_unrec = h->pending.size(), n_bn = updates.size();
+            f.write((const char*)&steps, 8); f.write((const char*)&h->sched.lr, 8); f.write((const char*)&budget, 8); f.write((const char*)&swp, 8);
+            f.write((const char*)&h->last_loss, 8);
+            f.write((const char*)&nh, 8);
             for (double v : h->sched.history) f.write((const char*)&v, 8);
+            f.write((const char*)&n_unrec, 8);
+            for (const auto& pl : h->pending) { const uint64_t st = pl.step; f.write((const char*)&st, 8); f.write((const char*)&pl.value, 8); }
+            f.write((const char*)&n_bn, 8);
+            for (double v : updates) f.write((const char*)&v, 8);
             f.write((const char*)p.data(), p.size() * 4); f.write((const char*)m.data(), m.size() * 4); f.write((const char*)r.data(), r.size() * 4);
             if (!f) fail(ANH_ERR_IO, "short write to " + tmp);
         }
@@ -765,41 +993,73 @@ int anh_trainer_save_state(anh_trainer* h, const char* path) {
     });
 }
 
+namespace {
+void load_state_into(anh_trainer* h, Engine& e, const char* path) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) fail(ANH_ERR_IO, std::string("cannot read ") + path);
+    BlobHeader hd;
+    f.read((char*)&hd, sizeof hd);
+    if (!f || std::memcmp(hd.magic, kStateMagic, 8) != 0) fail(ANH_ERR_IO, "not an annonet_hip trainer state file (or one of an older format)");
+    const Spec& s = e.spec;
+    if (hd.levels != s.cfg.levels || hd.in_channels != s.cfg.in_channels || hd.classes != s.cfg.classes || hd.n_params != s.n_params || hd.n_running != s.n_running)
+        fail(ANH_ERR_IO, "trainer state file was written for a different net");
+    uint64_t steps = 0, nh = 0, budget = 0, swp = 0, n_unrec = 0, n_bn = 0;
+    double lr = 0, last_loss = 0;
+    f.read((char*)&steps, 8); f.read((char*)&lr, 8); f.read((char*)&budget, 8); f.read((char*)&swp, 8); f.read((char*)&last_loss, 8); f.read((char*)&nh, 8);
+    if (!f || nh > (1u << 26)) fail(ANH_ERR_IO, "trainer state file is corrupt");
+    std::deque<double> hist;
+    for (uint64_t i = 0; i < nh; ++i) { double v; f.read((char*)&v, 8); hist.push_back(v); }
+    f.read((char*)&n_unrec, 8);
+    if (!f || n_unrec > 4096) fail(ANH_ERR_IO, "trainer state file is corrupt");
+    std::deque<anh_trainer::PendingLoss> unrec;
+    for (uint64_t i = 0; i < n_unrec; ++i) { uint64_t st; double v; f.read((char*)&st, 8); f.read((char*)&v, 8); unrec.push_back({nullptr, 0, (unsigned long)st, true, v}); }
+    f.read((char*)&n_bn, 8);
+    if (!f || n_bn > 4096) fail(ANH_ERR_IO, "trainer state file is corrupt");
+    std::vector<double> updates((size_t)n_bn);
+    for (auto& v : updates) f.read((char*)&v, 8);
+    std::vector<float> p((size_t)s.n_params), m((size_t)s.n_params), r((size_t)s.n_running);
+    f.read((char*)p.data(), p.size() * 4); f.read((char*)m.data(), m.size() * 4); f.read((char*)r.data(), r.size() * 4);
+    if (!f) fail(ANH_ERR_IO, "trainer state file is truncated");
+    for (size_t rr = 0; rr < h->replicas(); ++rr) {   // every replica resumes from the same state
+        DeviceScope scope(h->device_of(rr));
+        Engine& er = h->replica(rr);
+        er.synchronize();
+        er.set_params(p.data(), r.data());
+        er.set_momentum(m.data());
+        er.set_running_updates(updates);
+    }
+    for (auto& pl : h->pending) if (pl.ev) h->free_events.push_back(pl.ev);
+    h->pending = unrec;
+    h->steps = (unsigned long)steps; h->last_loss = last_loss;
+    h->sched.lr = lr; h->sched.check_budget = (unsigned long)budget; h->sched.steps_without_progress = (unsigned long)swp; h->sched.history = hist;
+}
+}  // namespace
+
+void anh_trainer::resume() { load_state_into(this, *eng, sync_path.c_str()); }
+
 int anh_trainer_load_state(anh_trainer* h, const char* path) {
     return guarded([&] {
         ANH_REQUIRE(h && path, "null argument");
-        Engine& e = h->engine();
-        std::ifstream f(path, std::ios::binary);
-        if (!f) fail(ANH_ERR_IO, std::string("cannot read ") + path);
-        BlobHeader hd;
-        f.read((char*)&hd, sizeof hd);
-        if (!f || std::memcmp(hd.magic, kStateMagic, 8) != 0) fail(ANH_ERR_IO, "not an annonet_hip trainer state file");
-        const Spec& s = e.spec;
-        if (hd.levels != s.cfg.levels || hd.in_channels != s.cfg.in_channels || hd.classes != s.cfg.classes || hd.n_params != s.n_params || hd.n_running != s.n_running)
-            fail(ANH_ERR_IO, "trainer state file was written for a different net");
-        uint64_t steps = 0, nh = 0, budget = 0;
-        double lr = 0;
-        f.read((char*)&steps, 8); f.read((char*)&lr, 8); f.read((char*)&budget, 8); f.read((char*)&nh, 8);
-        if (!f || nh > (1u << 26)) fail(ANH_ERR_IO, "trainer state file is corrupt");
-        std::deque<double> hist;
-        for (uint64_t i = 0; i < nh; ++i) { double v; f.read((char*)&v, 8); hist.push_back(v); }
-        std::vector<float> p((size_t)s.n_params), m((size_t)s.n_params), r((size_t)s.n_running);
-        f.read((char*)p.data(), p.size() * 4); f.read((char*)m.data(), m.size() * 4); f.read((char*)r.data(), r.size() * 4);
-        if (!f) fail(ANH_ERR_IO, "trainer state file is truncated");
-        e.synchronize();
-        e.set_params(p.data(), r.data());
-        e.set_momentum(m.data());
-        h->steps = (unsigned long)steps; h->sched.lr = lr; h->sched.check_budget = (unsigned long)budget; h->sched.history = hist;
+        h->resume_pending = false;   // an explicit load wins over the synchronization file
+        load_state_into(h, h->engine(), path);
     });
 }
 
-int anh_trainer_set_stream(anh_trainer* h, void* s) { return guarded([&] { ANH_REQUIRE(h, "null handle"); h->engine().set_stream((hipStream_t)s); }); }
+int anh_trainer_set_stream(anh_trainer* h, void* s) {
+    return guarded([&] { ANH_REQUIRE(h, "null handle"); ANH_REQUIRE(h->replicas() == 1, "a handle that drives several devices keeps its own streams"); h->engine().set_stream((hipStream_t)s); });
+}
 int anh_trainer_get_stream(anh_trainer* h, void** s) { return guarded([&] { ANH_REQUIRE(h && s, "null argument"); *s = (void*)h->engine().stream; }); }
 int anh_trainer_synchronize(anh_trainer* h) {
     return guarded([&] {
         ANH_REQUIRE(h, "null handle");
-        h->engine().synchronize();
-        if (h->engine().read_error_flag_and_clear()) fail(ANH_ERR_INVALID, "a label value exceeds the class count");
+        (void)h->engine();
+        bool bad = false;
+        for (size_t r = 0; r < h->replicas(); ++r) {
+            DeviceScope scope(h->device_of(r));
+            h->replica(r).synchronize();
+            bad = h->replica(r).read_error_flag_and_clear() || bad;
+        }
+        if (bad) fail(ANH_ERR_INVALID, "a label value exceeds the class count");
     });
 }
 int anh_trainer_layer_tensor(anh_trainer* h, int layer, int which, float* out, int64_t capacity, int dims4[4]) {
@@ -838,6 +1098,15 @@ int anh_profile_entry(void* handle, int is_trainer, int index, char* name, size_
         if (launches) *launches = en.launches;
         if (flops) *flops = en.flops;
         if (bytes) *bytes = en.bytes;
+    });
+}
+int anh_profile_launch_order(void* handle, int is_trainer, char* buf, size_t cap, size_t* needed) {
+    return guarded([&] {
+        Engine* e = engine_of(handle, is_trainer);
+        std::string joined;
+        for (const std::string& n : e->prof.order) { joined += n; joined += '\n'; }
+        if (needed) *needed = joined.size() + 1;
+        if (buf && cap) { std::strncpy(buf, joined.c_str(), cap - 1); buf[cap - 1] = 0; }
     });
 }
 
@@ -910,6 +1179,7 @@ int anh_trainer_step_crops(anh_trainer* h, anh_dataset* d, const anh_crop_spec* 
     return guarded([&] {
         ANH_REQUIRE(h && d && specs, "null argument");
         ANH_REQUIRE(n >= 1 && dim >= 1, "empty mini-batch");
+        ANH_REQUIRE(h->replicas() == 1, "device-cut crops live on ONE device: a handle over several devices takes host mini-batches (anh_trainer_step)");
         Engine& e = h->engine();
         const int C = e.spec.cfg.in_channels, K = e.spec.cfg.classes;
         ANH_REQUIRE(C == d->channels, "the dataset's channel count differs from the net's");

@@ -22,6 +22,10 @@ class Profiler {
     std::string filter;  // when non-empty only kernels whose name contains it are timed
     int sample_every = 1;  // time the kernels of every n-th pass only (an event pair costs ~6 us of stream time per launch)
     int64_t pass_index = 0; // advanced by the engine at the start of every forward pass
+    // entry names of the most recent pass in host enqueue order, one per begin() (kept whether or not that launch is timed):
+    // tools/pmc_traffic.py maps the dispatches of a rocprofv3 trace onto bench.py's per-layer entries with it
+    std::vector<std::string> order;
+    void start_pass() { ++pass_index; if (enabled) order.clear(); }
     ~Profiler();
     int begin(hipStream_t s, const char* name, double flops, double bytes);  // returns a token (or -1 when disabled)
     void end(hipStream_t s, int token);
@@ -79,6 +83,8 @@ class Engine {
     void get_grads_canonical(float* out);
     void get_momentum(float* out);
     void set_momentum(const float* in);
+    std::vector<double> get_running_updates() const;   // dlib bn_ num_updates, one per bn layer (trainer state file)
+    void set_running_updates(const std::vector<double>& v);
     void random_init(uint64_t seed);
     float* grad_bucket() { return grad.as<float>(); }  // n_params + 1 floats (last = loss)
 

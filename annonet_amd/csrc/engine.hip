@@ -29,6 +29,7 @@ hipEvent_t Profiler::get_event() {
 }
 int Profiler::begin(hipStream_t s, const char* name, double flops, double bytes) {
     if (!enabled) return -1;
+    order.emplace_back(name);
     if (sample_every > 1 && (pass_index % sample_every) != 0) return -1;
     if (!filter.empty() && std::string(name).find(filter) == std::string::npos) return -1;
     int idx = -1;
@@ -200,6 +201,16 @@ void Engine::get_grads_canonical(float* out) {
     HIP_CHECK(hipMemcpy(out, tmp.p, (size_t)spec.n_params * 4, hipMemcpyDeviceToHost));
 }
 
+std::vector<double> Engine::get_running_updates() const {
+    std::vector<double> v;
+    for (size_t li = 0; li < spec.layers.size(); ++li) if (spec.layers[li].has_bn) v.push_back(ls[li].running_updates);
+    return v;
+}
+void Engine::set_running_updates(const std::vector<double>& v) {
+    size_t k = 0;
+    for (size_t li = 0; li < spec.layers.size(); ++li) if (spec.layers[li].has_bn) { ANH_REQUIRE(k < v.size(), "running update counters: one per bn layer"); ls[li].running_updates = v[k++]; }
+}
+
 void Engine::get_momentum(float* out) {
     ANH_REQUIRE(training, "not a training net");
     synchronize();
@@ -321,9 +332,9 @@ void Engine::wgrad_dispatch(WgradArgs& a, const char* tag, double flops, double 
 }
 
 // profiler entry of a layer's kernel: layer kind + channel shape, so that an entry is ONE kernel instantiation at one shape
-static std::string layer_tag(const anh_layer_desc& L) {
+static std::string layer_tag(int li, const anh_layer_desc& L) {
     const char* kind = L.in_a < 0 ? "stem" : !L.has_bn ? "head" : L.type == 1 ? "cont3x3s2" : L.stride == 2 ? "con3x3s2" : "con3x3s1";
-    return std::string(kind) + "_" + std::to_string(L.cin) + "x" + std::to_string(L.cout);
+    return "L" + std::to_string(li) + "_" + kind + "_" + std::to_string(L.cin) + "x" + std::to_string(L.cout);
 }
 
 void Engine::run_conv_forward(int li, const Src& image, bool training_pass, float* d_out_nchw) {
@@ -354,7 +365,7 @@ void Engine::run_conv_forward(int li, const Src& image, bool training_pass, floa
             a.stat_partials = bn_partials.as<double>();
         }
     }
-    conv_dispatch(a, (std::string("fwd_") + layer_tag(L)).c_str(), flops, bytes);
+    conv_dispatch(a, (std::string("fwd_") + layer_tag(li, L)).c_str(), flops, bytes);
     if (L.has_bn && training_pass) {
         BnFwdArgs b;
         b.y = s.raw.p; b.dtype = dtype; b.pixels = p_out; b.c = L.cout;
@@ -364,7 +375,7 @@ void Engine::run_conv_forward(int li, const Src& image, bool training_pass, floa
         if (update_running_in_forward) {
             const double P = (double)p_out;
             b.averaging_factor = 1.0 / (s.running_updates + 1.0);
-            if (s.running_updates + 1.0 < (double)bn_window) s.running_updates += 1.0;
+            if (s.running_updates < (double)bn_window) s.running_updates += 1.0;   // dlib bn_: count capped AT the window [UPSTREAM-UNVERIFIED]
             b.unbias = P > 1 ? P / (P - 1.0) : 1.0;
             b.running_mean = running.as<float>() + L.rs_off; b.running_var = running.as<float>() + L.rs_off + L.cout;
         }
@@ -393,14 +404,14 @@ bool Engine::head_is_fused() const {
 }
 
 void Engine::forward_inference(const Src& image, int n, int h, int w, float* d_out_nchw) {
-    ++prof.pass_index;
+    prof.start_pass();
     ANH_REQUIRE(!training, "forward_inference on a training net: take a runtime snapshot first");
     plan_dims(n, h, w);
     for (size_t li = 0; li < spec.layers.size(); ++li) run_conv_forward((int)li, image, false, d_out_nchw);
 }
 
 void Engine::forward_training(const Src& image, int n, int h, int w) {
-    ++prof.pass_index;
+    prof.start_pass();
     ANH_REQUIRE(training, "not a training net");
     plan_dims(n, h, w);
     const size_t n_run = head_is_fused() ? spec.layers.size() - 1 : spec.layers.size();  // the fused tail computes the logits itself
@@ -491,7 +502,7 @@ void Engine::backward(const uint16_t* d_labels, const float* d_weights, double l
         // Fused schedule (two streams, MFMA path): the main stream runs reduce -> finalize -> backward-data conv, the conv
         // applying bn + relu backward to (da, y) while staging; the elementwise apply pass — needed by the filter gradient
         // only — runs out of place on the second stream ahead of that layer's wgrad.
-        bool fused_apply = false, wgrad_computes_dy = false;
+        bool fused_apply = false, wgrad_computes_dy = false, dgrad_writes_dy = false;
         if (L.has_bn) {
             ANH_REQUIRE(s.dact_written, "internal: layer output has no consumer");
             BnBwdArgs b;
@@ -513,15 +524,23 @@ void Engine::backward(const uint16_t* d_labels, const float* d_weights, double l
             prof.end(stream, tok);
             const bool dgrad_fuses = has_dgrad && dtype == DT_BF16 && conv_takes_mfma(dg, dtype) && conv_accepts_bnbwd(dg);
             static const bool force_fused = getenv("ANH_FORCE_FUSED_APPLY") != nullptr;  // experiment: fused schedule on one stream
-            fused_apply = (two_streams && dgrad_fuses) || (force_fused && dgrad_fuses);
+            if (dgrad_fuses && bn_bwd_apply_fusion_mode() == 2) {
+                // the backward-data conv computes dy = bn + relu backward of (da, y) while staging and also WRITES it: no apply
+                // pass; the filter gradient (second stream) starts once that conv is done
+                ConvArgs probe = dg;
+                probe.src.kind = SRC_BNBWD;
+                dgrad_writes_dy = conv_writes_dy(probe);
+            }
+            fused_apply = dgrad_writes_dy || (two_streams && dgrad_fuses) || (force_fused && dgrad_fuses);
             hipStream_t apply_on = stream;
             if (fused_apply && !two_streams) b.dy_out = s.dyp.p;
-            if (fused_apply && two_streams) {
+            if (fused_apply && two_streams && !dgrad_writes_dy) {
                 HIP_CHECK(hipEventRecord(ev_dy_ready, stream));   // coefficients final: the second stream may produce dy
                 HIP_CHECK(hipStreamWaitEvent(aux_stream, ev_dy_ready, 0));
                 apply_on = aux_stream;
                 if (has_dgrad) b.dy_out = s.dyp.p;               // da stays intact for the conv on the main stream
             }
+            if (dgrad_writes_dy) b.dy_out = s.dyp.p;
             // a layer without backward-data conv (the stem): only its filter gradient consumes dy, and the stem wgrad
             // kernel can compute dy from (da, y) while staging -> no apply pass on the critical path
             WgradArgs probe;
@@ -529,7 +548,7 @@ void Engine::backward(const uint16_t* d_labels, const float* d_weights, double l
             probe.n = s.n; probe.h_in = s.h_in; probe.w_in = s.w_in; probe.c_in = L.cin; probe.h_out = s.h; probe.w_out = s.w; probe.c_out = L.cout;
             probe.k = L.k; probe.stride = L.stride; probe.pad = L.pad; probe.gather = L.type;
             wgrad_computes_dy = !has_dgrad && wgrad_accepts_bnbwd(probe, dtype);
-            if (!wgrad_computes_dy) {
+            if (!wgrad_computes_dy && !dgrad_writes_dy) {
                 tok = prof.begin(apply_on, "bn_bwd_apply", 0, (double)p_out * L.cout * es * 3);
                 launch_bn_bwd_apply(b, apply_on);
                 prof.end(apply_on, tok);
@@ -539,10 +558,11 @@ void Engine::backward(const uint16_t* d_labels, const float* d_weights, double l
                 dg.src.kind = SRC_BNBWD; dg.src.a = s.dact.p; dg.src.b = s.raw.p;
                 dg.src.a_scale = s.scale; dg.src.a_shift = s.shift;
                 dg.src.bn_mean = s.mean; dg.src.bn_invstd = s.invstd; dg.src.bn_coef = s.coef;
+                if (dgrad_writes_dy) dg.dy_out = s.dyp.p;
             } else if (has_dgrad) dg.src.a = dy;
         } else { dy = dlogits.p; dy_dt = DT_F32; if (has_dgrad) dg.src.a = dy; }
 
-        {   // filter gradient
+        auto run_wgrad = [&]() {   // filter gradient
             WgradArgs g;
             g.src = layer_source(li, last_image);
             g.dy = dy; g.dy_dtype = dy_dt;
@@ -562,15 +582,15 @@ void Engine::backward(const uint16_t* d_labels, const float* d_weights, double l
             static const bool tail_on_main = getenv("ANH_STEM_WGRAD_MAIN") ? atoi(getenv("ANH_STEM_WGRAD_MAIN")) != 0 : true;
             const bool on_main = two_streams && !has_dgrad && tail_on_main;
             if (two_streams && !on_main) {
-                if (!fused_apply) {   // dy of this layer is final on the main stream: let the second stream pick it up
+                if (!fused_apply || dgrad_writes_dy) {   // dy of this layer is final on the main stream: let the second stream pick it up
                     HIP_CHECK(hipEventRecord(ev_dy_ready, stream));
                     HIP_CHECK(hipStreamWaitEvent(aux_stream, ev_dy_ready, 0));
                 }
                 on = aux_stream;
             }
-            wgrad_dispatch(g, (std::string("wgrad_") + layer_tag(L)).c_str(), flops, bytes, on, on_main ? wgrad_partials_main : wgrad_partials);
-        }
-        if (has_dgrad) {   // data gradient -> d(activation of the producing layers)
+            wgrad_dispatch(g, (std::string("wgrad_") + layer_tag(li, L)).c_str(), flops, bytes, on, on_main ? wgrad_partials_main : wgrad_partials);
+        };
+        auto run_dgrad = [&]() {   // data gradient -> d(activation of the producing layers)
             LayerState& P = ls[L.in_a];
             const anh_layer_desc& PL = spec.layers[L.in_a];
             P.dact_written = true; ++P.da_writes;
@@ -585,10 +605,13 @@ void Engine::backward(const uint16_t* d_labels, const float* d_weights, double l
                     P.fused_bwd_blocks = blocks;
                 }
             }
-            const double bytes = (double)p_out * L.cout * (L.has_bn ? es : 4.0) * (dg.src.kind == SRC_BNBWD ? 2 : 1) +
+            const double bytes = (double)p_out * L.cout * (L.has_bn ? es : 4.0) * (dg.src.kind == SRC_BNBWD ? (dg.dy_out ? 3 : 2) : 1) +
                                  (double)p_in * L.cin * es * (L.in_b >= 0 ? 2 : 1) * (dg.out_accumulate ? 2 : 1);
-            conv_dispatch(dg, (std::string("dgrad_") + layer_tag(L)).c_str(), flops, bytes);
-        }
+            conv_dispatch(dg, (std::string("dgrad_") + layer_tag(li, L)).c_str(), flops, bytes);
+        };
+        // the filter gradient reads dy: when the backward-data conv is the kernel that writes dy, it goes first
+        if (dgrad_writes_dy) { run_dgrad(); run_wgrad(); }
+        else { run_wgrad(); if (has_dgrad) run_dgrad(); }
     }
     if (concurrent_wgrad && aux_stream) {  // gradients are complete on the main stream only after the aux stream drains
         HIP_CHECK(hipEventRecord(ev_aux_done, aux_stream));
@@ -664,7 +687,7 @@ void Engine::infer_tile(const anh_tile& t, const uint8_t* d_image, int H, int W,
     hb.src = layer_source((int)spec.layers.size() - 1, image); hb.c_in = head.cin; hb.k = head.cout;
     const bool fuse_head = !training && head.k == 1 && head.has_bias && head.in_a >= 0 && head_blend_supported(hb);
     if (fuse_head) {
-        ++prof.pass_index;
+        prof.start_pass();
         plan_dims(1, win.height, win.width);
         for (size_t li = 0; li + 1 < spec.layers.size(); ++li) run_conv_forward((int)li, image, false, nullptr);
     } else {

@@ -58,6 +58,10 @@ struct ConvArgs {
     const void* bnred_y = nullptr;
     const float* bnred_scale = nullptr; const float* bnred_shift = nullptr; const float* bnred_mean = nullptr; const float* bnred_invstd = nullptr;
     double* bnred_partials = nullptr;
+    // SRC_BNBWD only: the staging waves also write the dy they compute ([n][h_in][w_in][c_red], storage dtype) — every
+    // input pixel belongs to the core of exactly one pixel tile — so that the layer's filter gradient reads dy instead of
+    // recomputing it and no separate bn backward apply pass runs (conv_writes_dy() says whether the layer's kernel does)
+    void* dy_out = nullptr;
 };
 
 // dw[tap][ci][co] = sum_pixels src(n, iy, ix, ci) * dy[n,oy,ox,co]; same gather convention as ConvArgs.
@@ -233,7 +237,11 @@ int conv_fused_stat_blocks(const ConvArgs& a);
 int conv_fused_bnred_blocks(const ConvArgs& a);   // same for ConvArgs::bnred_partials (backward-data convs)
 // the layer's MFMA kernel can read its input through SRC_BNBWD (decided on the args with src.kind = SRC_RAW)
 bool conv_accepts_bnbwd(const ConvArgs& a);
-bool bn_bwd_apply_fusion_enabled();  // ANH_FUSE_BN_BWD_APPLY=1 (off by default: measured slower)
+// ANH_FUSE_BN_BWD_APPLY: 0 = separate apply pass, 1 = backward-data conv applies bn backward in its prologue and the apply
+// pass runs on the second stream, 2 = that conv also writes dy (ConvArgs::dy_out): no apply pass at all
+int bn_bwd_apply_fusion_mode();
+inline bool bn_bwd_apply_fusion_enabled() { return bn_bwd_apply_fusion_mode() != 0; }
+bool conv_writes_dy(const ConvArgs& a);   // decided on the args with src.kind = SRC_BNBWD
 bool mfma_wgrad_supported(const WgradArgs& a);
 void launch_wgrad_mfma(const WgradArgs& a, hipStream_t s);
 int64_t wgrad_mfma_scratch_floats(const WgradArgs& a);

@@ -28,9 +28,11 @@ namespace anh {
 void ensure_dynamic_lds(const void* kernel, size_t bytes) {
     if (bytes <= 64 * 1024) return;   // the default limit
     static std::mutex mu;   // handles may be driven from different threads
-    static std::unordered_map<const void*, size_t> configured;
+    static std::unordered_map<const void*, size_t> configured[64];   // the attribute is per (device, kernel)
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lock(mu);
-    size_t& have = configured[kernel];
+    size_t& have = configured[dev & 63][kernel];
     if (bytes > have) {
         HIP_CHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
         have = bytes;
@@ -924,6 +926,8 @@ struct GeoS1 {
     __device__ static void decode(int rec, int& py, int& px, int& key) { py = rec / PW; px = rec - py * PW; key = (px >> 2) & 3; }
     __device__ static int in_y0(int ty) { return ty * TH - 1; }
     __device__ static int in_x0(int tx) { return tx * TW - 1; }
+    // core of a patch = the input pixels no other tile's core holds (the rest is halo): every in-tensor pixel is core once
+    __device__ static bool core(int py, int px, bool, bool) { return py >= 1 && py <= TH && px >= 1 && px <= TW; }
     static constexpr int NB = 3;  // one lane base per kx
     struct Bases { const char* x[3][2]; };
     __device__ static void init(Bases& b, const char* lds_x, int wave, int col, int half) {
@@ -975,6 +979,8 @@ struct GeoDown {
     }
     __device__ static int in_y0(int ty) { return ty * 8; }
     __device__ static int in_x0(int tx) { return tx * 64; }
+    // the ninth row / 65th column is the next tile's first one, except behind the last tile row / column
+    __device__ static bool core(int py, int px, bool last_y, bool last_x) { return (py < 8 || last_y) && (px < 64 || last_x); }
     static constexpr int NB = 2;
     struct Bases { const char* x[2][2]; };  // [kx >> 1][ks]
     __device__ static void init(Bases& b, const char* lds_x, int wave, int col, int half) {
@@ -1013,6 +1019,7 @@ struct GeoUp {
     __device__ static void decode(int rec, int& py, int& px, int& key) { py = rec / 33; px = rec - py * 33; key = (px >> 2) & 3; }
     __device__ static int in_y0(int ty) { return ty * 4 - 1; }
     __device__ static int in_x0(int tx) { return tx * 32 - 1; }
+    __device__ static bool core(int py, int px, bool, bool) { return py >= 1 && px >= 1; }
     static constexpr int NB = 2;
     struct Bases { const char* x[2][2]; };  // [ib][ks]: input column j - ib, row i - 1 (the immediate adds a row for ia = 0)
     __device__ static void init(Bases& b, const char* lds_x, int wave, int col, int half) {
@@ -1157,6 +1164,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
         RawChunk<KIND> praw[NP];
         u32x4 wraw[NW];  // a native vector type: hipcc keeps a HIP uint4 that is only copied (never unpacked) in scratch
         unsigned pok = 0;
+        // SRC_BNBWD with ConvArgs::dy_out: the dy chunks this thread computes for the CORE pixels of its patch also go to memory
+        // (first channel group only: the groups stage the same patches) — poff / pcore / dyo describe the fetched item
+        const bool write_dy = KIND == SRC_BNBWD && a.dy_out != nullptr && blockIdx.y == 0;
+        int poff[KIND == SRC_BNBWD ? NP : 1];
+        unsigned pcore = 0;
+        bf16* dyo = nullptr;
         auto fetch = [&](int tile_, int slab_, bool with_w) __attribute__((always_inline)) {
             const int tx = tile_ % tiles_x, ty = (tile_ / tiles_x) % tiles_y, n = tile_ / (tiles_x * tiles_y);
             const int x0 = G::in_x0(tx), y0 = G::in_y0(ty);
@@ -1164,12 +1177,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
             const bf16* pb = (KIND == SRC_ACT2 || KIND == SRC_BNBWD) ? xb + (size_t)n * plane : nullptr;
             const int cc = slab_ * 32;
             pok = 0;
+            if (KIND == SRC_BNBWD) { pcore = 0; dyo = reinterpret_cast<bf16*>(a.dy_out) + (size_t)n * plane; }
 #pragma unroll
             for (int jj = 0; jj < NP; ++jj) {
                 const int iy = y0 + (pgeo[jj] & 255), ix = x0 + (pgeo[jj] >> 8);
                 const int cy = min(max(iy, 0), H - 1), cx = min(max(ix, 0), W - 1);
-                praw[jj] = side_load_at<KIND>(pa, pb, (cy * W + cx) * c_red + cc + c16 * 8);
+                const int off = (cy * W + cx) * c_red + cc + c16 * 8;
+                praw[jj] = side_load_at<KIND>(pa, pb, off);
                 pok |= ((iy == cy && ix == cx) ? 1u : 0u) << jj;
+                if (KIND == SRC_BNBWD) {
+                    poff[jj] = off;
+                    pcore |= (G::core(pgeo[jj] & 255, pgeo[jj] >> 8, ty == tiles_y - 1, tx == tiles_x - 1) ? 1u : 0u) << jj;
+                }
             }
             if (with_w) {
 #pragma unroll
@@ -1213,6 +1232,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
                     uint4 v = KIND == SRC_BNBWD ? chunk_bnbwd(praw[jj].a, praw[jj].b, sa, ta, sb, tb, q0, q1, q2) : chunk_convert<KIND>(praw[jj], sa, ta, sb, tb);
                     if (!((pok >> jj) & 1u)) v = make_uint4(0u, 0u, 0u, 0u);
                     if ((tid >> 2) + 64 * jj < G::RECS) *reinterpret_cast<uint4*>(lbuf + pdst[jj]) = v;
+                    if (KIND == SRC_BNBWD) {
+                        if (write_dy && ((pok & pcore) >> jj & 1u) && (tid >> 2) + 64 * jj < G::RECS) *reinterpret_cast<uint4*>(dyo + poff[jj]) = v;
+                    }
                 }
                 if (stage_w) {
 #pragma unroll
@@ -2062,10 +2084,12 @@ bool bnbwd_form_ok(const ConvArgs& a) {
 }
 }  // namespace
 
-bool bn_bwd_apply_fusion_enabled() {
+int bn_bwd_apply_fusion_mode() {
     static const int on = getenv("ANH_FUSE_BN_BWD_APPLY") ? atoi(getenv("ANH_FUSE_BN_BWD_APPLY")) : 0;
-    return on != 0;
+    return on;
 }
+
+bool conv_writes_dy(const ConvArgs& a) { return bn_bwd_apply_fusion_mode() == 2 && a.src.kind == SRC_BNBWD && mfma_conv_supported(a) && !stem_mfma_ok(a); }
 
 bool conv_accepts_bnbwd(const ConvArgs& a) {
     ConvArgs b = a;

@@ -1,0 +1,73 @@
+// multidev.h — one process driving several GPUs of a node (anh_set_devices): the device selection of a host thread, the
+// exchange step between the replicas of a handle (RCCL over xGMI), and the host logic that decides who owns what.
+//   training  (annonet_train_main.cpp:583-614): the mini-batch is split along N, every replica runs forward + backward on its
+//             share with the loss scale of the WHOLE batch, ONE all-reduce (sum) of the flat gradient bucket, identical update;
+//   inference (annonet_infer.cpp:46-165): the tile list is split into contiguous row-major chunks, every replica blends its
+//             tiles into planes of its own, the plane sums are exchanged ONLY where tiles of different replicas overlap.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <memory>
+#include <vector>
+
+#include "common.h"
+
+namespace anh {
+
+// HIP's current device is per host thread; every call into a replica runs under its device
+struct DeviceScope {
+    int prev = -1, cur = -1;
+    explicit DeviceScope(int device) : cur(device) {
+        if (device < 0) return;
+        HIP_CHECK(hipGetDevice(&prev));
+        if (prev != device) HIP_CHECK(hipSetDevice(device));
+    }
+    ~DeviceScope() { if (cur >= 0 && prev != cur) (void)hipSetDevice(prev); }
+    DeviceScope(const DeviceScope&) = delete;
+    DeviceScope& operator=(const DeviceScope&) = delete;
+};
+
+// anh_set_devices: the devices that handles created afterwards ON THIS THREAD drive (empty = the thread's current device)
+const std::vector<int>& selected_devices();
+void select_devices(const int* devices, int n);
+
+// replica r of `world` takes the units [lo, hi) of n (mini-batch samples, tiles): contiguous chunks, sizes differ by at most 1
+inline void shard_range(int64_t n, int world, int rank, int64_t& lo, int64_t& hi) { lo = n * rank / world; hi = n * (rank + 1) / world; }
+
+// The rectangles (inclusive, clipped to the image) in which tiles owned by DIFFERENT replicas overlap: the only pixels where a
+// replica's blended planes hold partial sums.  Pairwise intersections; they may overlap each other (the exchange is idempotent).
+std::vector<anh_rect> cross_replica_overlaps(const std::vector<anh_tile>& tiles, int world, int width, int height);
+
+// SUM over the replicas of one fp32 buffer each, the result left in every buffer; enqueued on the replicas' own streams.
+//   distinct devices  -> RCCL: one communicator per device (ncclCommInitAll), one grouped ncclAllReduce — xGMI, no host copy;
+//   a repeated device -> rehearsal backend for boxes with fewer GPUs than replicas (tests): fixed-order sum on replica 0's
+//                        stream, then copies back.  Same result up to fp32 summation order.
+class Collective {
+  public:
+    explicit Collective(const std::vector<int>& devices);
+    ~Collective();
+    void all_reduce_sum(const std::vector<float*>& bufs, size_t count, const std::vector<hipStream_t>& streams);
+    bool uses_rccl() const { return !comms_.empty(); }
+    int world() const { return (int)devices_.size(); }
+
+  private:
+    std::vector<int> devices_;
+    std::vector<void*> comms_;   // ncclComm_t
+    std::vector<hipEvent_t> ready_;
+    hipEvent_t done_ = nullptr;
+    DevBuf scratch_;
+};
+
+// gather / scatter of plane pixels inside a list of rectangles: packed[k][offset_j + (y - top_j) * w_j + (x - left_j)] <-> planes[k][y][x]
+struct RectTable {
+    std::vector<anh_rect> rects;
+    std::vector<int64_t> offset;   // first packed index of each rectangle; back() = total
+    int64_t total() const { return offset.empty() ? 0 : offset.back(); }
+};
+RectTable make_rect_table(const std::vector<anh_rect>& rects);
+void launch_pack_rects(const float* planes, int k, int height, int width, const anh_rect* d_rects, const int64_t* d_offsets, int n_rects, int64_t total,
+                       float* packed, hipStream_t s);
+void launch_unpack_rects(float* planes, int k, int height, int width, const anh_rect* d_rects, const int64_t* d_offsets, int n_rects, int64_t total,
+                         const float* packed, hipStream_t s);
+
+}  // namespace anh

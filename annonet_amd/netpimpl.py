@@ -23,6 +23,32 @@ def net_config(levels=2, in_channels=3, classes=3, width_scaler=1.0, min_filters
     return NetConfig(levels, in_channels, classes, width_scaler, min_filters, precision)
 
 
+def set_devices(devices):
+    """anh_set_devices: handles created afterwards on this thread hold one replica per listed device ([] = back to one device)."""
+    arr = (C.c_int * max(len(devices), 1))(*devices)
+    check(_lib.lib().anh_set_devices(arr, len(devices)))
+
+
+def shard_range(n, world, rank):
+    lo, hi = C.c_int64(), C.c_int64()
+    check(_lib.lib().anh_shard_range(n, world, rank, C.byref(lo), C.byref(hi)))
+    return lo.value, hi.value
+
+
+def cross_replica_overlaps(tiles, world, width, height):
+    """tiles: list of (full, unique) rectangles -> sorted list of (l, t, r, b): where tiles of different replicas overlap"""
+    arr = (_lib.Tile * max(len(tiles), 1))()
+    for i, (full, uniq) in enumerate(tiles):
+        arr[i].full_rect = _lib.Rect(*full)
+        arr[i].unique_rect = _lib.Rect(*uniq)
+    rects, n = C.POINTER(_lib.Rect)(), C.c_size_t()
+    check(_lib.lib().anh_cross_replica_overlaps(arr, len(tiles), world, width, height, C.byref(rects), C.byref(n)))
+    try:
+        return [rects[i].tuple() for i in range(n.value)]
+    finally:
+        _lib.lib().anh_free(rects)
+
+
 def net_layers(cfg):
     L = _lib.lib()
     n = L.anh_net_layer_count(C.byref(cfg))
@@ -179,6 +205,14 @@ class _Profiled:
 
     def profile_reset(self):
         check(self.L.anh_profile_reset(self.h, self._is_trainer))
+
+    def profile_launch_order(self):
+        """Entry names of the most recent pass in host enqueue order (one per kernel-class launch)."""
+        need = C.c_size_t()
+        check(self.L.anh_profile_launch_order(self.h, self._is_trainer, None, 0, C.byref(need)))
+        buf = C.create_string_buffer(max(need.value, 1))
+        check(self.L.anh_profile_launch_order(self.h, self._is_trainer, buf, need.value, None))
+        return [x for x in buf.value.decode().split("\n") if x]
 
     def profile(self):
         n = self.L.anh_profile_count(self.h, self._is_trainer)
@@ -439,6 +473,14 @@ class TrainingNet(_Profiled):
         p = np.ascontiguousarray(params, dtype=np.float32)
         r = np.ascontiguousarray(running, dtype=np.float32)
         check(self.L.anh_trainer_set_params(self.h, _ptr(p), p.size, _ptr(r), r.size))
+
+    def replicas(self):
+        return self.L.anh_handle_replicas(self.h, 1)
+
+    def replica_params(self, replica):
+        p = np.empty(self.n_params, np.float32)
+        check(self.L.anh_trainer_replica_params(self.h, replica, _ptr(p), p.size))
+        return p
 
     def get_grads(self):
         g = np.empty(self.n_params, np.float32)

@@ -2,25 +2,36 @@
 """bench.py — BASELINE.json's metric on its config: 227x227 RGB tiles/s, training step (forward + loss + backward +
 SGD update), batch 32 per GPU, bf16, random-init net (levels 2, width 1.0, K=3), synthetic tiles.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            (N > 1: starts N rank processes itself, see self_launch)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    python bench.py --mode infer [--image-side 4096]         BASELINE.json configs[2] / [4]: tiled inference, Mpx/s
 
 One process per GPU; for N > 1 the only exchange step of the path is the all-reduce (RCCL) of the flat gradient
-bucket.  Inputs are resident in HBM before the timed region.  Prints ONE JSON line on rank 0, with
-  roofline     — the dominant kernel class: algorithmic flops (or bytes) per launch / its mean launch time, measured
-                 with HIP events on the compute stream inside the timed region;
-  cpu_baseline — the oracle (a CPU port of the path, see oracle/) timed on this host on a bounded sample.
+bucket (training) / of the cross-rank overlap sums (inference).  Inputs are resident in HBM before the timed region.
+Prints ONE JSON line on rank 0, with
+  roofline     — the §8d conv entry (layer x pass) with the largest time: algorithmic flops and minimum bytes per launch
+                  / its mean launch time, measured with HIP events on the compute stream inside the
+                 timed region; `traffic` = HBM-side bytes per launch from the committed rocprofv3 --pmc passes;
+  layers       — every layer x {fwd, bwd-data, bwd-filter}: time (HIP events, untimed profile pass of the same step),
+                 §8d flops and minimum bytes, bound = min(MFMA, AI x HBM), fraction of that bound;
+  overhead_kernels — everything in the step that is not a §8d conv pass (bn finalize / apply, partial sums, SGD ...);
+  cpu_baseline — the oracle (a CPU port of the path, see oracle/) timed on this host on a bounded sample, all threads and
+                 one thread, plus a PyTorch-CPU (oneDNN) figure of the same net as a second, clearly labelled baseline;
+  ranks_seen / devices — an all-reduce of ones and the device index of every rank.
 """
 import argparse
 import json
-import re
 import os
+import re
+import socket
+import subprocess
 import sys
 import time
 
 import numpy as np
 
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before HIP initialises: keeps the trainer's two streams on separate hardware queues (annonet_amd/_lib.py)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -32,20 +43,39 @@ LEVELS, WIDTH, CLASSES = 2, 1.0, 3
 PEAK_HBM_GBS = 8000.0
 PEAK_BF16_TFLOPS = 2500.0
 RIDGE = PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
+PROFILE_STEPS = 4          # untimed all-kernel profile pass (feeds `layers`)
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r02_traffic.json")
 
 
-def pmc_traffic(entry):
-    """HBM-side bytes per launch of a profiler entry, from the committed rocprofv3 --pmc passes (tools/pmc_traffic.py)."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json")
-    try:
-        with open(path) as f:
-            entries = json.load(f)["entries"]
-            e = entries.get(entry) or entries.get(re.sub(r"_\d+x\d+$", "", entry))  # conv/wgrad entries carry a channel-shape suffix
-        return e["traffic_bytes_per_launch"] if e else None
-    except (OSError, ValueError, KeyError):
-        return None
+# ----------------------------------------------------------------------------------------------------------------------
+# N > 1 from `python bench.py --gpus N` alone: start the rank processes as fresh children BEFORE anything touches the GPU
+# ----------------------------------------------------------------------------------------------------------------------
+def self_launch(args):
+    """WORLD_SIZE unset and --gpus N > 1: run `python -m torch.distributed.run --nproc-per-node N bench.py <same args>` as a
+    child (one fresh process per GPU, rendezvous on 127.0.0.1), pass its output through and exit with its return code.
+    This process never initialises HIP (counting devices does not)."""
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) visible", file=sys.stderr)
+        sys.exit(2)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:        # rank 0's JSON line (and nothing else goes to the children's stdout)
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    sys.exit(proc.wait())
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# workload
+# ----------------------------------------------------------------------------------------------------------------------
 def synthetic_batch(rank):
     import annonet_amd as aa
     rng_img = np.random.default_rng(1000 * rank + 0)
@@ -57,8 +87,118 @@ def synthetic_batch(rank):
     return img, lab, w
 
 
-def cpu_baseline(sample_tiles=4):
-    """The oracle's training step on `sample_tiles` tiles of the same workload, all host cores (OpenMP)."""
+def layer_geometry(aa, cfg, side):
+    """(h_in, h_out) of every layer for a square input of `side` (the spec's dimension rule: con (h+2p-k)/s+1, cont (h-1)s+k-2p)."""
+    layers = aa.net_layers(cfg)
+    dims = []
+    for L in layers:
+        h_in = side if L.in_a < 0 else dims[L.in_a][1]
+        h_out = (h_in + 2 * L.pad - L.k) // L.stride + 1 if L.type == 0 else (h_in - 1) * L.stride + L.k - 2 * L.pad
+        dims.append((h_in, h_out))
+    return layers, dims
+
+
+def section8d(layers, dims, li, n, first_layer_u8=True):
+    """SURVEY.md §8d per pass of layer li: flops = 2 k^2 Cin Cout P, minimum bf16 traffic = 2 (Cin P_in + Cout P_out) + 2 k^2 Cin Cout bytes
+    (P = pixels of the low-res side for stride 2; the stem reads a u8 image: 1 byte per value)."""
+    L = layers[li]
+    p_in, p_out = n * dims[li][0] ** 2, n * dims[li][1] ** 2
+    flops = 2.0 * L.k * L.k * L.cin * L.cout * (p_out if L.type == 0 else p_in)
+    in_bytes = L.cin * p_in * (1 if (L.in_a < 0 and first_layer_u8) else 2)
+    min_bytes = in_bytes + 2.0 * L.cout * p_out + 2.0 * L.k * L.k * L.cin * L.cout
+    return flops, min_bytes
+
+
+def bound_of(flops, min_bytes, seconds):
+    """min(MFMA, AI x HBM) roofline of one launch: the floor time is the larger of the two resource times."""
+    t_mfma, t_hbm = flops / (PEAK_BF16_TFLOPS * 1e12), min_bytes / (PEAK_HBM_GBS * 1e9)
+    bound = "mfma" if t_mfma >= t_hbm else "hbm"
+    out = {"bound": bound, "floor_us": 1e6 * max(t_mfma, t_hbm), "frac": max(t_mfma, t_hbm) / seconds if seconds > 0 else 0.0}
+    if bound == "mfma":
+        out.update(achieved=flops / seconds / 1e12, peak=PEAK_BF16_TFLOPS, unit="TFLOP/s")
+    else:
+        out.update(achieved=min_bytes / seconds / 1e9, peak=PEAK_HBM_GBS, unit="GB/s")
+    return out
+
+
+ENTRY_RE = re.compile(r":(fwd|dgrad|wgrad)_L(\d+)_(\w+?)_(\d+)x(\d+)$")
+PASS_NAME = {"fwd": "fwd", "dgrad": "bwd-data", "wgrad": "bwd-filter"}
+
+
+def split_entries(prof, layers, dims, n, per_steps):
+    """-> (layers array, overhead array) from the profiler entries of `per_steps` passes."""
+    convs, other = [], []
+    total_ms = sum(e["total_ms"] for e in prof) or 1.0
+    for e in prof:
+        if not e["launches"]:
+            continue
+        m = ENTRY_RE.search(e["name"])
+        t_us = 1e3 * e["total_ms"] / e["launches"]
+        if m and layers[int(m.group(2))].k > 1:
+            li = int(m.group(2))
+            flops, min_bytes = section8d(layers, dims, li, n)
+            row = {"entry": e["name"], "layer": li, "kind": m.group(3), "cin": int(m.group(4)), "cout": int(m.group(5)), "side": dims[li][1],
+                   "pass": PASS_NAME[m.group(1)], "time_us": round(t_us, 2), "gflop": round(flops / 1e9, 3), "min_mb": round(min_bytes / 1e6, 2),
+                   "design_mb": round(e["bytes"] / e["launches"] / 1e6, 2), "flop_per_byte": round(flops / min_bytes, 1)}
+            b = bound_of(flops, min_bytes, t_us * 1e-6)
+            row.update(bound=b["bound"], floor_us=round(b["floor_us"], 2), frac=round(b["frac"], 4), achieved=round(b["achieved"], 1), unit=b["unit"])
+            convs.append(row)
+        else:
+            other.append({"entry": e["name"], "launches_per_step": e["launches"] / per_steps, "us_per_step": round(1e3 * e["total_ms"] / per_steps, 2),
+                          "share_pct": round(100 * e["total_ms"] / total_ms, 1), "design_mb_per_step": round(e["bytes"] / per_steps / 1e6, 2)})
+    convs.sort(key=lambda r: (r["layer"], r["pass"]))
+    other.sort(key=lambda r: -r["us_per_step"])
+    return convs, other
+
+
+def pmc_traffic(entry):
+    """HBM-side bytes per launch of a profiler entry, from the committed rocprofv3 --pmc passes (tools/pmc_traffic.py)."""
+    try:
+        with open(TRAFFIC_JSON) as f:
+            e = json.load(f)["entries"].get(entry)
+        return e["traffic_bytes_per_launch"] if e else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# CPU baselines (rank 0, N = 1 only; bounded samples)
+# ----------------------------------------------------------------------------------------------------------------------
+def _omp_set_threads(n):
+    import ctypes
+    ctypes.CDLL("libgomp.so.1").omp_set_num_threads(int(n))
+
+
+def torch_cpu_net(aa, cfg):
+    """The same encoder-decoder in PyTorch (fp32, CPU, oneDNN convolutions) — a second, independent CPU baseline; random init."""
+    import torch
+    import torch.nn as nn
+    layers = aa.net_layers(cfg)
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.convs, self.bns = nn.ModuleList(), nn.ModuleList()
+            for L in layers:
+                conv = (nn.Conv2d if L.type == 0 else nn.ConvTranspose2d)(L.cin, L.cout, L.k, stride=L.stride, padding=L.pad, bias=bool(L.has_bias))
+                self.convs.append(conv)
+                self.bns.append(nn.BatchNorm2d(L.cout, eps=1e-4) if L.has_bn else nn.Identity())
+
+        def forward(self, x):
+            acts = []
+            for i, L in enumerate(layers):
+                a = x if L.in_a < 0 else acts[L.in_a]
+                if L.in_b >= 0:
+                    a = a + acts[L.in_b]
+                y = self.bns[i](self.convs[i](a))
+                acts.append(torch.relu(y) if L.has_bn else y)
+            return acts[-1]
+    return Net()
+
+
+def cpu_baseline_train(aa, cfg):
+    """The oracle's training step on a bounded sample of the same workload: all threads of this job's CPU share, then one
+    thread; plus PyTorch-CPU (oneDNN) on the same sample size."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from conftest import random_params
     from oracle.oracle import OracleNet
@@ -66,24 +206,101 @@ def cpu_baseline(sample_tiles=4):
     p, r = random_params(o, 2)
     o.params[:], o.running[:] = p, r
     img, lab, w = synthetic_batch(0)
+    cores = int(os.environ["OMP_NUM_THREADS"])   # set by oracle/oracle.py: the CPUs this job may use, capped at 16 (a one-GPU box's share)
     o.train_step(img[:1], lab[:1], w[:1])  # warm-up (page-in, OpenMP pool)
     t0 = time.perf_counter()
     o.train_step(img[:2], lab[:2], w[:2], apply_update=False)  # estimate of the per-tile cost
     per_tile = (time.perf_counter() - t0) / 2
-    sample_tiles = int(min(len(img), max(sample_tiles, round(20.0 / max(per_tile, 1e-3)))))  # ~10-20 s of CPU work, at most the whole batch
-    img, lab, w = img[:sample_tiles], lab[:sample_tiles], w[:sample_tiles]
+    n_all = int(min(len(img), max(4, round(10.0 / max(per_tile, 1e-3)))))  # ~10 s of CPU work, at most the whole batch
     t0 = time.perf_counter()
-    o.train_step(img, lab, w)
-    dt = time.perf_counter() - t0
-    cores = int(os.environ["OMP_NUM_THREADS"])   # set by oracle/oracle.py: the CPUs this job may use, capped at 16 (a one-GPU box's share)
-    return {"value": sample_tiles / dt, "unit": "tiles/s", "cores": cores, "kind": "port",
-            "sample": f"1 training step on {sample_tiles} tiles of {TILE}x{TILE}x3 (same net, fp32 CPU oracle, {dt:.2f} s)"}
+    o.train_step(img[:n_all], lab[:n_all], w[:n_all])
+    dt_all = time.perf_counter() - t0
+    _omp_set_threads(1)
+    n_one = int(max(1, min(n_all, round(8.0 / max(per_tile * cores, 1e-3)))))   # ~8 s on one thread
+    t0 = time.perf_counter()
+    o.train_step(img[:n_one], lab[:n_one], w[:n_one], apply_update=False)
+    dt_one = time.perf_counter() - t0
+    _omp_set_threads(cores)
+    out = {"value": n_all / dt_all, "unit": "tiles/s", "cores": cores, "kind": "port",
+           "sample": f"1 training step on {n_all} tiles of {TILE}x{TILE}x3 (same net, fp32 CPU oracle: direct convolution, OpenMP; {dt_all:.2f} s)",
+           "one_thread": {"value": n_one / dt_one, "unit": "tiles/s", "cores": 1, "sample": f"fwd+bwd on {n_one} tile(s), {dt_one:.2f} s"}}
+    try:
+        import torch
+        torch.set_num_threads(cores)
+        net = torch_cpu_net(aa, cfg)
+        opt = torch.optim.SGD(net.parameters(), lr=0.1, momentum=0.9, weight_decay=0.0005)
+        nb = min(n_all, 8)
+        x = torch.from_numpy(img[:nb].astype(np.float32) / 256.0).permute(0, 3, 1, 2).contiguous()
+        y = torch.from_numpy(np.where(lab[:nb] == 65535, -100, lab[:nb].astype(np.int64)))
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            loss = torch.nn.functional.cross_entropy(net(x), y, ignore_index=-100)
+            loss.backward()
+            opt.step()
+        step()
+        t0 = time.perf_counter()
+        reps = 0
+        while time.perf_counter() - t0 < 6.0:
+            step()
+            reps += 1
+        dt = time.perf_counter() - t0
+        out["pytorch_cpu"] = {"value": reps * nb / dt, "unit": "tiles/s", "cores": cores, "kind": "independent PyTorch-CPU (oneDNN) fp32 statement of the same net, not the reference",
+                              "sample": f"{reps} training steps on {nb} tiles, {dt:.2f} s"}
+    except Exception as e:   # a baseline, never a reason to lose the bench line
+        out["pytorch_cpu"] = {"error": repr(e)}
+    return out
+
+
+def cpu_baseline_infer(aa, cfg, ov):
+    """The oracle's annonet_infer() on a bounded crop (all threads, then one thread), Mpx/s."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import random_params
+    from oracle.oracle import OracleNet
+    o = OracleNet(LEVELS, 3, CLASSES, WIDTH, 1)
+    p, r = random_params(o, 2)
+    o.params[:], o.running[:] = p, r
+    cores = int(os.environ["OMP_NUM_THREADS"])
+    rng = np.random.default_rng(3)
+    side = 227
+    o.infer(rng.integers(0, 256, (side, side, 3), dtype=np.uint8))
+    t0 = time.perf_counter()
+    o.infer(rng.integers(0, 256, (side, side, 3), dtype=np.uint8))
+    per_px = (time.perf_counter() - t0) / (side * side)
+    side_all = int(min(1500, max(300, (8.0 / per_px) ** 0.5)))     # ~8 s of CPU work
+    image = rng.integers(0, 256, (side_all, side_all, 3), dtype=np.uint8)
+    t0 = time.perf_counter()
+    o.infer(image, max_tile=(1024, 1024), overlap=ov)
+    dt_all = time.perf_counter() - t0
+    _omp_set_threads(1)
+    side_one = int(max(227, side_all / max(cores, 1) ** 0.5))
+    t0 = time.perf_counter()
+    o.infer(image[:side_one, :side_one], max_tile=(1024, 1024), overlap=ov)
+    dt_one = time.perf_counter() - t0
+    _omp_set_threads(cores)
+    return {"value": side_all * side_all / dt_all / 1e6, "unit": "Mpx/s", "cores": cores, "kind": "port",
+            "sample": f"annonet_infer() of a {side_all}x{side_all} crop of the same synthetic image (fp32 CPU oracle, {dt_all:.2f} s)",
+            "one_thread": {"value": side_one * side_one / dt_one / 1e6, "unit": "Mpx/s", "cores": 1, "sample": f"{side_one}x{side_one} crop, {dt_one:.2f} s"}}
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def dist_facts(torch, dist, dev, local_rank, world, use_dist):
+    """ranks_seen = all-reduce of ones; devices = every rank's device index (proves N distinct ranks drove N devices)."""
+    if not use_dist:
+        return 1, [local_rank]
+    ones = torch.ones(1, device=dev)
+    dist.all_reduce(ones)
+    mine = torch.tensor([local_rank], device=dev, dtype=torch.int64)
+    gathered = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(gathered, mine)
+    return int(ones.item()), [int(g.item()) for g in gathered]
 
 
 def bench_infer(args, aa, aad, torch, dist, prec, rank, local_rank, world, use_dist):
     """BASELINE.json configs[2] / [4]: tiled sliding-window inference over one synthetic image, tiles sharded across ranks.
     Timed: tile cut + forward + blend, the exchange of the cross-rank overlap sums (one RCCL all-reduce of ~2 % of the
-    planes; nothing at one GPU) and argmax; image and label map resident in HBM."""
+    planes; nothing at one GPU) and argmax; image and label map resident in HBM.  `value_labels_on_host` times the same
+    passes with the label map copied to (pinned) host memory inside the timed region (SURVEY.md §8d's unit)."""
     side = args.image_side
     dev = torch.device("cuda", local_rank)
     cfg = aa.net_config(LEVELS, 3, CLASSES, WIDTH, 1, prec)
@@ -95,6 +312,7 @@ def bench_infer(args, aa, aad, torch, dist, prec, rank, local_rank, world, use_d
     rng = np.random.default_rng(3)
     image = torch.from_numpy(rng.integers(0, 256, (side, side, 3), dtype=np.uint8)).to(dev)
     labels = torch.empty((side, side), dtype=torch.int16, device=dev)
+    host_labels = torch.empty((side, side), dtype=torch.int16).pin_memory()
     blended = torch.empty((CLASSES, side, side), dtype=torch.float32, device=dev)
     import ctypes as C
     ov = aa.lib().anh_required_input_dim(C.byref(cfg))
@@ -102,10 +320,16 @@ def bench_infer(args, aa, aad, torch, dist, prec, rank, local_rank, world, use_d
     tiles = aa.tiling.get_tiles(side, side, tp)
     mine = aad.shard_tiles(tiles, rank, world)
     exchange = aad.OverlapExchange(tiles, world, side, side, dev)   # the pixels where tiles of different ranks overlap (none at world 1)
+    ranks_seen, devices = dist_facts(torch, dist, dev, local_rank, world, use_dist)
 
-    def run():
+    def run(to_host=False):
         # blend this rank's tiles -> all-reduce the plane sums of the cross-rank overlaps -> label this rank's rows
-        aad.sharded_infer(net, image, labels, blended, tiles, rank, world, exchange, tiling_parameters=tp, stream=net_stream)
+        row0, row1 = aad.sharded_infer(net, image, labels, blended, tiles, rank, world, exchange, tiling_parameters=tp, stream=net_stream)
+        if to_host and row1 > row0:   # D2H on torch's own stream, ordered after the net's stream and before its next pass
+            cur = torch.cuda.current_stream()
+            cur.wait_stream(net_stream)
+            host_labels[row0:row1].copy_(labels[row0:row1], non_blocking=True)
+            net_stream.wait_stream(cur)
 
     def fence():
         torch.cuda.synchronize()
@@ -113,24 +337,58 @@ def bench_infer(args, aa, aad, torch, dist, prec, rank, local_rank, world, use_d
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(steps, **kw):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            run(**kw)
+        fence()
+        elapsed = time.perf_counter() - t0
+        if use_dist:
+            el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+            elapsed = float(el.item())
+        return elapsed
+
     for _ in range(max(args.warmup, 1)):
         run()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        elapsed = float(el.item())
+    # untimed profile pass: every kernel class of one image
+    net.synchronize()
+    net.profile_enable(True)
+    run()
+    net.synchronize()
+    prof_all = net.profile()
+    net.profile_reset()
+    layers, dims = layer_geometry(aa, cfg, 1024)
+    convs = [e for e in prof_all if ENTRY_RE.search(e["name"]) and layers[int(ENTRY_RE.search(e["name"]).group(2))].k > 1]
+    dominant = max(convs, key=lambda e: e["total_ms"])["name"] if convs else ""
+    net.profile_set_filter(dominant)
+    elapsed = timed(args.steps)
+    net.synchronize()
+    dom = [e for e in net.profile() if e["name"] == dominant]
+    net.profile_enable(False)
+    elapsed_host = timed(max(1, args.steps // 2), to_host=True)
     if rank == 0:
+        roof = None
+        if dom and dom[0]["launches"]:
+            e = dom[0]
+            avg_s = e["total_ms"] / 1e3 / e["launches"]
+            flops, byts = e["flops"] / e["launches"], e["bytes"] / e["launches"]   # per tile launch: 2 k^2 Cin Cout P and operand + result bytes
+            roof = bound_of(flops, byts, avg_s)
+            roof.pop("floor_us")
+            roof.update(traffic=None, kernel=dominant, avg_launch_us=avg_s * 1e6, launches=e["launches"], algorithmic_bytes_per_launch=byts, arithmetic_intensity=flops / byts)
+        total_ms = sum(e["total_ms"] for e in prof_all) or 1.0
+        share = sorted(((e["name"], round(100 * e["total_ms"] / total_ms, 1)) for e in prof_all), key=lambda x: -x[1])[:10]
         out = {"metric": f"Mpixels/s tiled inference, {side}x{side} image, 1024^2 tiles, overlap {ov}", "value": side * side * args.steps / elapsed / 1e6,
                "unit": "Mpx/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-               "config": {"workload": f"annonet_infer(): {len(tiles)} tiles ({len(mine)} on rank 0), levels={LEVELS} width={WIDTH} K={CLASSES}", "parallelism": f"tile-shard{world}", "exchanged_pixels": exchange.pixels()}}
+               "config": {"workload": f"annonet_infer(): {len(tiles)} tiles ({len(mine)} on rank 0), levels={LEVELS} width={WIDTH} K={CLASSES}", "parallelism": f"tile-shard{world}", "exchanged_pixels": exchange.pixels()},
+               "value_labels_on_host": side * side * max(1, args.steps // 2) / elapsed_host / 1e6,
+               "roofline": roof, "kernel_time_share_pct": share, "ranks_seen": ranks_seen, "devices": devices,
+               "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline_infer(aa, cfg, ov)}
         print(json.dumps(out), flush=True)
+    torch.cuda.synchronize()
+    del host_labels, exchange, net_stream   # torch-side objects that refer to the net's stream go before the net
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -139,13 +397,19 @@ def bench_infer(args, aa, aad, torch, dist, prec, rank, local_rank, world, use_d
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", default="train", choices=["train", "infer"], help="train = BASELINE.json's metric (default); infer = tiled inference over a 4096x4096 image")
     ap.add_argument("--image-side", type=int, default=4096)
+    ap.add_argument("--dump-launch-order", default=None, help="write the step's launch order (profiler entry per kernel-class launch) as JSON: input of tools/pmc_traffic.py")
     args = ap.parse_args()
+    if args.mode == "infer" and args.steps == 200:
+        args.steps, args.warmup = 20, 3
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)   # does not return
 
     import torch
     import annonet_amd as aa
@@ -155,7 +419,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     aa._lib.check(aa.lib().anh_set_device(local_rank))
     import torch.distributed as dist
@@ -168,6 +432,7 @@ def main():
     prec = aa.ANH_BF16 if args.precision == "bf16" else aa.ANH_FP32
     if args.mode == "infer":
         return bench_infer(args, aa, aad, torch, dist, prec, rank, local_rank, world, use_dist)
+    cfg = aa.net_config(LEVELS, 3, CLASSES, WIDTH, 1, prec)
     t = aa.TrainingNet(LEVELS, 3, prec, seed=2)
     t.SetNetWidth(WIDTH, 1)
     t.SetClassCount(CLASSES)
@@ -181,6 +446,7 @@ def main():
     d_img = torch.from_numpy(img).to(dev)
     d_lab = torch.from_numpy(lab.view(np.int16)).to(dev)
     d_w = torch.from_numpy(w).to(dev)
+    ranks_seen, devices = dist_facts(torch, dist, dev, local_rank, world, use_dist)
 
     def step():
         aad.data_parallel_step(t, bucket, d_img.data_ptr(), d_lab.data_ptr(), d_w.data_ptr(), BATCH, TILE, TILE, world, force_collective=use_dist, stream=t_stream)
@@ -191,20 +457,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # untimed: warm-up, then a short all-kernel profile to find the dominant kernel class
+    # untimed: warm-up, then an all-kernel profile pass (per-layer table, and which §8d conv entry is the dominant one)
     for _ in range(max(args.warmup, 1)):
         step()
     t.synchronize()
     t.profile_enable(True)
-    for _ in range(2):
+    for _ in range(PROFILE_STEPS):
         step()
     t.synchronize()
     prof_all = t.profile()
+    if args.dump_launch_order and rank == 0:
+        with open(args.dump_launch_order, "w") as f:
+            json.dump({"order": t.profile_launch_order()}, f, indent=0)
     t.profile_reset()
-    dominant = max(prof_all, key=lambda e: e["total_ms"])["name"] if prof_all else ""
+    layers, dims = layer_geometry(aa, cfg, TILE)
+    layer_rows, overhead = split_entries(prof_all, layers, dims, BATCH, PROFILE_STEPS)
+    dominant = max(layer_rows, key=lambda r: r["time_us"])["entry"] if layer_rows else ""
     t.profile_set_filter(dominant)
-    # An event pair costs ~6 us of stream time per launch, so the timed region times the dominant kernel on a sample of
-    # its steps (every 4th), not on all of them: the average launch duration is estimated from >= steps/4 * launches.
+    # An event pair costs ~6 us of stream time per launch, so the timed region times the dominant entry on a sample of
+    # its steps (every 4th), not on all of them: the average launch duration is estimated from >= steps/4 launches.
     sample_every = 4 if args.steps >= 8 else 1
     t.profile_set_sampling(sample_every)
 
@@ -227,39 +498,37 @@ def main():
         roof = None
         if dom and dom[0]["launches"]:
             e = dom[0]
+            row = [r for r in layer_rows if r["entry"] == dominant][0]
             avg_s = e["total_ms"] / 1e3 / e["launches"]
-            flops, byts = e["flops"] / e["launches"], e["bytes"] / e["launches"]
-            ai = flops / byts if byts else 0.0
-            if flops > 0 and ai >= RIDGE:  # above the ridge point (peak flops / peak bytes): the matrix cores bound it
-                roof = {"bound": "mfma", "achieved": flops / avg_s / 1e12, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s"}
-            else:                          # below it: HBM traffic bounds it
-                roof = {"bound": "hbm", "achieved": byts / avg_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s"}
-            roof["frac"] = roof["achieved"] / roof["peak"]
-            roof["traffic"] = pmc_traffic(dominant)
-            roof["algorithmic_bytes_per_launch"] = byts
-            roof["kernel"] = dominant
-            roof["avg_launch_us"] = avg_s * 1e6
-            roof["launches"] = e["launches"]
-            roof["sampled_every_n_steps"] = sample_every
-            roof["arithmetic_intensity"] = ai
-        total_ms = sum(e["total_ms"] for e in prof_all) or 1.0
-        breakdown = sorted(((e["name"], round(100 * e["total_ms"] / total_ms, 1)) for e in prof_all), key=lambda x: -x[1])[:8]
-        if os.environ.get("ANH_BENCH_VERBOSE"):
-            for e in sorted(prof_all, key=lambda e: -e["total_ms"]):
-                per = e["total_ms"] / 2.0
-                print(f"  {e['name']:44s} {per:8.3f} ms/step  {e['launches'] // 2:3d} launches  "
-                      f"{e['flops'] / 2 / per / 1e9 if per else 0:9.1f} TFLOP/s  {e['bytes'] / 2 / per / 1e6 if per else 0:9.1f} GB/s", file=sys.stderr)
+            flops, min_bytes = row["gflop"] * 1e9, row["min_mb"] * 1e6
+            roof = bound_of(flops, min_bytes, avg_s)
+            roof.pop("floor_us")
+            roof.update(traffic=pmc_traffic(dominant), kernel=dominant, layer=row["layer"], **{"pass": row["pass"]},
+                        avg_launch_us=avg_s * 1e6, launches=e["launches"], sampled_every_n_steps=sample_every,
+                        algorithmic_flops_per_launch=flops, algorithmic_bytes_per_launch=min_bytes, arithmetic_intensity=flops / min_bytes)
+        step_gflop = 3 * sum(section8d(layers, dims, li, BATCH)[0] for li in range(len(layers))) / 1e9
+        ms = 1e3 * elapsed / args.steps
         out = {
             "metric": "227x227 RGB tiles/sec fwd+bwd @ batch 32", "value": BATCH * world * args.steps / elapsed, "unit": "tiles/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": f"training step (fwd+loss+bwd+SGD), batch {BATCH}x3x{TILE}x{TILE} per GPU, encoder-decoder levels={LEVELS} width={WIDTH} K={CLASSES}, random init",
                        "global_batch": BATCH * world, "parallelism": f"dp{world}"},
             "roofline": roof,
-            "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline(),   # rank 0 at N=1 only
-            "kernel_time_share_pct": breakdown,
+            "step_roofline": {"gflop_per_step": round(step_gflop, 1), "achieved_tflops": round(step_gflop / ms, 1), "frac_of_bf16_mfma_peak": round(step_gflop / ms / PEAK_BF16_TFLOPS, 4),
+                              "sum_of_layer_floors_us": round(sum(r["floor_us"] for r in layer_rows), 1)},
+            "layers": layer_rows,
+            "layers_measured": f"HIP events on the launching stream, untimed profile pass of {PROFILE_STEPS} steps right before the timed region",
+            "overhead_kernels": overhead,
+            "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline_train(aa, cfg),   # rank 0 at N=1 only
+            "ranks_seen": ranks_seen, "devices": devices,
             "final_loss": loss,
         }
+        if os.environ.get("ANH_BENCH_VERBOSE"):
+            for e in sorted(prof_all, key=lambda e: -e["total_ms"]):
+                per = e["total_ms"] / PROFILE_STEPS
+                print(f"  {e['name']:52s} {per:8.3f} ms/step  {e['launches'] // PROFILE_STEPS:3d} launches  "
+                      f"{e['flops'] / PROFILE_STEPS / per / 1e9 if per else 0:9.1f} TFLOP/s  {e['bytes'] / PROFILE_STEPS / per / 1e6 if per else 0:9.1f} GB/s", file=sys.stderr)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()

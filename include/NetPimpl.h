@@ -89,6 +89,11 @@ inline void check(int status) {  // the reference's error convention: std::excep
     if (status != ANH_OK) throw std::runtime_error(std::string("annonet_hip: ") + anh_last_error());
 }
 
+// Extension (the reference has only --primary-cuda-device, annonet_train_main.cpp:307,392-394): the GPUs that nets created
+// afterwards on this thread drive.  TrainingNet::StartTraining then splits every mini-batch over them (one RCCL all-reduce of
+// the gradients per step), annonet_infer() splits the tile list; the host code is unchanged.  {} = one device again.
+inline void SetDevices(const std::vector<int>& devices) { check(anh_set_devices(devices.data(), (int)devices.size())); }
+
 // read-only view standing in for `const dlib::tensor&` (annonet_infer.cpp:77-100)
 class OutputTensor {
   public:

@@ -80,6 +80,19 @@ void anh_free(void* p); /* releases buffers this library returned (serialize, ge
 /* dlib::cuda::set_device (annonet_train_main.cpp:392-394): device used by handles created afterwards on this thread */
 int anh_set_device(int device);
 int anh_device_count(void); /* number of visible GPUs; 0 when none (never fails) */
+/* One process, several GPUs (the reference has only --primary-cuda-device, annonet_train_main.cpp:307,392-394):
+ * handles created afterwards ON THIS THREAD hold one replica per listed device.
+ *   TrainingNet::StartTraining (anh_trainer_step) splits the mini-batch along N over the replicas (annonet_train_main.cpp:583-614
+ *     stays unchanged), sums the flat gradient buckets with ONE all-reduce (RCCL over xGMI) and applies the identical update;
+ *     the loss scale uses the whole batch, batch-norm statistics are per replica;
+ *   annonet_infer (anh_infer) splits the tile list into contiguous chunks, exchanges the plane sums where tiles of different
+ *     replicas overlap (one RCCL all-reduce) and returns ONE host label map.
+ * n = 0 returns to "the thread's current device".  A list that repeats a device is a rehearsal on fewer GPUs (tests): the
+ * exchange then runs as a fixed-order sum on the first replica's stream instead of RCCL. */
+int anh_set_devices(const int* devices, int n);
+int anh_handle_replicas(void* handle, int is_trainer); /* number of replicas (devices) a handle drives */
+/* the host logic of the two splits, exported for tests: replica `rank` of `world` takes units [*lo, *hi) of n */
+int anh_shard_range(int64_t n, int world, int rank, int64_t* lo, int64_t* hi);
 
 /* ---- static dimension maths ---- */
 /* TrainingNet::GetRequiredInputDimension() (annonet_train_main.cpp:376,441; annonet_infer_main.cpp:421): receptive-field side */
@@ -163,6 +176,7 @@ int anh_trainer_grad_buffer(anh_trainer* h, void** d_ptr, int64_t* count); /* fl
 int anh_trainer_get_params(anh_trainer* h, float* params, int64_t n_params, float* running, int64_t n_running);
 int anh_trainer_set_params(anh_trainer* h, const float* params, int64_t n_params, const float* running, int64_t n_running);
 int anh_trainer_get_grads(anh_trainer* h, float* grads_canonical, int64_t n_params);
+int anh_trainer_replica_params(anh_trainer* h, int replica, float* params, int64_t n_params); /* anh_set_devices: every replica must hold the same weights */
 int anh_trainer_get_momentum(anh_trainer* h, float* momentum, int64_t n_params);
 int anh_trainer_set_momentum(anh_trainer* h, const float* momentum, int64_t n_params);
 /* GetRuntimeNet() (annonet_train_main.cpp:558): independent by-value snapshot; quiesces the device first */
@@ -183,6 +197,9 @@ int anh_profile_reset(void* handle, int is_trainer);
 int anh_profile_count(void* handle, int is_trainer);
 int anh_profile_entry(void* handle, int is_trainer, int index, char* name, size_t name_cap,
                       double* total_ms, int64_t* launches, double* flops, double* bytes);
+/* entry names of the most recent pass (forward [+ backward + update]) in host enqueue order, one per kernel-class launch,
+ * newline-separated; *needed = bytes incl. the terminator.  tools/pmc_traffic.py maps rocprofv3 dispatches onto entries with it. */
+int anh_profile_launch_order(void* handle, int is_trainer, char* buf, size_t cap, size_t* needed);
 
 /* ---- single-layer ops on host tensors (kernel-level parity tests and micro-benchmarks) ----
  * The same kernels the net runs, on caller-provided data.  Tensors are fp32 NHWC on the host; in ANH_BF16 they are
@@ -216,6 +233,9 @@ int anh_op_conv_backward_filter_bn(int precision, const anh_conv_desc* d, int n,
 /* ---- host logic ---- */
 /* tiling::get_tiles(width, height, params) (annonet_infer.cpp:42): *tiles is malloc'd, release with anh_free */
 int anh_get_tiles(int width, int height, const anh_tiling_params* params, anh_tile** tiles, size_t* count);
+/* the rectangles (inclusive, clipped to the image) in which tiles owned by different replicas overlap when the tile list is split
+   into `world` contiguous chunks: the pixels whose plane sums the replicas exchange.  *rects is malloc'd, release with anh_free */
+int anh_cross_replica_overlaps(const anh_tile* tiles, size_t n_tiles, int world, int width, int height, anh_rect** rects, size_t* count);
 /* set_weights() (annonet_train.h:20-83) */
 int anh_set_weights(const uint16_t* labels, int nr, int nc, double class_weight, double image_weight, anh_wlabel* out);
 /* random_rect_containing_point() (annonet_train.h:85-105); the two 32-bit draws of dlib::rand are passed in */

@@ -509,8 +509,8 @@ void train_step(Net& net, const uint8_t* images, const uint16_t* labels, const f
         }
     }
     if (!apply_update) return;
-    // running statistics, dlib bn_ [UPSTREAM-UNVERIFIED]: averaging factor 1/(updates+1) until the
-    // window is reached; variance stored unbiased (N/(N-1)).
+    // running statistics, dlib bn_ [UPSTREAM-UNVERIFIED]: averaging factor 1/(updates+1); the update count is incremented
+    // after use and capped AT the window (steady-state factor 1/(window+1)); variance stored unbiased (N/(N-1)).
     int bn_idx = 0;
     for (int li = 0; li < nl; ++li) {
         const Layer& L = s.layers[li];
@@ -519,7 +519,7 @@ void train_step(Net& net, const uint8_t* images, const uint16_t* labels, const f
         const double P = (double)net.raw[li].pixels();
         double& cnt = net.running_count[bn_idx++];
         const double af = 1.0 / (cnt + 1.0);
-        if (cnt + 1.0 < (double)net.bn_window) cnt += 1.0;
+        if (cnt < (double)net.bn_window) cnt += 1.0;
         float* rm = net.running.data() + L.rs_off;
         float* rv = rm + L.cout;
         const double unb = P > 1 ? P / (P - 1.0) : 1.0;

@@ -98,6 +98,32 @@ int main() {
     bool threw = false;
     try { NetPimpl::input_type bad; bad.set_size(24, 24); net.Forward(bad); } catch (const std::exception&) { threw = true; }
     REQUIRE(threw);
-    std::printf("shim smoke ok (trained 3 steps, serialized %zu bytes, inferred 150x170)\n", serialized.str().size());
+    {   // two replicas from this one process (two GPUs when the box has them, else device 0 twice = the rehearsal backend):
+        // the training loop and annonet_infer() above, unchanged
+        NetPimpl::SetDevices({0, anh_device_count() > 1 ? 1 : 0});
+        NetPimpl::TrainingNet dp_net;
+        dp_net.Initialize();
+        dp_net.SetNetWidth(0.25, 4);
+        dp_net.SetClassCount(3);
+        dp_net.SetLearningRate(0.1);
+        REQUIRE(anh_handle_replicas(dp_net.handle(), 1) == 2);
+        for (int step = 0; step < 3; ++step) dp_net.StartTraining(samples, labels);
+        const NetPimpl::RuntimeNet dp_runtime = dp_net.GetRuntimeNet(ANH_FP32);
+        REQUIRE(anh_handle_replicas(dp_runtime.handle(), 0) == 2);
+        dlib::matrix<uint16_t> dp_result;
+        annonet_infer(const_cast<NetPimpl::RuntimeNet&>(dp_runtime), image, dp_result, temp, {}, {}, small);   // tiles sharded over the replicas
+        NetPimpl::SetDevices({});
+        std::ostringstream blob;
+        dp_runtime.Serialize(blob);
+        NetPimpl::RuntimeNet one_device;
+        { std::istringstream iss(blob.str()); one_device.Deserialize(iss, ANH_FP32); }
+        REQUIRE(anh_handle_replicas(one_device.handle(), 0) == 1);
+        dlib::matrix<uint16_t> one_result;
+        annonet_infer(one_device, image, one_result, temp, {}, {}, small);
+        long differing = 0;
+        for (long r = 0; r < 150; ++r) for (long c = 0; c < 170; ++c) differing += dp_result(r, c) != one_result(r, c);
+        REQUIRE(differing <= 3);   // equal except exact near-ties where four tiles meet (summation order)
+    }
+    std::printf("shim smoke ok (trained 3 steps, serialized %zu bytes, inferred 150x170; 2 replicas: 3 data-parallel steps + sharded inference)\n", serialized.str().size());
     return 0;
 }

@@ -32,11 +32,42 @@ def test_training_bench_line():
     assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and r["peak"] > 0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.05 < r["frac"] < 1.0
     assert r["traffic"] is None or r["traffic"] > 0.5 * r["algorithmic_bytes_per_launch"]
+    assert r["kernel"].split(":")[1].split("_")[0] in ("fwd", "dgrad", "wgrad")   # a §8d conv pass, not a bn / reduction kernel
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "tiles/s" and 1 <= c["cores"] <= 16 and 0 < c["value"] < d["value"] and c["sample"]
+    assert c["one_thread"]["cores"] == 1 and 0 < c["one_thread"]["value"] <= c["value"] * 1.5
+    assert "pytorch_cpu" in c and ("value" in c["pytorch_cpu"] or "error" in c["pytorch_cpu"])
+    # per-layer table: every 3x3 / 5x5 layer x {fwd, bwd-data, bwd-filter} (the stem has no bwd-data), each with its §8d bound
+    rows = d["layers"]
+    assert len(rows) == 9 * 3 - 1
+    assert {x["pass"] for x in rows} == {"fwd", "bwd-data", "bwd-filter"}
+    for x in rows:
+        assert x["bound"] in ("hbm", "mfma") and 0 < x["frac"] < 1.0 and x["time_us"] >= x["floor_us"] > 0
+    assert abs(sum(x["gflop"] for x in rows) - (564.6 - 3 * 0.32 - 7.91)) < 1.5      # 564.6 GFLOP per step incl. the 1x1 head (3 passes) and the stem's absent bwd-data
+    assert any(o["entry"].startswith("bn_") for o in d["overhead_kernels"])
+    assert d["ranks_seen"] == 1 and d["devices"] == [0]
+
+
+def test_self_launch_refuses_more_gpus_than_visible():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "1", "--warmup", "1"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 2 and "GPU(s) visible" in r.stderr
+
+
+def test_launched_as_a_rank_takes_the_rccl_path():
+    """python -m torch.distributed.run --nproc-per-node 1 (what the self-launcher starts, at N = 1): one rank, RCCL all-reduce on the bucket"""
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1", "--master-port", "29533",
+                        os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["ranks_seen"] == 1 and d["n_gpus"] == 1 and d["value"] > 5000
 
 
 def test_inference_bench_line():
     d = run_bench("--mode", "infer", "--image-side", "2048", "--steps", "3", "--warmup", "1")
     assert d["unit"] == "Mpx/s" and d["n_gpus"] == 1 and d["scaling"] == "strong" and d["vs_baseline"] is None
     assert d["config"]["exchanged_pixels"] == 0 and d["value"] > 100
+    assert 0 < d["value_labels_on_host"] <= d["value"] * 1.05
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and 0.01 < r["frac"] < 1.0 and "fwd_L" in r["kernel"]
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "Mpx/s" and 0 < c["value"] < d["value"] and c["one_thread"]["cores"] == 1

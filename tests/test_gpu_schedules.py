@@ -38,6 +38,8 @@ def default_run(tmp_path_factory):
 @pytest.mark.parametrize("name,env", [
     ("one_stream", {"ANH_CONCURRENT_WGRAD": "0"}),
     ("bn_backward_in_conv_prologue", {"ANH_FUSE_BN_BWD_APPLY": "1"}),
+    ("backward_data_conv_writes_dy", {"ANH_FUSE_BN_BWD_APPLY": "2"}),
+    ("backward_data_conv_writes_dy_one_stream", {"ANH_FUSE_BN_BWD_APPLY": "2", "ANH_CONCURRENT_WGRAD": "0"}),
     ("stem_filter_gradient_on_second_stream", {"ANH_STEM_WGRAD_MAIN": "0"}),
     ("conv_filters_streamed_with_every_patch", {"ANH_WS_WEIGHT_RESIDENT": "0"}),
 ])

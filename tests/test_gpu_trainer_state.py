@@ -1,0 +1,103 @@
+"""Trainer state: the 10-minute synchronization file (annonet_train_main.cpp:403), resume, and the learning-rate schedule.
+
+  * SetSynchronizationFile is called BEFORE SetClassCount in the reference (annonet_train_main.cpp:400-405): the resume must
+    wait until the net structure is final, for any class count;
+  * save -> new trainer -> load -> continue equals an uninterrupted run bit for bit (parameters, momentum, running statistics
+    incl. the bn update counters, learning rate, the losses still ahead of the schedule's lag);
+  * the step at which a loss enters the schedule is fixed (lag of anh_trainer::kLossLag steps), so the learning-rate history
+    does not depend on how often the host synchronises or polls."""
+import numpy as np
+import pytest
+
+import annonet_amd as aa
+
+pytestmark = pytest.mark.gpu
+
+D = 35   # valid for 2 levels
+
+
+def batch(seed, n=3, classes=4):
+    rng = np.random.default_rng(seed)
+    img = rng.integers(0, 256, (n, D, D, 3), dtype=np.uint8)
+    lab = rng.integers(0, classes, (n, D, D)).astype(np.uint16)
+    lab[rng.random((n, D, D)) < 0.1] = aa.LABEL_IGNORE
+    return list(img), [aa.set_weights(l, 0.5, 0.5) for l in lab]
+
+
+def make_trainer(classes=4, sync=None, precision=aa.ANH_FP32, seed=5, lr=0.05):
+    """the reference's call order: Initialize, SetNetWidth, SetSynchronizationFile, BeVerbose, SetClassCount, rates (annonet_train_main.cpp:400-410)"""
+    t = aa.TrainingNet(2, 3, precision, seed=seed)
+    t.Initialize()
+    t.SetNetWidth(0.25, 4)
+    if sync:
+        t.SetSynchronizationFile(sync, 600)
+    t.SetClassCount(classes)
+    t.SetLearningRate(lr)
+    t.SetLearningRateShrinkFactor(0.5)
+    t.SetIterationsWithoutProgressThreshold(6)
+    t.SetPreviousLossValuesDumpAmount(2)
+    t.SetAllBatchNormalizationRunningStatsWindowSizes(3)   # small window: the bn update counters saturate inside the test
+    return t
+
+
+def state_of(t):
+    p, r = t.get_params()
+    return p, r, t.get_momentum(), t.GetLearningRate(), t.step_count()
+
+
+def test_sync_file_resume_with_the_reference_call_order(tmp_path):
+    path = str(tmp_path / "annonet_trainer_state_file.dat")
+    a = make_trainer(classes=4)
+    for i in range(5):
+        a.StartTraining(*batch(i))
+    a.save_state(path)
+    want = state_of(a)
+    b = make_trainer(classes=4, sync=path)     # names the file while the class count is still the default 3
+    got = state_of(b)                          # first use of the net: resumes
+    for w, g in zip(want, got):
+        np.testing.assert_array_equal(g, w)
+    c = make_trainer(classes=3, sync=path)     # a different net: the file must be refused, not half-loaded
+    with pytest.raises(aa.AnnonetHipError, match="different net"):
+        c.get_params()
+
+
+@pytest.mark.parametrize("precision", [aa.ANH_FP32, aa.ANH_BF16])
+def test_save_load_continue_equals_uninterrupted_run(tmp_path, precision):
+    path = str(tmp_path / "state.dat")
+    ref = make_trainer(precision=precision)
+    lr_ref = []
+    for i in range(14):
+        ref.StartTraining(*batch(i))
+        lr_ref.append(ref.GetLearningRate())
+    a = make_trainer(precision=precision)
+    for i in range(7):
+        a.StartTraining(*batch(i))
+    a.save_state(path)
+    b = make_trainer(precision=precision, seed=99)   # different init: everything must come from the file
+    b.load_state(path)
+    lr_b = lr_ref[:7]
+    for i in range(7, 14):
+        b.StartTraining(*batch(i))
+        lr_b.append(b.GetLearningRate())
+    assert lr_b == lr_ref
+    for w, g in zip(state_of(ref), state_of(b)):
+        np.testing.assert_array_equal(g, w)
+    assert abs(ref.get_last_loss() - b.get_last_loss()) == 0
+
+
+def test_learning_rate_history_does_not_depend_on_host_timing():
+    runs = []
+    for polling in (False, True):
+        t = make_trainer(lr=1e-7)             # a rate too small to move the loss: the history is a plateau from the first step
+        lrs = []
+        for i in range(30):
+            t.StartTraining(*batch(i % 4))    # a repeating batch sequence: the loss plateaus and the rate shrinks
+            if polling:
+                t.synchronize()
+                t.get_last_loss()
+            lrs.append(t.GetLearningRate())
+        runs.append((lrs, state_of(t)))
+    assert runs[0][0] == runs[1][0]
+    assert runs[0][0][-1] < 1e-7, "the schedule never shrank the rate: the test does not exercise the lag"
+    for w, g in zip(runs[0][1], runs[1][1]):
+        np.testing.assert_array_equal(g, w)
