@@ -51,7 +51,8 @@ class Tile(C.Structure):
 
 class CropSpec(C.Structure):   # anh_crop_spec
     _fields_ = [("image", C.c_int), ("left", C.c_long), ("top", C.c_long), ("flip_left_right", C.c_int), ("flip_upside_down", C.c_int),
-                ("brightness_change", C.c_double)]
+                ("brightness_change", C.c_double), ("further_downscaling_factor", C.c_double), ("noise_level", C.c_int), ("noise_seed", C.c_uint64),
+                ("color_offset", C.c_int * 3)]
 
 
 class ConvDesc(C.Structure):

@@ -250,8 +250,13 @@ struct anh_dataset {
             ANH_REQUIRE(c.left > -(1L << 30) && c.left < (1L << 30) && c.top > -(1L << 30) && c.top < (1L << 30), "crop batch: rectangle out of range");
             ANH_REQUIRE(c.brightness_change >= 0, "crop batch: negative brightness change");
             const Item& it = items[(size_t)c.image];
+            ANH_REQUIRE(c.further_downscaling_factor == 0.0 || (c.further_downscaling_factor >= 1.0 && c.further_downscaling_factor <= 64.0), "crop batch: further downscaling factor must be >= 1");
+            ANH_REQUIRE(c.noise_level >= 0 && c.noise_level <= 255, "crop batch: noise level must be 0..255");
+            const double f = c.further_downscaling_factor == 0.0 ? 1.0 : c.further_downscaling_factor;
+            const int src_dim = (int)std::round(dim * f);   // dim_before_downscaling (annonet_train_main.cpp:127)
             hs[i] = CropSource{it.image.as<uint8_t>(), it.labels.as<uint16_t>(), it.height, it.width, (int)c.left, (int)c.top,
-                               c.flip_left_right ? 1 : 0, c.flip_upside_down ? 1 : 0, c.brightness_change};
+                               c.flip_left_right ? 1 : 0, c.flip_upside_down ? 1 : 0, c.brightness_change, src_dim, c.noise_level,
+                               (unsigned long long)c.noise_seed, {c.color_offset[0], c.color_offset[1], c.color_offset[2]}};
         }
         HIP_CHECK(hipMemcpyAsync(d_specs.p, hs, spec_bytes, hipMemcpyHostToDevice, stream));
         HIP_CHECK(hipMemsetAsync(d_bad.p, 0, 4, stream));

@@ -196,7 +196,23 @@ struct CropSource {
     int left, top;                                  // crop rectangle = [left, left+dim) x [top, top+dim), may leave the image
     int flip_lr, flip_ud;
     double gain;                                    // multiplicative brightness change (the reference's double); 1 = none
+    // further downscaling (annonet_train_main.cpp:124-127,160-171): the rectangle is src_dim x src_dim (= round(dim * factor)) and
+    // is resized to dim x dim — bilinear for the image, nearest neighbour for the labels; src_dim == dim: none
+    int src_dim;
+    // add_random_noise (:73-105): per channel value + uniform integer in [-noise_level, noise_level], clamped to 0..255; the draws
+    // come from a counter-based generator keyed by (noise_seed, position in the final crop) instead of dlib::rand's sequence
+    int noise_level;
+    unsigned long long noise_seed;
+    int color_offset[3];                            // apply_random_color_offset (:226-231): per-channel offsets drawn by the host, clamped add
 };
+// the counter-based draw of the device's add_random_noise (splitmix64 finaliser): uniform in [-level, level]
+__host__ __device__ inline int crop_noise_draw(unsigned long long seed, unsigned long long counter, int level) {
+    unsigned long long z = seed + (counter + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (int)(z % (unsigned long long)(2 * level + 1)) - level;
+}
 // pass 1: pixels (clamp-to-edge = extract_image_chip at scale 1 + outpaint), labels (ignore outside the image), flips and
 // brightness; per crop a histogram of the UNFLIPPED labels and the first row-major position of every label value
 void launch_crop_pixels(const CropSource* d_specs, int n, int dim, int channels, uint8_t* d_images, uint16_t* d_labels,

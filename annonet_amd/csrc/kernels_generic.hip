@@ -1561,13 +1561,32 @@ __global__ __launch_bounds__(256) void crop_pixels_kernel(const CropSource* spec
     uint8_t* oi = out_img + (size_t)crop * plane * channels;
     uint16_t* ol = out_lab + (size_t)crop * plane;
     const double gain = sp.gain;
+    const bool resize = sp.src_dim != dim;
+    // dlib::resize_image's corner-aligned grid [UPSTREAM-UNVERIFIED, restated in annonet_host.h and the oracle]: output (r, c) samples
+    // the src_dim x src_dim chip at (r, c) * (src_dim - 1) / max(dim - 1, 1)
+    const double scale = (double)(sp.src_dim - 1) / (double)max(dim - 1, 1);
+    auto chip_label = [&](int yy, int xx) -> uint16_t {   // the chip's label image: "ignore" outside the full image (:150-158)
+        const int sy = sp.top + yy, sx = sp.left + xx;
+        const bool inside = sy >= 0 && sy < sp.height && sx >= 0 && sx < sp.width;
+        return inside ? sp.labels[(size_t)sy * sp.width + sx] : (uint16_t)ANH_LABEL_IGNORE;
+    };
+    auto chip_pixel = [&](int yy, int xx, int ch) -> uint8_t {   // the chip after outpaint: clamp to the nearest image pixel
+        const int cy = min(max(sp.top + yy, 0), sp.height - 1), cx = min(max(sp.left + xx, 0), sp.width - 1);
+        return sp.image[((size_t)cy * sp.width + cx) * channels + ch];
+    };
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < plane; p += gridDim.x * blockDim.x) {
         const int r = p / dim, c = p - r * dim;
-        const int sy = sp.top + r, sx = sp.left + c;
-        const int cy = min(max(sy, 0), sp.height - 1), cx = min(max(sx, 0), sp.width - 1);
-        const bool inside = sy == cy && sx == cx;
-        const size_t src = (size_t)cy * sp.width + cx;
-        const uint16_t label = inside ? sp.labels[src] : (uint16_t)ANH_LABEL_IGNORE;
+        uint16_t label;
+        int y0 = r, x0 = c, y1 = r, x1 = c;
+        float fy = 0.f, fx = 0.f;
+        if (!resize) label = chip_label(r, c);
+        else {
+            const double y = r * scale, x = c * scale;
+            label = chip_label((int)floor(y + 0.5), (int)floor(x + 0.5));   // interpolate_nearest_neighbor
+            y0 = (int)floor(y); x0 = (int)floor(x);
+            y1 = min(y0 + 1, sp.src_dim - 1); x1 = min(x0 + 1, sp.src_dim - 1);
+            fy = (float)(y - y0); fx = (float)(x - x0);
+        }
         if (label != ANH_LABEL_IGNORE) {
             if (label < classes) { atomicAdd(&sh_hist[label], 1u); atomicMin(&sh_first[label], (unsigned)p); }
             else *bad_label = 1;
@@ -1576,9 +1595,18 @@ __global__ __launch_bounds__(256) void crop_pixels_kernel(const CropSource* spec
         const size_t dst = (size_t)fr * dim + fc;
         ol[dst] = label;
         for (int ch = 0; ch < channels; ++ch) {
-            const uint8_t v = sp.image[src * channels + ch];
+            int v;
+            if (!resize) v = chip_pixel(r, c, ch);
+            else {   // interpolate_bilinear in float, rounded half up
+                const float tl = chip_pixel(y0, x0, ch), tr = chip_pixel(y0, x1, ch), bl = chip_pixel(y1, x0, ch), br = chip_pixel(y1, x1, ch);
+                const float top = (1.f - fx) * tl + fx * tr, bot = (1.f - fx) * bl + fx * br;
+                v = (int)((1.f - fy) * top + fy * bot + 0.5f);
+            }
             // tuc::round<unsigned char>(tuc::clamp(value * change, 0.0, 255.0)) (annonet_train_main.cpp:203-205), in double
-            oi[dst * channels + ch] = gain == 1.0 ? v : (uint8_t)floor(fmin(fmax((double)v * gain, 0.0), 255.0) + 0.5);
+            if (gain != 1.0) v = (int)floor(fmin(fmax((double)v * gain, 0.0), 255.0) + 0.5);
+            if (sp.noise_level > 0) v = min(max(v + crop_noise_draw(sp.noise_seed, (unsigned long long)(dst * channels + ch), sp.noise_level), 0), 255);
+            if (channels == 3 && sp.color_offset[ch] != 0) v = min(max(v + sp.color_offset[ch], 0), 255);
+            oi[dst * channels + ch] = (uint8_t)v;
         }
     }
     __syncthreads();

@@ -249,9 +249,19 @@ int anh_outpaint(uint8_t* image, int nr, int nc, int channels, const anh_rect* i
    "ignore" outside the image (:150-158), set_weights (:178), flips (:183-194) and the multiplicative brightness change
    (:196-216), for further_downscaling_factor = 1.  The random draws stay with the caller (dlib::rand is the host's): a
    crop is described by its rectangle (random_rect_containing_point), the two flip decisions and the brightness factor.
-   Not covered: further downscaling, add_random_noise, apply_random_color_offset (dlib routines, absent from the snapshot). */
+   Further downscaling, add_random_noise and apply_random_color_offset are covered with the host's draws passed in (see anh_crop_spec);
+   dlib's own routines are absent from the snapshot, so their arithmetic is restated [UPSTREAM-UNVERIFIED]. */
 typedef struct anh_dataset anh_dataset;
-typedef struct { int image; long left, top; int flip_left_right, flip_upside_down; double brightness_change; /* 1 = none */ } anh_crop_spec;
+typedef struct {
+    int image; long left, top; int flip_left_right, flip_upside_down;
+    double brightness_change;          /* multiplicative (:196-216); 1 = none */
+    double further_downscaling_factor; /* :124-127,160-171: the rectangle is round(dim * factor) wide and is resized to dim (bilinear image,
+                                          nearest-neighbour labels, dlib::resize_image's corner-aligned grid); 0 or 1 = none */
+    int noise_level;                   /* add_random_noise (:73-105): uniform integer in [-level, level] per channel value; 0 = none.  The draws
+                                          come from a counter-based generator keyed by (noise_seed, position), not from dlib::rand's sequence */
+    uint64_t noise_seed;
+    int color_offset[3];               /* apply_random_color_offset (:226-231): per-channel offsets drawn by the host (RGB nets); 0 = none */
+} anh_crop_spec;
 int anh_dataset_create(int channels, anh_dataset** out);
 void anh_dataset_destroy(anh_dataset* d);
 /* uploads one full image (u8, HWC, `channels` interleaved) and its label image (u16) and keeps them resident; *index = its number */
