@@ -1192,7 +1192,12 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float* blended, int k
 // components, the seed property is flooded through them: 32x32 tiles (+1 halo) iterate in LDS until nothing changes inside
 // the tile; the launch is repeated until no tile changed.  Flags only ever go 0 -> 1, so the in-place sweeps are race-benign.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void det_seed_kernel(const float* blended, const uint16_t* labels, int k, int64_t pixels, const double* det, uint8_t* flags) {
+// transposed = 0: the seed at (r, c) marks the blob that holds (r, c) — the intended behaviour.
+// transposed = 1 (ANH_DET_SEED_REFERENCE_ORDER=1): the reference stores the seed as point(r, c) (annonet_infer.cpp:210) and looks the
+//   blob up at (point.y(), point.x()) = (c, r) (:222): the seed marks the blob that holds the TRANSPOSED pixel.  Out-of-range transposed
+//   positions (non-square images: undefined behaviour in the reference) are dropped.  flags must be zero on entry.
+__global__ __launch_bounds__(256) void det_seed_kernel(const float* blended, const uint16_t* labels, int k, int64_t pixels, const double* det, uint8_t* flags,
+                                                       int transposed, int h, int w) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < pixels; p += stride) {
         const uint16_t lab = labels[p];
@@ -1201,7 +1206,11 @@ __global__ __launch_bounds__(256) void det_seed_kernel(const float* blended, con
             const float clean = blended[p], mine = blended[(size_t)lab * pixels + p];
             if ((double)(mine - clean) > det[lab] - det[0]) f = 1;
         }
-        flags[p] = f;
+        if (!transposed) flags[p] = f;
+        else if (f) {
+            const int64_t r = p / w, c = p - r * w;
+            if (c < h && r < w) flags[c * w + r] = 1;
+        }
     }
 }
 
@@ -1260,7 +1269,9 @@ void run_detection_filter(const float* d_blended, uint16_t* d_labels, int k, int
     const int64_t pixels = (int64_t)h * w;
     if (pixels == 0) return;
     const int blocks = (int)std::min<int64_t>((pixels + 255) / 256, 256 * 16);
-    hipLaunchKernelGGL(det_seed_kernel, dim3(blocks), dim3(256), 0, s, d_blended, d_labels, k, pixels, d_det, d_flags);
+    static const int reference_order = getenv("ANH_DET_SEED_REFERENCE_ORDER") ? atoi(getenv("ANH_DET_SEED_REFERENCE_ORDER")) : 0;
+    if (reference_order) HIP_CHECK(hipMemsetAsync(d_flags, 0, (size_t)pixels, s));
+    hipLaunchKernelGGL(det_seed_kernel, dim3(blocks), dim3(256), 0, s, d_blended, d_labels, k, pixels, d_det, d_flags, reference_order, h, w);
     HIP_CHECK(hipGetLastError());
     const dim3 grid((unsigned)((w + 31) / 32), (unsigned)((h + 31) / 32));
     for (int round = 0;; ++round) {

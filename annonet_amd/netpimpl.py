@@ -122,8 +122,9 @@ def ignore_large_nonzero_regions(label_image, receptive_field_side, by_area=floa
 
 class Dataset:
     """Full images + label images resident in HBM; training crops are cut on the device (randomly_crop_image,
-    annonet_train_main.cpp:110-232, further_downscaling_factor = 1, draws supplied by the caller).
-    A crop spec is (image index, left, top, flip_left_right, flip_upside_down, brightness_change)."""
+    annonet_train_main.cpp:110-232, draws supplied by the caller).
+    A crop spec is (image index, left, top, flip_left_right, flip_upside_down, brightness_change) optionally followed by
+    (further_downscaling_factor, noise_level, noise_seed, (red, green, blue) colour offsets)."""
 
     def __init__(self, channels=3):
         self.L = _lib.lib()
@@ -147,8 +148,12 @@ class Dataset:
     @staticmethod
     def _specs(specs):
         arr = (_lib.CropSpec * len(specs))()
-        for a, s in zip(arr, specs):
+        for a, s in zip(arr, specs):   # (image, left, top, flip_lr, flip_ud, brightness[, further downscaling, noise level, noise seed, (dr, dg, db)])
             a.image, a.left, a.top, a.flip_left_right, a.flip_upside_down, a.brightness_change = int(s[0]), int(s[1]), int(s[2]), int(s[3]), int(s[4]), float(s[5])
+            if len(s) > 6:
+                a.further_downscaling_factor, a.noise_level, a.noise_seed = float(s[6]), int(s[7]), int(s[8])
+                for k in range(3):
+                    a.color_offset[k] = int(s[9][k])
         return arr
 
     def crop_batch(self, specs, dim, classes, class_weight=0.5, image_weight=0.5):

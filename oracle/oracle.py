@@ -240,25 +240,57 @@ def get_tiles(width, height, max_w, max_h, ov_x, ov_y):
     return [(tuple(arr[i].full), tuple(arr[i].unique)) for i in range(n)]
 
 
-def crop_sample(image, labels, left, top, dim, flip_lr, flip_ud, brightness_change, class_weight, image_weight):
-    """randomly_crop_image (annonet_train_main.cpp:110-232) for further_downscaling_factor = 1 and given draws, composed from
-    the oracle's own pieces: integer-rect chip, outpaint (annonet.h:74-120), labels "ignore" outside the image (:150-158),
-    set_weights (:178), flips (:183-194), multiplicative brightness (:196-216; tuc::round taken as round-half-up
-    [UPSTREAM-UNVERIFIED: tuc is not in the snapshot]).  -> (image u8, labels u16, weights f32)"""
+def noise_draw(seed, counter, level):
+    """The counter-based draw of the device's add_random_noise (kernels.h crop_noise_draw): splitmix64 finaliser -> [-level, level]"""
+    m = (1 << 64) - 1
+    z = (int(seed) + (int(counter) + 1) * 0x9E3779B97F4A7C15) & m
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & m
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & m
+    z ^= z >> 31
+    return int(z % (2 * level + 1)) - level
+
+
+def crop_sample(image, labels, left, top, dim, flip_lr, flip_ud, brightness_change, class_weight, image_weight,
+                further_downscaling_factor=1.0, noise_level=0, noise_seed=0, color_offset=(0, 0, 0)):
+    """randomly_crop_image (annonet_train_main.cpp:110-232) for given draws, composed from the oracle's own pieces: integer-rect
+    chip of round(dim * further_downscaling_factor) pixels, outpaint (annonet.h:74-120), labels "ignore" outside the image
+    (:150-158), the resize to dim x dim when downscaling (:160-171; dlib::resize_image restated [UPSTREAM-UNVERIFIED]: corner-aligned
+    grid, bilinear in float rounded half up for the image, nearest neighbour for the labels), set_weights (:178), flips (:183-194),
+    multiplicative brightness (:196-216; tuc::round taken as round-half-up [UPSTREAM-UNVERIFIED: tuc is not in the snapshot]),
+    add_random_noise (:73-105,218-222, with the device's counter-based draws) and the colour offset (:226-231, offsets given).
+    -> (image u8, labels u16, weights f32)"""
     image = np.asarray(image, dtype=np.uint8)
     labels = np.asarray(labels, dtype=np.uint16)
     H, W = labels.shape
-    chip = np.zeros((dim, dim) + image.shape[2:], dtype=np.uint8)
-    lab = np.full((dim, dim), 65535, dtype=np.uint16)
-    y0, y1, x0, x1 = max(top, 0), min(top + dim, H), max(left, 0), min(left + dim, W)   # valid_rect_in_full_image
+    f = 1.0 if not further_downscaling_factor else float(further_downscaling_factor)
+    src = int(np.floor(dim * f + 0.5)) if f != 1.0 else dim      # std::round
+    chip = np.zeros((src, src) + image.shape[2:], dtype=np.uint8)
+    lab = np.full((src, src), 65535, dtype=np.uint16)
+    y0, y1, x0, x1 = max(top, 0), min(top + src, H), max(left, 0), min(left + src, W)   # valid_rect_in_full_image
     if y0 < y1 and x0 < x1:
         chip[y0 - top:y1 - top, x0 - left:x1 - left] = image[y0:y1, x0:x1]
         lab[y0 - top:y1 - top, x0 - left:x1 - left] = labels[y0:y1, x0:x1]
         chip = outpaint(chip, (x0 - left, y0 - top, x1 - left - 1, y1 - top - 1))
     else:   # the rectangle misses the image entirely: the device clamps to the nearest edge pixel
-        ys = np.clip(np.arange(top, top + dim), 0, H - 1)
-        xs = np.clip(np.arange(left, left + dim), 0, W - 1)
+        ys = np.clip(np.arange(top, top + src), 0, H - 1)
+        xs = np.clip(np.arange(left, left + src), 0, W - 1)
         chip = image[np.ix_(ys, xs)]
+    if src != dim:
+        scale = (src - 1) / max(dim - 1, 1)
+        pos = np.arange(dim) * scale
+        near = np.floor(pos + 0.5).astype(np.int64)
+        lab = lab[np.ix_(near, near)]
+        i0 = np.floor(pos).astype(np.int64)
+        i1 = np.minimum(i0 + 1, src - 1)
+        fr = (pos - i0).astype(np.float32)
+        c = chip.astype(np.float32).reshape(src, src, -1)
+        one = np.float32(1.0)
+        fx = fr[None, :, None]
+        fy = fr[:, None, None]
+        topv = (one - fx) * c[np.ix_(i0, i0)] + fx * c[np.ix_(i0, i1)]
+        botv = (one - fx) * c[np.ix_(i1, i0)] + fx * c[np.ix_(i1, i1)]
+        val = (one - fy) * topv + fy * botv + np.float32(0.5)
+        chip = val.astype(np.int32).astype(np.uint8).reshape((dim, dim) + image.shape[2:])
     weights = set_weights(lab, class_weight, image_weight)
     if flip_lr:
         chip, lab, weights = chip[:, ::-1], lab[:, ::-1], weights[:, ::-1]
@@ -266,6 +298,13 @@ def crop_sample(image, labels, left, top, dim, flip_lr, flip_ud, brightness_chan
         chip, lab, weights = chip[::-1], lab[::-1], weights[::-1]
     if brightness_change != 1.0:
         chip = np.floor(np.clip(chip.astype(np.float64) * float(brightness_change), 0.0, 255.0) + 0.5).astype(np.uint8)
+    chip = np.ascontiguousarray(chip)
+    if noise_level > 0:
+        flat = chip.reshape(-1).astype(np.int64)
+        draws = np.array([noise_draw(noise_seed, i, noise_level) for i in range(flat.size)], dtype=np.int64)
+        chip = np.clip(flat + draws, 0, 255).astype(np.uint8).reshape(chip.shape)
+    if chip.ndim == 3 and any(color_offset):
+        chip = np.clip(chip.astype(np.int64) + np.asarray(color_offset, dtype=np.int64)[None, None, :], 0, 255).astype(np.uint8)
     return np.ascontiguousarray(chip), np.ascontiguousarray(lab), np.ascontiguousarray(weights)
 
 

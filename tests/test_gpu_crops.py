@@ -53,6 +53,39 @@ def test_crop_batch_matches_oracle(channels, classes, dim):
         np.testing.assert_array_equal(wgt2[k], orc.crop_sample(full[i][0], full[i][1], left, top, dim, flr, fud, gain, 0.3, 0.9)[2])
 
 
+@pytest.mark.parametrize("channels,dim", [(3, 35), (1, 40)])
+def test_crop_batch_with_downscaling_noise_and_colour_offset_matches_oracle(channels, dim):
+    """further downscaling (annonet_train_main.cpp:124-127,160-171), add_random_noise (:73-105) and the colour offset (:226-231) on
+    the device, bit for bit against the oracle's restatement (same float32 bilinear arithmetic, same counter-based noise draws)"""
+    rng = np.random.default_rng(50 + channels)
+    ds, full = make_dataset(rng, channels, [(130, 171), (64, 90)], 4)
+    specs = []
+    for k, base in enumerate(random_specs(rng, full, 18, dim)):
+        f = [1.0, 1.5, 2.0, 2.37][k % 4]
+        level = [0, 3, 40, 255][(k // 2) % 4]
+        off = (0, 0, 0) if channels == 1 or k % 3 == 0 else tuple(int(v) for v in rng.integers(-40, 41, 3))
+        i, left, top = base[0], base[1], base[2]
+        if f != 1.0:   # keep part of the larger rectangle on the image
+            h, w = full[i][1].shape
+            left, top = int(rng.integers(-20, w - 10)), int(rng.integers(-20, h - 10))
+        specs.append((i, left, top, base[3], base[4], base[5], f, level, int(rng.integers(0, 2 ** 62)), off))
+    img, lab, wgt = ds.crop_batch(specs, dim, 4, 0.5, 0.5)
+    for k, (i, left, top, flr, fud, gain, f, level, seed, off) in enumerate(specs):
+        wi, wl, ww = orc.crop_sample(full[i][0], full[i][1], left, top, dim, flr, fud, gain, 0.5, 0.5, f, level, seed, off)
+        np.testing.assert_array_equal(lab[k], wl, err_msg=f"crop {k} {specs[k]}")
+        np.testing.assert_array_equal(wgt[k], ww, err_msg=f"crop {k} {specs[k]}")
+        np.testing.assert_array_equal(img[k], wi, err_msg=f"crop {k} {specs[k]}")
+    noisy = [k for k, s in enumerate(specs) if s[7] == 40 and s[6] == 1.0 and s[5] == 1.0]
+    assert noisy, "the parametrisation lost its plain noise case"
+    k = noisy[0]
+    clean = ds.crop_batch([specs[k][:6]], dim, 4)[0][0].astype(int)
+    delta = img[k].astype(int) - np.clip(clean + np.asarray(specs[k][9] if channels == 3 else 0), 0, 255)
+    unclamped = (clean > 45) & (clean < 210)
+    assert np.abs(delta[unclamped]).max() <= 40 and delta[unclamped].std() > 15        # uniform in [-40, 40]: sigma 23.4
+    with pytest.raises(aa.AnnonetHipError):
+        ds.crop_batch([(0, 0, 0, 0, 0, 1.0, 0.5, 0, 0, (0, 0, 0))], dim, 4)               # factor < 1
+
+
 def test_crop_batch_errors():
     rng = np.random.default_rng(1)
     ds, full = make_dataset(rng, 3, [(30, 30)], 3)

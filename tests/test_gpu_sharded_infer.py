@@ -73,6 +73,18 @@ def test_sharded_inference_assembles_the_single_process_result(world):
         srt = np.sort(want_pl_np + g, axis=0)
         assert ((srt[-1] - srt[-2])[diff] <= 4e-6 * span).all()
     assert diff.mean() < 1e-4
+    # ... and against the ORACLE (annonet_infer.cpp:42-214 restated on the CPU), not only against the library's own single-process result
+    from oracle.oracle import OracleNet
+    o = OracleNet(1, 3, 3, 0.5, 4)
+    p, r = t.get_params()
+    o.params[:], o.running[:] = p, r
+    ref_lab, ref_pl = o.infer(image.cpu().numpy(), gains=gains, max_tile=(96, 112), overlap=ov, want_blended=True)
+    np.testing.assert_allclose(got_pl, ref_pl, rtol=0, atol=2e-6 * span)
+    odiff = got_lab != ref_lab.astype(np.int64)
+    if odiff.any():
+        srt = np.sort(ref_pl + np.asarray(gains, dtype=np.float32)[:, None, None], axis=0)
+        assert ((srt[-1] - srt[-2])[odiff] <= 4e-6 * span).all()
+    assert odiff.mean() < 1e-4
 
 
 def test_exchange_is_empty_for_one_rank():

@@ -123,3 +123,69 @@ def test_confusion_matrix_printout_layout(tmp_path):
     assert lines[4].split() == ["2", "1", "0", "2", "66.67", "%"]
     assert lines[5].split() == ["precision", "50", "%", "67", "%", "100", "%"]
     assert lines[6].split() == ["accuracy", "71.43", "%"]
+
+
+# ---------------------------------------------------------------------------------------------------------------- N2: training data path
+from oracle import oracle as orc   # noqa: E402  (the checker of the host-cut crops)
+
+
+@pytest.mark.parametrize("case", [
+    dict(left=7, top=4, dim=35, flr=0, fud=0, gain=1.0, f=1.0, off=(0, 0, 0)),
+    dict(left=-12, top=60, dim=35, flr=1, fud=0, gain=1.23, f=1.0, off=(0, 0, 0)),          # partly outside: outpaint + ignore labels
+    dict(left=30, top=-9, dim=40, flr=0, fud=1, gain=0.8, f=1.5, off=(5, -17, 30)),          # further downscaling + colour offset
+    dict(left=-200, top=10, dim=33, flr=1, fud=1, gain=1.0, f=2.37, off=(0, 0, 0)),          # the rectangle misses the image entirely
+])
+def test_host_cut_crop_matches_the_oracle(tmp_path, case):
+    """cut_crop_on_host (= randomly_crop_image, annonet_train_main.cpp:129-231, with the draws given) bit for bit against the oracle's
+    crop_sample — the same checker the device-cut crops are held to (tests/test_gpu_crops.py)"""
+    rng = np.random.default_rng(7)
+    h, w = 90, 120
+    img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    coarse = rng.integers(0, 3, (h // 6 + 1, w // 6 + 1))
+    lab = np.kron(coarse, np.ones((6, 6), dtype=np.int64))[:h, :w].astype(np.uint16)
+    lab[rng.random((h, w)) < 0.1] = 65535
+    pu.write_png(tmp_path / "i.png", img)
+    pu.write_png(tmp_path / "i.png_mask.png", pu.labels_to_rgba(lab))
+    c = case
+    run("crop", tmp_path / "i.png", tmp_path / "i.png_mask.png", c["left"], c["top"], c["dim"], c["flr"], c["fud"], c["gain"], c["f"], *c["off"], tmp_path / "out")
+    d = c["dim"]
+    gi = np.fromfile(str(tmp_path / "out") + ".img.raw", np.uint8).reshape(d, d, 3)
+    gl = np.fromfile(str(tmp_path / "out") + ".lab.raw", np.uint16).reshape(d, d)
+    gw = np.fromfile(str(tmp_path / "out") + ".w.raw", np.float32).reshape(d, d)
+    wi, wl, ww = orc.crop_sample(img, lab, c["left"], c["top"], d, c["flr"], c["fud"], c["gain"], 0.5, 0.5, c["f"], 0, 0, c["off"])
+    np.testing.assert_array_equal(gl, wl)
+    np.testing.assert_array_equal(gw, ww)
+    np.testing.assert_array_equal(gi, wi)
+
+
+def test_add_random_noise_is_uniform_in_the_rounded_level():
+    lo, hi, mean = run("noise", 12.4, 5, 200).split()       # std::round(12.4) = 12 (annonet_train_main.cpp:75)
+    assert int(lo) == -12 and int(hi) == 12 and abs(float(mean)) < 0.1
+    lo, hi, mean = run("noise", 0.4, 5, 20).split()         # rounds to 0: untouched
+    assert (int(lo), int(hi), float(mean)) == (0, 0, 0.0)
+
+
+def test_color_offsets_follow_the_covariance_square_root():
+    """apply_random_color_offset's offsets [UPSTREAM-UNVERIFIED]: round(0.1 * tform * gaussian) — strongly correlated channels, sigma ~ 7"""
+    v = np.array(run("color-offsets", 3, 4000).split(), dtype=np.int64).reshape(-1, 3)
+    tform = np.array([[-66.379, 25.094, 6.79698], [-68.0492, -0.302309, -13.9539], [-68.4907, -24.0199, 7.27653]])
+    want_cov = 0.01 * tform @ tform.T
+    got_cov = np.cov(v.T)
+    assert np.abs(got_cov - want_cov).max() < 0.12 * np.abs(want_cov).max()
+    assert np.abs(v.mean(0)).max() < 0.5
+
+
+def test_shared_lru_cache_evicts_the_least_recently_used(tmp_path):
+    from collections import OrderedDict
+    rng = np.random.default_rng(0)
+    keys = [f"k{'x' * int(i)}" for i in rng.integers(0, 9, 300)]
+    for cap in (1, 3, 8, 20):
+        d, hits, misses, ev = OrderedDict(), 0, 0, 0
+        for k in keys:
+            if k in d:
+                d.move_to_end(k); hits += 1
+            else:
+                d[k] = 1; misses += 1
+                if len(d) > cap:
+                    d.popitem(last=False); ev += 1
+        assert [int(x) for x in run("lru", cap, *keys).split()] == [hits, misses, ev, len(d)]
