@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 #include "kernels.h"
@@ -241,6 +242,315 @@ __global__ __launch_bounds__(256) void conv_generic_kernel(ConvArgs a) {
                 }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// conv_f32_mfma: the fp32 parity mode on the matrix cores.  v_mfma_f32_32x32x2_f32 is bit for bit a k-ordered fmaf chain
+// (D = fma(a_k1, b_k1, fma(a_k0, b_k0, C)), one rounding per product, no wider accumulation: MI355X_MICROARCH.md § Matrix cores),
+// so chaining it over (tap row-major, input channel innermost, two channels per instruction) reproduces conv_generic's — and
+// the oracle's — sums exactly, at the fp32 MATRIX rate instead of one fmaf per lane and output.
+//   one wave = 32 consecutive output pixels of one output row x NT*32 output channels; any con / cont geometry (the tap ->
+//   source pixel rule is conv_generic's); A = weights (row = output channel, k = channel parity = lane >> 5), B = pixels.
+//   Operands come straight from global memory: a lane fetches 8 consecutive channels of ITS pixel (32 B, through the producer's
+//   bn + relu (+ skip add)) per four instructions and one weight dword per instruction (32 output channels contiguous); an MFMA
+//   holds the pipe for 64 cycles, so 4+ waves per SIMD hide those L1 / L2 round trips without LDS staging.
+//   Padding taps, channels beyond c_red and output channels beyond c_out multiply by an exact 0 (fma(w, 0, acc) = acc: acc is
+//   never -0 because every chain starts at +0), so the result is the same as skipping them.
+// ---------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+// exact zeroing without a select: a "cond ? loaded : 0" makes hipcc branch around the LOAD and wait for it on the spot
+// (cdna_hip_programming.md §5, trap (c)); an integer AND keeps every load unconditional and in flight together
+__device__ __forceinline__ float and_mask(float v, unsigned m) { return __uint_as_float(__float_as_uint(v) & m); }
+
+template <int KIND, int NT, bool VEC>
+__global__ __launch_bounds__(256) void conv_f32_mfma_kernel(ConvArgs a, int tiles_x) {
+    const int lane = threadIdx.x & 63, j = lane & 31, hf = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t n_tiles = (int64_t)a.n * a.h_out * tiles_x;
+    if (tile >= n_tiles) return;   // wave-uniform; the kernel has no barrier
+    const int tx = (int)(tile % tiles_x);
+    const int64_t row = tile / tiles_x;
+    const int oy = (int)(row % a.h_out), n = (int)(row / a.h_out);
+    // con: 32 consecutive output columns.  cont (transposed, stride s): 32 columns of ONE residue class mod s — a tap is then valid
+    // for every lane or for none (t = ox + pad - kx must be a multiple of s), so no instruction multiplies structural zeros
+    const int xs = a.gather ? a.stride : 1;
+    const int ox = a.gather ? ((tx / xs) * 32 + j) * xs + (tx % xs) : tx * 32 + j;
+    const bool px_live = ox < a.w_out;
+    const int co_base = blockIdx.y * (NT * 32);
+    const int c_red = a.c_red, c_out = a.c_out;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+    // this lane's output channel per tile (A operand row), clamped for the load, and the mask that zeroes rows beyond c_out
+    int co_l[NT];
+    unsigned co_m[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { const int co = co_base + nt * 32 + j; co_m[nt] = co < c_out ? 0xffffffffu : 0u; co_l[nt] = min(co, c_out - 1); }
+    const float* xa = reinterpret_cast<const float*>(a.src.a);
+    const float* xb = reinterpret_cast<const float*>(a.src.b);
+
+    for (int ky = 0; ky < a.k; ++ky) {
+        int iy;
+        const bool vy = tap_source(oy, ky, a.stride, a.pad, a.gather, a.h_in, iy);   // wave-uniform
+        if (!vy) continue;
+        for (int kx = 0; kx < a.k; ++kx) {
+            int ix;
+            const bool valid = tap_source(ox, kx, a.stride, a.pad, a.gather, a.w_in, ix) && px_live;
+            if (!__any(valid)) continue;   // every lane would multiply by 0: the identity
+            const float* wt = a.w_f32 + (size_t)(ky * a.k + kx) * c_red * c_out;
+            const int ixc = valid ? ix : 0;
+            const unsigned vm = valid ? 0xffffffffu : 0u;
+            const size_t pixel = ((size_t)n * a.h_in + iy) * a.w_in + ixc;   // always inside the tensor: the load is unconditional
+            if (VEC) {
+                for (int c8 = 0; c8 < c_red; c8 += 8) {
+                    // every load of the group first: 8 channels of this lane's pixel (both inputs of a skip add) and the 4 NT weights
+                    const Raw8<float> ra = raw_load8(xa + pixel * c_red + c8);
+                    Raw8<float> rb{};
+                    if (KIND == SRC_ACT2) rb = raw_load8(xb + pixel * c_red + c8);
+                    float wv[4][NT];
+#pragma unroll
+                    for (int st = 0; st < 4; ++st)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) wv[st][nt] = wt[(size_t)(c8 + 2 * st + hf) * c_out + co_l[nt]];
+                    float v[8];
+                    raw_to_float(ra, v);
+                    if (KIND != SRC_RAW) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[q] = relu_affine(v[q], a.src.a_scale[c8 + q], a.src.a_shift[c8 + q]);
+                        if (KIND == SRC_ACT2) {
+                            float u[8];
+                            raw_to_float(rb, u);
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) v[q] += relu_affine(u[q], a.src.b_scale[c8 + q], a.src.b_shift[c8 + q]);
+                        }
+                    }
+#pragma unroll
+                    for (int st = 0; st < 4; ++st) {
+                        const float b = and_mask(hf ? v[2 * st + 1] : v[2 * st], vm);
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(and_mask(wv[st][nt], co_m[nt]), b, acc[nt], 0, 0, 0);
+                    }
+                }
+            } else {   // channel counts that are not multiples of 8 (the image: 1 or 3 channels; odd widths): one value at a time
+                for (int c8 = 0; c8 < c_red; c8 += 8) {
+                    float v[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] = and_mask(fetch1<float, KIND>(a.src, n, iy, ixc, a.h_in, a.w_in, c_red, min(c8 + q, c_red - 1)), (c8 + q < c_red) ? vm : 0u);
+#pragma unroll
+                    for (int st = 0; st < 4; ++st) {
+                        if (c8 + 2 * st >= c_red) break;          // wave-uniform: nothing but padding left in this group
+                        const int c = c8 + 2 * st + hf;
+                        const float b = hf ? v[2 * st + 1] : v[2 * st];
+                        const unsigned cm = c < c_red ? 0xffffffffu : 0u;
+                        const float* wr = wt + (size_t)min(c, c_red - 1) * c_out;
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(and_mask(wr[co_l[nt]], co_m[nt] & cm), b, acc[nt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    if (!px_live) return;
+    // accumulator: column = pixel j; register r of lane half hf = output channel (r & 3) + 8 (r >> 2) + 4 hf of the tile
+    const size_t opix = ((size_t)n * a.h_out + oy) * a.w_out + ox;
+    float* out = reinterpret_cast<float*>(a.out);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int co0 = co_base + nt * 32 + 8 * g + 4 * hf;
+            if (co0 >= c_out) continue;
+            float r[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) r[q] = acc[nt][4 * g + q] + ((a.bias && co0 + q < c_out) ? a.bias[co0 + q] : 0.f);
+            if (a.out_nchw) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (co0 + q < c_out) out[(((size_t)n * c_out + co0 + q) * a.h_out + oy) * a.w_out + ox] = r[q];
+            } else if ((c_out & 3) == 0) *reinterpret_cast<float4*>(out + opix * c_out + co0) = make_float4(r[0], r[1], r[2], r[3]);
+            else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (co0 + q < c_out) out[opix * c_out + co0 + q] = r[q];
+            }
+        }
+}
+
+// The same computation for channel counts that are multiples of 8 (every layer but the image stem), software-pipelined: the
+// (tap, 8-channel group) items of a wave are walked by a wave-uniform state machine, and the operands of item i+1 (32 B of the
+// lane's pixel per input tensor + 4 NT weight dwords) are requested BEFORE the four MFMA steps of item i issue, so their L1 / L2
+// round trip hides behind 4 NT x 64 matrix cycles instead of being exposed once per item; the producer's (scale, shift) tables
+// sit in LDS.  Two register sets used alternately (A computes while B loads, then the reverse): no copies.  The instruction
+// ORDER — and with it every sum — is exactly that of conv_f32_mfma_kernel.
+template <int KIND, int NT>
+__global__ __launch_bounds__(256) void conv_f32_mfma_vec_kernel(ConvArgs a, int tiles_x) {
+    extern __shared__ __attribute__((aligned(16))) float f32_tab[];   // [a_scale | a_shift | b_scale | b_shift][c_red]
+    const int c_red = a.c_red, c_out = a.c_out;
+    if (KIND != SRC_RAW) {
+        for (int i = threadIdx.x; i < c_red; i += 256) {
+            f32_tab[i] = a.src.a_scale[i]; f32_tab[c_red + i] = a.src.a_shift[i];
+            if (KIND == SRC_ACT2) { f32_tab[2 * c_red + i] = a.src.b_scale[i]; f32_tab[3 * c_red + i] = a.src.b_shift[i]; }
+        }
+        __syncthreads();
+    }
+    const int lane = threadIdx.x & 63, j = lane & 31, hf = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t n_tiles = (int64_t)a.n * a.h_out * tiles_x;
+    if (tile >= n_tiles) return;   // wave-uniform, after the only barrier
+    const int tx = (int)(tile % tiles_x);
+    const int64_t row = tile / tiles_x;
+    const int oy = (int)(row % a.h_out), n = (int)(row / a.h_out);
+    const int xs = a.gather ? a.stride : 1;
+    const int ox = a.gather ? ((tx / xs) * 32 + j) * xs + (tx % xs) : tx * 32 + j;
+    const bool px_live = ox < a.w_out;
+    const int co_base = blockIdx.y * (NT * 32);
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+    int co_l[NT];
+    unsigned co_m[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { const int co = co_base + nt * 32 + j; co_m[nt] = co < c_out ? 0xffffffffu : 0u; co_l[nt] = min(co, c_out - 1); }
+    const float* xa = reinterpret_cast<const float*>(a.src.a);
+    const float* xb = reinterpret_cast<const float*>(a.src.b);
+
+    struct Item { Raw8<float> ra, rb; float wv[4][NT]; unsigned vm; int c8; };
+    // the walk over (filter row, filter column, channel group): wave-uniform except for the lane's pixel and validity
+    int ky = 0, kx = -1, c8 = c_red;
+    size_t pix = 0;
+    unsigned vm = 0;
+    const float* wt = a.w_f32;
+    auto next = [&]() __attribute__((always_inline)) -> bool {
+        c8 += 8;
+        if (c8 < c_red) return true;
+        for (;;) {
+            if (++kx >= a.k) { kx = 0; ++ky; }
+            if (ky >= a.k) return false;
+            int iy, ix;
+            if (!tap_source(oy, ky, a.stride, a.pad, a.gather, a.h_in, iy)) { kx = a.k - 1; continue; }   // the whole filter row misses the image
+            const bool valid = tap_source(ox, kx, a.stride, a.pad, a.gather, a.w_in, ix) && px_live;
+            if (!__any(valid)) continue;   // every lane would multiply by 0: the identity
+            wt = a.w_f32 + (size_t)(ky * a.k + kx) * c_red * c_out;
+            vm = valid ? 0xffffffffu : 0u;
+            pix = (((size_t)n * a.h_in + iy) * a.w_in + (valid ? ix : 0)) * c_red;   // always inside the tensor: unconditional loads
+            c8 = 0;
+            return true;
+        }
+    };
+    auto load = [&](Item& it) __attribute__((always_inline)) {
+        it.c8 = c8; it.vm = vm;
+        it.ra = raw_load8(xa + pix + c8);
+        if (KIND == SRC_ACT2) it.rb = raw_load8(xb + pix + c8);
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) it.wv[st][nt] = wt[(size_t)(c8 + 2 * st + hf) * c_out + co_l[nt]];
+    };
+    auto compute = [&](const Item& it) __attribute__((always_inline)) {
+        float v[8];
+        raw_to_float(it.ra, v);
+        if (KIND != SRC_RAW) {
+            float sc[8], sh[8];
+            load8<float>(f32_tab + it.c8, sc);
+            load8<float>(f32_tab + c_red + it.c8, sh);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = relu_affine(v[q], sc[q], sh[q]);
+            if (KIND == SRC_ACT2) {
+                float u[8];
+                raw_to_float(it.rb, u);
+                load8<float>(f32_tab + 2 * c_red + it.c8, sc);
+                load8<float>(f32_tab + 3 * c_red + it.c8, sh);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] += relu_affine(u[q], sc[q], sh[q]);
+            }
+        }
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            const float b = and_mask(hf ? v[2 * st + 1] : v[2 * st], it.vm);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(and_mask(it.wv[st][nt], co_m[nt]), b, acc[nt], 0, 0, 0);
+        }
+    };
+    Item A, B;
+    if (next()) {
+        load(A);
+        for (;;) {
+            const bool more_b = next();
+            if (more_b) load(B);
+            compute(A);
+            if (!more_b) break;
+            const bool more_a = next();
+            if (more_a) load(A);
+            compute(B);
+            if (!more_a) break;
+        }
+    }
+    if (!px_live) return;
+    const size_t opix = ((size_t)n * a.h_out + oy) * a.w_out + ox;
+    float* out = reinterpret_cast<float*>(a.out);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int co0 = co_base + nt * 32 + 8 * g + 4 * hf;
+            if (co0 >= c_out) continue;
+            float r[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) r[q] = acc[nt][4 * g + q] + ((a.bias && co0 + q < c_out) ? a.bias[co0 + q] : 0.f);
+            if (a.out_nchw) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (co0 + q < c_out) out[(((size_t)n * c_out + co0 + q) * a.h_out + oy) * a.w_out + ox] = r[q];
+            } else if ((c_out & 3) == 0) *reinterpret_cast<float4*>(out + opix * c_out + co0) = make_float4(r[0], r[1], r[2], r[3]);
+            else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (co0 + q < c_out) out[opix * c_out + co0 + q] = r[q];
+            }
+        }
+}
+
+bool conv_f32_mfma_ok(const ConvArgs& a) {
+    static const int on = getenv("ANH_FP32_MFMA") ? atoi(getenv("ANH_FP32_MFMA")) : 1;
+    const bool in_f32 = a.src.kind == SRC_IMAGE || a.src.dtype == DT_F32;
+    const bool out_f32 = a.out_nchw || a.out_dtype == DT_F32;
+    return on && in_f32 && out_f32 && a.src.kind != SRC_BNBWD && !a.out_accumulate && !a.out2 && !a.stat_partials && !a.bnred_partials;
+}
+
+template <int NT>
+void launch_conv_f32_mfma_nt(const ConvArgs& a, hipStream_t s) {
+    const int xs = a.gather ? a.stride : 1;   // cont: one tile = 32 columns of one residue class mod stride
+    const int tiles_x = (((a.w_out + xs - 1) / xs + 31) / 32) * xs;
+    const int64_t n_tiles = (int64_t)a.n * a.h_out * tiles_x;
+    const dim3 grid((unsigned)((n_tiles + 3) / 4), (unsigned)((a.c_out + NT * 32 - 1) / (NT * 32))), block(256);
+    const bool vec = a.src.kind != SRC_IMAGE && (a.c_red % 8) == 0;
+    static const int pipelined = getenv("ANH_FP32_MFMA_PIPELINED") ? atoi(getenv("ANH_FP32_MFMA_PIPELINED")) : 1;
+    if (vec && pipelined) {
+        const size_t lds = (size_t)a.c_red * 16;
+        switch (a.src.kind) {
+            case SRC_RAW: hipLaunchKernelGGL((conv_f32_mfma_vec_kernel<SRC_RAW, NT>), grid, block, lds, s, a, tiles_x); break;
+            case SRC_ACT: hipLaunchKernelGGL((conv_f32_mfma_vec_kernel<SRC_ACT, NT>), grid, block, lds, s, a, tiles_x); break;
+            default: hipLaunchKernelGGL((conv_f32_mfma_vec_kernel<SRC_ACT2, NT>), grid, block, lds, s, a, tiles_x); break;
+        }
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
+    switch (a.src.kind) {
+        case SRC_RAW: if (vec) hipLaunchKernelGGL((conv_f32_mfma_kernel<SRC_RAW, NT, true>), grid, block, 0, s, a, tiles_x); else hipLaunchKernelGGL((conv_f32_mfma_kernel<SRC_RAW, NT, false>), grid, block, 0, s, a, tiles_x); break;
+        case SRC_ACT: if (vec) hipLaunchKernelGGL((conv_f32_mfma_kernel<SRC_ACT, NT, true>), grid, block, 0, s, a, tiles_x); else hipLaunchKernelGGL((conv_f32_mfma_kernel<SRC_ACT, NT, false>), grid, block, 0, s, a, tiles_x); break;
+        case SRC_ACT2: if (vec) hipLaunchKernelGGL((conv_f32_mfma_kernel<SRC_ACT2, NT, true>), grid, block, 0, s, a, tiles_x); else hipLaunchKernelGGL((conv_f32_mfma_kernel<SRC_ACT2, NT, false>), grid, block, 0, s, a, tiles_x); break;
+        default: hipLaunchKernelGGL((conv_f32_mfma_kernel<SRC_IMAGE, NT, false>), grid, block, 0, s, a, tiles_x); break;
+    }
+    HIP_CHECK(hipGetLastError());
 }
 
 template <typename TIN, typename TOUT>
@@ -1294,6 +1604,12 @@ void run_detection_filter(const float* d_blended, uint16_t* d_labels, int k, int
 void launch_conv_generic(const ConvArgs& a, hipStream_t s) {
     const int64_t total = (int64_t)a.n * a.h_out * a.w_out;
     if (total == 0) return;
+    if (conv_f32_mfma_ok(a)) {   // fp32 storage: the same k-ordered chains on v_mfma_f32_32x32x2_f32
+        if (a.c_out > 64) launch_conv_f32_mfma_nt<4>(a, s);
+        else if (a.c_out > 32) launch_conv_f32_mfma_nt<2>(a, s);
+        else launch_conv_f32_mfma_nt<1>(a, s);
+        return;
+    }
     if (stem_forward_ok(a)) {
         const int tiles_x = (a.w_out + 31) / 32, tiles_y = (a.h_out + 7) / 8;
         const dim3 grid((unsigned)(tiles_x * tiles_y * a.n));

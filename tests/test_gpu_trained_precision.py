@@ -20,10 +20,10 @@ def scene(rng, h, w):
     for _ in range(rng.integers(3, 8)):
         y, x = rng.integers(0, h - 8), rng.integers(0, w - 8)
         lab[y:y + rng.integers(8, 30), x:x + rng.integers(8, 30)] = rng.integers(1, 3)
-    img = rng.integers(0, 50, (h, w, 3)).astype(np.int64)
-    img[lab == 1] += 90
-    img[lab == 2] += 170
-    img[(lab == 2) & ((np.arange(w)[None, :] // 2) % 2 == 0)] -= 40
+    img = rng.integers(0, 110, (h, w, 3)).astype(np.int64)     # heavy pixel noise: single pixels are ambiguous, neighbourhoods are not
+    img[lab == 1] += 45
+    img[lab == 2] += 95
+    img[(lab == 2) & ((np.arange(w)[None, :] // 2) % 2 == 0)] -= 35
     return np.clip(img, 0, 255).astype(np.uint8), lab
 
 
@@ -39,7 +39,7 @@ def test_bf16_and_fp32_label_maps_agree_on_a_trained_net():
             img, lab = scene(rng, D, D)
             imgs.append(img); wls.append(aa.set_weights(lab, 0.5, 0.5))
         t.StartTraining(imgs, wls)
-        if step % 50 == 49:
+        if step % 50 == 0 or step == 299:
             losses.append(t.get_last_loss())
     assert losses[-1] < 0.25 * losses[0], losses          # it learnt
     fp32, bf16 = t.GetRuntimeNet(aa.ANH_FP32), t.GetRuntimeNet(aa.ANH_BF16)
@@ -56,7 +56,7 @@ def test_bf16_and_fp32_label_maps_agree_on_a_trained_net():
         if differ.any():
             srt = np.sort(planes, axis=0)
             worst_margin = max(worst_margin, float((srt[-1] - srt[-2])[differ].max() / (planes.max() - planes.min())))
-    assert wrong / total < 0.1                            # the fp32 labels are mostly right: the margins are real
+    assert wrong / total < 0.2                            # the fp32 labels are mostly right: the margins are real
     assert mismatch / total < 2e-3, (mismatch, total)     # << 1 %: bf16 flips only near-ties
     assert worst_margin < 0.05, worst_margin             # ... and only where the top-2 margin is a few percent of the logit range
     print(f"bf16 vs fp32 label mismatch on a trained net: {mismatch}/{total} = {mismatch / total:.2e}; fp32 error vs truth {wrong / total:.3f}; worst flipped margin {worst_margin:.3f} of the logit range")
