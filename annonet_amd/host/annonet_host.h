@@ -399,99 +399,104 @@ inline unsigned long label_connected_blobs(const dlib::matrix<uint16_t>& img, dl
 }
 
 // ---------------------------------------------------------------------------------------- confusion matrices
-typedef std::vector<std::vector<size_t>> confusion_matrix_type;   // first index: ground truth, second index: predicted (annonet_infer_main.cpp:91-92)
+// Counts of (ground truth class, predicted class) pairs and the tool's printout of them (format of annonet_infer_main.cpp:101-194:
+// a "predicted" caption, a class header with a "recall" column, one row per ground-truth class with the word "truth" on the
+// middle row, a "precision" row, an "accuracy" line).  The layout is computed as strings first and padded afterwards.
+class ConfusionMatrix {
+  public:
+    explicit ConfusionMatrix(size_t class_count = 0) : k_(class_count), cells_(class_count * class_count, 0) {}
+    size_t classes() const { return k_; }
+    void add(size_t truth, size_t predicted, size_t n = 1) { if (truth < k_ && predicted < k_) cells_[truth * k_ + predicted] += n; }   // (a 65535 label = an all-NaN pixel: not a class)
+    size_t at(size_t truth, size_t predicted) const { return cells_[truth * k_ + predicted]; }
+    size_t total() const { size_t t = 0; for (size_t v : cells_) t += v; return t; }
 
-inline void init_confusion_matrix(confusion_matrix_type& confusion_matrix, size_t class_count) {
-    confusion_matrix.resize(class_count);
-    for (auto& i : confusion_matrix) i.resize(class_count);
-}
-
-inline void print_confusion_matrix(const confusion_matrix_type& confusion_matrix, const std::vector<AnnoClass>& anno_classes, std::ostream& out = std::cout) {   // annonet_infer_main.cpp:101-194
-    size_t max_value = 0;
-    for (const auto& ground_truth : confusion_matrix) for (const auto& predicted : ground_truth) max_value = std::max(max_value, predicted);
-    const size_t class_count = anno_classes.size();
-    const std::string truth_label = "truth", predicted_label = "predicted", precision_label = "precision", recall_label = "recall", shortest_max_precision_string = "100 %";
-    const size_t max_value_length = std::to_string(max_value).length();
-    const size_t value_column_width = std::max(shortest_max_precision_string.length() + 1, max_value_length + 2);
-    const size_t class_column_width = std::to_string(class_count - 1).length() + 3;
-    const size_t recall_column_width = recall_label.length() + 4;
-    out << std::setw((int)(truth_label.length() + class_column_width + value_column_width * class_count / 2 + predicted_label.length() / 2)) << std::right << predicted_label << std::endl;
-    out << std::setw((int)(truth_label.length() + class_column_width)) << ' ';
-    for (const auto& anno_class : anno_classes) out << std::right << std::setw((int)value_column_width) << anno_class.index;
-    out << std::setw((int)recall_column_width) << std::right << recall_label << std::endl;
-    std::vector<size_t> total_predicted(class_count);
-    size_t total_correct = 0, total = 0;
-    for (size_t ground_truth_index = 0; ground_truth_index < class_count; ++ground_truth_index) {
-        out << std::setw((int)truth_label.length());
-        if (ground_truth_index == (class_count - 1) / 2) out << truth_label; else out << ' ';
-        out << std::right << std::setw((int)class_column_width) << ground_truth_index;
-        size_t total_ground_truth = 0;
-        for (size_t predicted_index = 0; predicted_index < class_count; ++predicted_index) {
-            const auto& predicted = confusion_matrix[ground_truth_index][predicted_index];
-            out << std::right << std::setw((int)value_column_width) << predicted;
-            total_predicted[predicted_index] += predicted;
-            total_ground_truth += predicted;
-            if (predicted_index == ground_truth_index) total_correct += predicted;
-            total += predicted;
-        }
-        out << std::setw((int)recall_column_width) << std::fixed << std::setprecision(2);
-        out << confusion_matrix[ground_truth_index][ground_truth_index] * 100.0 / total_ground_truth << " %" << std::endl;
-    }
-    const auto precision_accuracy = std::min(static_cast<size_t>(2), value_column_width - shortest_max_precision_string.length() - 1);
-    out << std::setw((int)(truth_label.length() + class_column_width)) << precision_label << "  ";
-    for (size_t predicted_index = 0; predicted_index < class_count; ++predicted_index) {
-        out << std::right << std::setw((int)value_column_width - 2) << std::fixed << std::setprecision((int)precision_accuracy);
-        if (total_predicted[predicted_index] > 0) out << confusion_matrix[predicted_index][predicted_index] * 100.0 / total_predicted[predicted_index] << " %";
-        else out << "-" << "  ";
-    }
-    out << std::endl;
-    out << std::setw((int)(truth_label.length() + class_column_width + class_count * value_column_width)) << std::right << "accuracy";
-    out << std::right << std::setw((int)recall_column_width) << std::fixed << std::setprecision(2) << total_correct * 100.0 / total << " %" << std::endl;
-}
-
-struct update_confusion_matrix_per_region_temp_type { dlib::matrix<int> ground_truth_blobs, result_blobs; };
-
-// annonet_infer_main.cpp:202-272: every blob of the ground truth AND every blob of the result votes once (two-way)
-inline void update_confusion_matrix_per_region(confusion_matrix_type& confusion_matrix_per_region, const std::unordered_map<uint16_t, std::deque<dlib::point>>& labeled_points_by_class,
-                                               const dlib::matrix<uint16_t>& ground_truth_label_image, const dlib::matrix<uint16_t>& result_label_image,
-                                               update_confusion_matrix_per_region_temp_type& temp) {
-    if (labeled_points_by_class.empty()) return;
-    if (ground_truth_label_image.nr() != result_label_image.nr() || ground_truth_label_image.nc() != result_label_image.nc()) throw std::runtime_error("ground truth and result sizes differ");
-    const unsigned long ground_truth_blob_count = label_connected_blobs(ground_truth_label_image, temp.ground_truth_blobs);
-    const unsigned long result_blob_count = label_connected_blobs(result_label_image, temp.result_blobs);
-    const uint16_t ignore = dlib::loss_multiclass_log_per_pixel_::label_to_ignore;
-    const auto vote_blob_class = [&](unsigned long blob_count, const dlib::matrix<int>& blobs) {
-        std::vector<std::unordered_map<uint16_t, size_t>> votes_ground_truth(blob_count), votes_predicted(blob_count);
-        // ties: the reference takes std::max_element over an unordered_map, i.e. an unspecified winner; here the smallest class index wins
-        const auto find_class_with_most_votes = [&](const std::unordered_map<uint16_t, size_t>& votes) {
-            uint16_t best = ignore;
-            size_t best_votes = 0;
-            for (const auto& v : votes) if (v.second > best_votes || (v.second == best_votes && v.first < best)) { best = v.first; best_votes = v.second; }
-            return best;
-        };
-        for (const auto& i : labeled_points_by_class) {
-            const auto ground_truth = i.first;
-            for (const dlib::point& point : i.second) {
-                const auto blob_number = blobs(point.y(), point.x());
-                ++votes_ground_truth[blob_number][ground_truth];
-                ++votes_predicted[blob_number][result_label_image(point.y(), point.x())];
+    void print(std::ostream& out, const std::vector<AnnoClass>& anno_classes) const {
+        auto pad = [](const std::string& text, size_t width) { return text.size() >= width ? text : std::string(width - text.size(), ' ') + text; };
+        size_t largest = 0, row_sum_all = 0, diagonal = 0;
+        std::vector<size_t> column_sum(k_, 0), row_sum(k_, 0);
+        for (size_t t = 0; t < k_; ++t)
+            for (size_t p = 0; p < k_; ++p) {
+                const size_t v = at(t, p);
+                largest = std::max(largest, v); column_sum[p] += v; row_sum[t] += v; row_sum_all += v;
+                if (t == p) diagonal += v;
             }
+        const std::string truth_word = "truth", predicted_word = "predicted", recall_word = "recall", precision_word = "precision", full = "100 %";
+        const size_t cell_w = std::max(full.size() + 1, std::to_string(largest).size() + 2);
+        const size_t class_w = std::to_string(k_ - 1).size() + 3;
+        const size_t lead_w = truth_word.size() + class_w, recall_w = recall_word.size() + 4;
+        out << pad(predicted_word, lead_w + cell_w * k_ / 2 + predicted_word.size() / 2) << std::endl;
+        std::string header(lead_w, ' ');
+        for (const AnnoClass& c : anno_classes) header += pad(std::to_string(c.index), cell_w);
+        out << header << pad(recall_word, recall_w) << std::endl;
+        for (size_t t = 0; t < k_; ++t) {
+            std::string line = t == (k_ - 1) / 2 ? truth_word : std::string(truth_word.size(), ' ');
+            line += pad(std::to_string(t), class_w);
+            for (size_t p = 0; p < k_; ++p) line += pad(std::to_string(at(t, p)), cell_w);
+            std::ostringstream recall;   // setw applies to the number only; the " %" follows it (as the reference's stream does)
+            recall << std::setw((int)recall_w) << std::fixed << std::setprecision(2) << at(t, t) * 100.0 / row_sum[t] << " %";
+            out << line << recall.str() << std::endl;
         }
-        for (unsigned long blob_number = 0; blob_number < blob_count; ++blob_number) {
-            const auto& blob_ground_truth = votes_ground_truth[blob_number];
-            auto& blob_predicted = votes_predicted[blob_number];
-            const bool ground_truth_predominantly_non_background = find_class_with_most_votes(blob_ground_truth) != 0;
-            const bool predicted_background_only = blob_predicted.size() == 1 && blob_predicted.find(0) != blob_predicted.end();
-            if (ground_truth_predominantly_non_background && !predicted_background_only) blob_predicted.erase(0);
-            const auto winner_ground_truth = find_class_with_most_votes(blob_ground_truth);
-            if (winner_ground_truth != ignore) {
-                const auto winner_predicted = find_class_with_most_votes(blob_predicted);
-                if (winner_predicted < confusion_matrix_per_region.size()) ++confusion_matrix_per_region[winner_ground_truth][winner_predicted];   // (65535 = an all-NaN pixel's label)
-            }
+        const int precision_digits = (int)std::min<size_t>(2, cell_w - full.size() - 1);
+        std::string precision_line = pad(precision_word, lead_w) + "  ";
+        for (size_t p = 0; p < k_; ++p) {
+            std::ostringstream cell;
+            cell << std::right << std::setw((int)cell_w - 2) << std::fixed << std::setprecision(precision_digits);
+            if (column_sum[p] > 0) cell << at(p, p) * 100.0 / column_sum[p] << " %";
+            else cell << "-" << "  ";
+            precision_line += cell.str();
         }
+        out << precision_line << std::endl;
+        std::ostringstream accuracy;
+        accuracy << pad("accuracy", lead_w + k_ * cell_w) << std::setw((int)recall_w) << std::fixed << std::setprecision(2) << diagonal * 100.0 / row_sum_all << " %";
+        out << accuracy.str() << std::endl;
+    }
+
+  private:
+    size_t k_;
+    std::vector<size_t> cells_;
+};
+
+// Region-level scoring (annonet_infer_main.cpp:202-272): every connected region of the ground truth AND every connected region of
+// the result casts ONE vote: (the class most labelled pixels of the region carry in the ground truth, the class most of them
+// carry in the result).  Where the ground truth of a region is predominantly a defect class, background predictions inside it
+// are disregarded unless the result is background ONLY ("do not ignore any detection, even if small in area").  Regions without
+// labelled pixels do not vote.  Ties go to the smaller class index (the reference leaves them to unordered_map order).
+class RegionScorer {
+  public:
+    void score(ConfusionMatrix& matrix, const sample_type& truth, const dlib::matrix<uint16_t>& result) {
+        if (truth.labeled_points_by_class.empty()) return;
+        if (truth.label_image.nr() != result.nr() || truth.label_image.nc() != result.nc()) throw std::runtime_error("ground truth and result sizes differ");
+        vote(matrix, truth, result, label_connected_blobs(truth.label_image, blobs_), blobs_);
+        vote(matrix, truth, result, label_connected_blobs(result, blobs_), blobs_);
+    }
+
+  private:
+    static constexpr uint16_t kNone = dlib::loss_multiclass_log_per_pixel_::label_to_ignore;
+    struct Tally {   // per region: votes per class, dense for small class counts
+        std::vector<size_t> by_class;
+        void add(size_t cls) { if (cls >= by_class.size()) by_class.resize(cls + 1, 0); ++by_class[cls]; }
+        uint16_t winner() const { uint16_t best = kNone; size_t most = 0; for (size_t c = 0; c < by_class.size(); ++c) if (by_class[c] > most) { most = by_class[c]; best = (uint16_t)c; } return best; }
+        size_t distinct() const { size_t n = 0; for (size_t v : by_class) n += v > 0; return n; }
     };
-    vote_blob_class(ground_truth_blob_count, temp.ground_truth_blobs);
-    vote_blob_class(result_blob_count, temp.result_blobs);
-}
+    void vote(ConfusionMatrix& matrix, const sample_type& truth, const dlib::matrix<uint16_t>& result, unsigned long regions, const dlib::matrix<int>& region_of) {
+        std::vector<Tally> in_truth(regions), in_result(regions);
+        for (const auto& cls_points : truth.labeled_points_by_class)
+            for (const dlib::point& p : cls_points.second) {
+                const int region = region_of(p.y(), p.x());
+                in_truth[region].add(cls_points.first);
+                const uint16_t predicted = result(p.y(), p.x());
+                if (predicted != kNone) in_result[region].add(predicted);
+            }
+        for (unsigned long r = 0; r < regions; ++r) {
+            const uint16_t truth_class = in_truth[r].winner();
+            if (truth_class == kNone) continue;
+            Tally& predicted = in_result[r];
+            const bool background_only = predicted.distinct() == 1 && !predicted.by_class.empty() && predicted.by_class[0] > 0;
+            if (truth_class != 0 && !background_only && !predicted.by_class.empty()) predicted.by_class[0] = 0;
+            matrix.add(truth_class, predicted.winner());
+        }
+    }
+    dlib::matrix<int> blobs_;
+};
 
 #endif  // ANNONET_HIP_HOST_H

@@ -15,8 +15,8 @@ static void write_u16(const std::string& path, const dlib::matrix<uint16_t>& m) 
     std::ofstream f(path, std::ios::binary | std::ios::trunc);
     f.write(reinterpret_cast<const char*>(&*m.begin()), (std::streamsize)(m.size() * 2));
 }
-static void print_matrix(const confusion_matrix_type& m) {
-    for (const auto& row : m) { for (size_t v : row) std::cout << v << ' '; std::cout << '\n'; }
+static void print_matrix(const ConfusionMatrix& m) {
+    for (size_t t = 0; t < m.classes(); ++t) { for (size_t p = 0; p < m.classes(); ++p) std::cout << m.at(t, p) << ' '; std::cout << '\n'; }
 }
 
 int main(int argc, char** argv) try {
@@ -47,16 +47,16 @@ int main(int argc, char** argv) try {
         const auto gt = read_u16(a.at(1), nr, nc), res = read_u16(a.at(2), nr, nc);
         sample_type s;
         for (long r = 0; r < nr; ++r) for (long c = 0; c < nc; ++c) if (gt(r, c) != 65535) s.labeled_points_by_class[gt(r, c)].push_back(dlib::point(c, r));
-        confusion_matrix_type per_pixel, per_region;
-        init_confusion_matrix(per_pixel, K); init_confusion_matrix(per_region, K);
-        for (const auto& lp : s.labeled_points_by_class) for (const auto& p : lp.second) ++per_pixel[lp.first][res(p.y(), p.x())];
-        update_confusion_matrix_per_region_temp_type temp;
-        update_confusion_matrix_per_region(per_region, s.labeled_points_by_class, gt, res, temp);
+        s.label_image = gt;
+        ConfusionMatrix per_pixel(K), per_region(K);
+        for (const auto& lp : s.labeled_points_by_class) for (const auto& p : lp.second) per_pixel.add(lp.first, res(p.y(), p.x()));
+        RegionScorer scorer;
+        scorer.score(per_region, s, res);
         if (a[0] == "confusion") { print_matrix(per_pixel); print_matrix(per_region); }
         else {
             std::vector<AnnoClass> classes;
             for (size_t k = 0; k < K; ++k) classes.push_back(AnnoClass((uint16_t)k, dlib::rgb_alpha_pixel(1, 1, 1, 1), "c"));
-            print_confusion_matrix(per_pixel, classes);
+            per_pixel.print(std::cout, classes);
         }
     } else if (a[0] == "crop") {   // image.png mask.png left top dim flip_lr flip_ud gain factor off_r off_g off_b prefix: cut_crop_on_host -> prefix.{img,lab,w}.raw
         const auto classes = parse_anno_classes("");

@@ -1,0 +1,308 @@
+// train_tool.cpp -> annonet_amd/lib/annonet_train_hip: the job of the reference's training tool (annonet_train_main.cpp:260-644) on the
+// drop-in headers, built from this repository's own parts:
+//
+//     CropFeeder (N loader threads + LRU cache of decoded full images)  ->  trainer thread (mini-batch assembly, StartTraining)  ->  NetSaver
+//
+// Kept from the reference because they are its observable behaviour: option names and defaults (:276-308), the echo lines (:322-383),
+// the trainer configuration and its ORDER (:396-410: the synchronization file is named before the class count is known), the derived
+// schedule constants (:388-390), the stop rule (:569-577), annonet.dnn written at step 0, every save-interval steps and at the end
+// (:557-565,611-613,634-636), the trainer state file name, exit codes (2: option / in-loop errors, 1: everything else).
+// What differs: by default the loader threads push crop SPECS and the mini-batch is cut on the device from full
+// images resident in HBM; --host-crops cuts crops on the loader threads as the reference does; --devices trains data-parallel from
+// this one process; the large-region filter the reference parses but never calls is applied when asked for.
+#define ANNONET_HIP_NO_DLIB
+#include "annonet_train_host.h"
+
+#include <map>
+
+namespace {
+
+struct TrainSettings {
+    std::string directory, precision = "bf16";
+    double initial_downscaling = 1.0, further_downscaling = 1.0;
+    bool flip_ud = false, flip_lr = false, color_offset = false, quiet_empty_labels = false, host_crops = false;
+    double brightness_probability = 0.0, brightness_sigma = 0.1, noise_stddev = 0.0, class_weight = 0.5, image_weight = 0.5;
+    std::vector<uint16_t> ignored_classes;
+    double region_area = std::numeric_limits<double>::infinity(), region_width = std::numeric_limits<double>::infinity(), region_height = std::numeric_limits<double>::infinity();
+    size_t minibatch = 100, save_interval = 1000, max_steps = 0;
+    bool has_max_steps = false, has_primary_device = false, has_seed = false;
+    double dimension_multiplier = 3.0, width_scaler = 1.0, learning_rate = 0.1, shrink_factor = 0.1, min_learning_rate = 1e-6, relative_length = 2.0;
+    int min_filters = 1, cached_images = 8, primary_device = 0;
+    unsigned loader_threads = std::max(1u, std::thread::hardware_concurrency());
+    std::vector<int> devices;
+    uint64_t seed = 0;
+};
+
+const char* usage_text() {
+    return "Train semantic-segmentation networks using data generated in anno\nUsage:\n  annonet_train_hip [OPTION...] <input-directory>\n\n"
+           "  -d, --initial-downscaling-factor arg   -f, --further-downscaling-factor arg   -i, --input-directory arg\n"
+           "  -u, --allow-flip-upside-down   -l, --allow-flip-left-right   -o, --allow-random-color-offset\n"
+           "      --multiplicative-brightness-change-probability arg   --multiplicative-brightness-change-sigma arg   -n, --noise-level-stddev arg\n"
+           "      --ignore-class arg   --ignore-large-nonzero-regions-by-area|-width|-height arg   --class-weight arg   --image-weight arg\n"
+           "  -b, --minibatch-size arg   --input-dimension-multiplier arg   --net-width-scaler arg   --net-width-min-filter-count arg\n"
+           "      --initial-learning-rate arg   --learning-rate-shrink-factor arg   --min-learning-rate arg   --save-interval arg\n"
+           "  -t, --relative-training-length arg   --max-total-steps arg   -c, --cached-image-count arg   --data-loader-thread-count arg\n"
+           "      --no-empty-label-image-warning   --primary-cuda-device arg\n"
+           "  extensions: --host-crops   --devices 0,1,...   --precision bf16|fp32   --seed arg\n";
+}
+
+TrainSettings read_command_line(int argc, char** argv) {
+    TrainSettings s;
+    using Set = std::function<void(const std::string&)>;
+    auto num = [](double& field) -> Set { return [&field](const std::string& v) { field = std::stod(v); }; };
+    auto count = [](size_t& field) -> Set { return [&field](const std::string& v) { field = std::stoul(v); }; };
+    auto integer = [](int& field) -> Set { return [&field](const std::string& v) { field = std::stoi(v); }; };
+    std::map<std::string, Set> valued = {
+        {"--initial-downscaling-factor", num(s.initial_downscaling)}, {"-d", num(s.initial_downscaling)},
+        {"--further-downscaling-factor", num(s.further_downscaling)}, {"-f", num(s.further_downscaling)},
+        {"--input-directory", [&](const std::string& v) { s.directory = v; }}, {"-i", [&](const std::string& v) { s.directory = v; }},
+        {"--multiplicative-brightness-change-probability", num(s.brightness_probability)}, {"--multiplicative-brightness-change-sigma", num(s.brightness_sigma)},
+        {"--noise-level-stddev", num(s.noise_stddev)}, {"-n", num(s.noise_stddev)},
+        {"--ignore-class", [&](const std::string& v) { s.ignored_classes.push_back((uint16_t)std::stoul(v)); }},
+        {"--ignore-large-nonzero-regions-by-area", num(s.region_area)}, {"--ignore-large-nonzero-regions-by-width", num(s.region_width)},
+        {"--ignore-large-nonzero-regions-by-height", num(s.region_height)},
+        {"--class-weight", num(s.class_weight)}, {"--image-weight", num(s.image_weight)},
+        {"--minibatch-size", count(s.minibatch)}, {"-b", count(s.minibatch)},
+        {"--input-dimension-multiplier", num(s.dimension_multiplier)}, {"--net-width-scaler", num(s.width_scaler)}, {"--net-width-min-filter-count", integer(s.min_filters)},
+        {"--initial-learning-rate", num(s.learning_rate)}, {"--learning-rate-shrink-factor", num(s.shrink_factor)}, {"--min-learning-rate", num(s.min_learning_rate)},
+        {"--save-interval", count(s.save_interval)}, {"--relative-training-length", num(s.relative_length)}, {"-t", num(s.relative_length)},
+        {"--max-total-steps", [&](const std::string& v) { s.max_steps = std::stoul(v); s.has_max_steps = true; }},
+        {"--cached-image-count", integer(s.cached_images)}, {"-c", integer(s.cached_images)},
+        {"--data-loader-thread-count", [&](const std::string& v) { s.loader_threads = (unsigned)std::stoul(v); }},
+        {"--primary-cuda-device", [&](const std::string& v) { s.primary_device = std::stoi(v); s.has_primary_device = true; }},
+        {"--precision", [&](const std::string& v) { s.precision = v; }},
+        {"--seed", [&](const std::string& v) { s.seed = std::stoull(v); s.has_seed = true; }},
+        {"--devices", [&](const std::string& v) { std::stringstream list(v); std::string item; while (std::getline(list, item, ',')) s.devices.push_back(std::stoi(item)); }},
+    };
+    std::map<std::string, bool*> switches = {
+        {"--allow-flip-upside-down", &s.flip_ud}, {"-u", &s.flip_ud}, {"--allow-flip-left-right", &s.flip_lr}, {"-l", &s.flip_lr},
+        {"--allow-random-color-offset", &s.color_offset}, {"-o", &s.color_offset}, {"--no-empty-label-image-warning", &s.quiet_empty_labels}, {"--host-crops", &s.host_crops},
+    };
+    for (int i = 1; i < argc; ++i) {
+        const std::string word = argv[i];
+        if (auto v = valued.find(word); v != valued.end()) {
+            if (i + 1 >= argc) throw std::runtime_error("Option '" + word + "' is missing an argument");
+            v->second(argv[++i]);
+        } else if (auto sw = switches.find(word); sw != switches.end()) *sw->second = true;
+        else if (!word.empty() && word[0] == '-') throw std::runtime_error("Option '" + word + "' does not exist");
+        else if (s.directory.empty()) s.directory = word;
+        else throw std::runtime_error("Unexpected argument " + word);
+    }
+    if (s.directory.empty()) throw std::runtime_error("Option 'input-directory' is required but not present");
+    if (s.precision != "bf16" && s.precision != "fp32") throw std::runtime_error("--precision must be fp32 or bf16");
+    return s;
+}
+
+// anno_classes.json lives in the ROOT of the dataset (annonet_train_main.cpp:236-256); absent = the three default classes
+std::string dataset_classes_json(const std::string& directory) {
+    const std::string path = (std::filesystem::path(directory) / "anno_classes.json").string();
+    if (std::ifstream(path)) return annonet_io::slurp(path);
+    std::cout << "Warning: no anno_classes.json file found in " + directory << std::endl << " --> Using the default anno classes" << std::endl;
+    return "";
+}
+
+// ---- the data side: loader threads over an LRU cache of decoded full images ------------------------------------------------------------
+struct FeedItem {
+    crop made;                              // host path: a finished crop; device path: only made.spec is set
+    std::shared_ptr<sample_type> full;      // device path: the full image the spec refers to (uploaded to HBM on first sight)
+};
+
+class CropFeeder {
+  public:
+    CropFeeder(const TrainSettings& s, const std::vector<image_filenames_type>& files, const std::vector<AnnoClass>& classes, int crop_side, bool specs_only)
+        : settings_(s), files_(files), crop_side_(crop_side), specs_only_(specs_only), queue_(2 * s.minibatch),
+          cache_([this, &classes](const image_filenames_type& names) { return decode(names, classes); }, (size_t)std::max(1, s.cached_images)) {
+        aug_.further_downscaling_factor = s.further_downscaling; aug_.class_weight = s.class_weight; aug_.image_weight = s.image_weight;
+        aug_.allow_flip_left_right = s.flip_lr; aug_.allow_flip_upside_down = s.flip_ud; aug_.allow_random_color_offset = s.color_offset;
+        aug_.multiplicative_brightness_change_probability = s.brightness_probability; aug_.multiplicative_brightness_change_sigma = s.brightness_sigma;
+        aug_.noise_level_stddev = s.noise_stddev;
+        const uint64_t base_seed = s.has_seed ? s.seed : (uint64_t)time(nullptr);   // the reference: time(0) + thread number (:524)
+        for (unsigned i = 0; i < std::max(1u, s.loader_threads); ++i) threads_.emplace_back([this, base_seed, i] { work(base_seed + i); });
+    }
+    ~CropFeeder() { stop(); }
+    void stop() { running_ = false; queue_.disable(); for (auto& t : threads_) if (t.joinable()) t.join(); }
+    FeedItem next() {
+        FeedItem item;
+        if (!queue_.dequeue(item)) throw std::runtime_error("the loader threads stopped");
+        return item;
+    }
+    std::string statistics(size_t resident) const {
+        std::ostringstream o;
+        o << "full images decoded: " << cache_.misses() << ", cache hits: " << cache_.hits() << ", evictions: " << cache_.evictions() << ", images resident in HBM: " << resident;
+        return o.str();
+    }
+
+  private:
+    std::shared_ptr<sample_type> decode(const image_filenames_type& names, const std::vector<AnnoClass>& classes) {   // :504-510 (+ the filters of :414-502)
+        auto sample = std::make_shared<sample_type>(read_sample(names, classes, true, settings_.initial_downscaling));
+        if (sample->error.empty()) {
+            ignore_classes_to_ignore(*sample, settings_.ignored_classes);
+            if (std::isfinite(settings_.region_area) || std::isfinite(settings_.region_width) || std::isfinite(settings_.region_height))
+                ignore_large_nonzero_regions(*sample, settings_.region_area, settings_.region_width, settings_.region_height);
+        }
+        return sample;
+    }
+    void work(uint64_t seed) {   // one loader thread: pick an image, draw a crop from it, queue it (:516-547)
+        host_rand rnd(seed);
+        while (running_) {
+            FeedItem item;
+            const auto& names = files_[rnd.get_random_32bit_number() % files_.size()];
+            const std::shared_ptr<sample_type> full = cache_(names);
+            if (!full->error.empty()) item.made.error = full->error;
+            else if (full->labeled_points_by_class.empty()) item.made.warning = "Warning: no labeled points in " + full->image_filenames.label_filename;
+            else if (specs_only_) {
+                item.made.spec = draw_crop_spec(crop_side_, *full, -1, rnd, aug_);
+                item.made.is_spec = true;
+                item.full = full;
+            } else {
+                try { randomly_crop_image(crop_side_, *full, item.made, rnd, aug_); }
+                catch (std::exception& e) { item.made.error = e.what(); }
+            }
+            if (!queue_.enqueue(std::move(item))) break;
+        }
+    }
+
+    const TrainSettings& settings_;
+    const std::vector<image_filenames_type>& files_;
+    const int crop_side_;
+    const bool specs_only_;
+    augmentation_options aug_;
+    anh_host::pipe<FeedItem> queue_;
+    shared_lru_cache<image_filenames_type, std::shared_ptr<sample_type>, image_filenames_hash> cache_;
+    std::atomic<bool> running_{true};
+    std::vector<std::thread> threads_;
+};
+
+// annonet.dnn: (anno classes json, total downscaling factor, serialized RuntimeNet) in dlib's stream framing (:557-565)
+void save_inference_net(NetPimpl::TrainingNet& trainer, const std::string& classes_json, double downscaling) {
+    const NetPimpl::RuntimeNet snapshot = trainer.GetRuntimeNet();
+    std::ostringstream serialized;
+    snapshot.Serialize(serialized);
+    std::cout << "saving network" << std::endl;
+    const std::string blob = serialized.str();
+    void* file = nullptr; size_t file_size = 0;
+    NetPimpl::check(anh_dnn_envelope_pack(classes_json.data(), classes_json.size(), downscaling, blob.data(), blob.size(), &file, &file_size));
+    std::ofstream out("annonet.dnn", std::ios::binary | std::ios::trunc);
+    out.write(static_cast<const char*>(file), (std::streamsize)file_size);
+    anh_free(file);
+    if (!out) throw std::runtime_error("Unable to write annonet.dnn");
+}
+
+int run(const TrainSettings& s) {
+    const double relative_length = std::max(0.01, s.relative_length);
+    std::cout << "Allow flipping input images upside down = " << (s.flip_ud ? "yes" : "no") << std::endl;
+    std::cout << "Minibatch size = " << s.minibatch << std::endl;
+    std::cout << "Net width scaler = " << s.width_scaler << ", min filter count = " << s.min_filters << std::endl;
+    std::cout << "Initial learning rate = " << s.learning_rate << std::endl;
+    std::cout << "Learning rate shrink factor = " << s.shrink_factor << std::endl;
+    std::cout << "Min learning rate = " << s.min_learning_rate << std::endl;
+    std::cout << "Save interval = " << s.save_interval << std::endl;
+    std::cout << "Relative training length = " << relative_length << std::endl;
+    std::cout << "Cached image count = " << s.cached_images << std::endl;
+    std::cout << "Data loader thread count = " << std::max(1u, s.loader_threads) << std::endl;
+    if (!s.ignored_classes.empty()) {
+        std::cout << "Classes to ignore =";
+        for (uint16_t c : s.ignored_classes) std::cout << " " << c;
+        std::cout << std::endl;
+    }
+    // crop side: the receptive field times the multiplier, rounded up to a side the net accepts (:376-383)
+    const int receptive_field = NetPimpl::TrainingNet::GetRequiredInputDimension();
+    const int requested = (int)std::round(s.dimension_multiplier * receptive_field);
+    const int crop_side = NetPimpl::RuntimeNet::GetRecommendedInputDimension(requested);
+    std::cout << "Required input dimension = " << receptive_field << std::endl << "Requested input dimension = " << requested << std::endl << "Actual input dimension = " << crop_side << std::endl;
+
+    const std::string classes_json = dataset_classes_json(s.directory);
+    const std::vector<AnnoClass> classes = parse_anno_classes(classes_json);
+
+    if (s.has_primary_device) NetPimpl::check(anh_set_device(s.primary_device));   // dlib::cuda::set_device (:392-394)
+    if (!s.devices.empty()) NetPimpl::SetDevices(s.devices);
+    const bool device_crops = !s.host_crops && s.devices.size() <= 1;
+    std::cout << "Mini-batches are cut " << (device_crops ? "on the device from HBM-resident full images" : "on the host by the loader threads") << std::endl;
+
+    NetPimpl::TrainingNet trainer;
+    if (s.precision == "fp32") NetPimpl::check(anh_trainer_set_precision(trainer.handle(), ANH_FP32));
+    if (s.has_seed) NetPimpl::check(anh_trainer_set_seed(trainer.handle(), s.seed));
+    trainer.Initialize();                                                               // the reference's order (:400-410)
+    trainer.SetNetWidth(s.width_scaler, s.min_filters);
+    trainer.SetSynchronizationFile("annonet_trainer_state_file.dat", std::chrono::seconds(10 * 60));
+    trainer.BeVerbose();
+    trainer.SetClassCount(classes.size());
+    trainer.SetLearningRate(s.learning_rate);
+    trainer.SetLearningRateShrinkFactor(s.shrink_factor);
+    trainer.SetIterationsWithoutProgressThreshold((unsigned long)std::round(relative_length * 2000));   // :388-390
+    trainer.SetPreviousLossValuesDumpAmount((unsigned long)std::round(relative_length * 400));
+    trainer.SetAllBatchNormalizationRunningStatsWindowSizes((unsigned long)std::round(relative_length * 100));
+
+    std::cout << "\nSCANNING ANNO DATASET\n" << std::endl;
+    const std::vector<image_filenames_type> files = find_image_files(s.directory, true);
+    std::cout << "images in dataset: " << files.size() << std::endl;
+    if (files.empty()) { std::cout << "Didn't find an anno dataset. " << std::endl; return 1; }
+    std::cout << std::endl << "Now training..." << std::endl;
+
+    CropFeeder feeder(s, files, classes, crop_side, device_crops);
+    NetPimpl::Dataset hbm_images;                                    // device path: full images, uploaded once each
+    std::unordered_map<std::string, int> hbm_index;
+    std::set<std::string> warned;
+    std::vector<NetPimpl::input_type> images;
+    std::vector<NetPimpl::training_label_type> labels;
+    std::vector<anh_crop_spec> specs;
+    size_t step = 0;
+    const double total_downscaling = s.initial_downscaling * s.further_downscaling;
+    try {
+        while (trainer.GetLearningRate() >= s.min_learning_rate && !(s.has_max_steps && step >= s.max_steps)) {   // :569-577,583
+            images.clear(); labels.clear(); specs.clear();
+            while ((device_crops ? specs.size() : images.size()) < s.minibatch) {
+                FeedItem item = feeder.next();
+                if (!item.made.error.empty()) throw std::runtime_error(item.made.error);
+                if (!item.made.warning.empty()) {
+                    if (!s.quiet_empty_labels && warned.insert(item.made.warning).second) std::cout << item.made.warning << std::endl;
+                    continue;
+                }
+                if (item.made.is_spec) {
+                    const std::string& key = item.full->image_filenames.image_filename;
+                    auto at = hbm_index.find(key);
+                    if (at == hbm_index.end()) at = hbm_index.emplace(key, hbm_images.Add(item.full->input_image, item.full->label_image)).first;
+                    item.made.spec.image = at->second;
+                    specs.push_back(item.made.spec);
+                } else {
+                    images.push_back(std::move(item.made.input_image));
+                    labels.push_back(std::move(item.made.label_image));
+                }
+            }
+            if (device_crops) trainer.StartTrainingOnCrops(hbm_images, specs, crop_side, s.class_weight, s.image_weight);
+            else trainer.StartTraining(images, labels);
+            if (step++ % s.save_interval == 0) save_inference_net(trainer, classes_json, total_downscaling);
+        }
+    } catch (std::exception& e) {   // in-loop errors: print and leave with 2 (:616-620)
+        std::cout << e.what() << std::endl;
+        feeder.stop();
+        std::exit(2);
+    }
+    feeder.stop();
+    save_inference_net(trainer, classes_json, total_downscaling);
+    std::cout << "steps: " << step << ", " << feeder.statistics(hbm_index.size()) << std::endl;
+    return 0;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    if (argc == 1) {
+        std::cout << "To run this program you need data annotated using the anno program." << std::endl << std::endl
+                  << "You call this program like this: " << std::endl << "./annonet_train_hip /path/to/anno/data" << std::endl;
+        return 1;
+    }
+    TrainSettings settings;
+    try {
+        settings = read_command_line(argc, argv);
+        std::cout << "Input directory = " << settings.directory << std::endl;
+        std::cout << "Initial downscaling factor = " << settings.initial_downscaling << std::endl;
+        std::cout << "Further downscaling factor = " << settings.further_downscaling << std::endl;
+        if (settings.initial_downscaling <= 0.0 || settings.further_downscaling <= 0.0) throw std::runtime_error("The downscaling factors have to be strictly positive.");
+    } catch (std::exception& e) {
+        std::cerr << e.what() << std::endl << std::endl << usage_text() << std::endl;
+        return 2;
+    }
+    try { return run(settings); }
+    catch (std::exception& e) { std::cout << e.what() << std::endl; return 1; }
+}

@@ -1,4 +1,4 @@
-"""annonet_infer_hip (annonet_amd/host/annonet_infer_main.cpp = the reference's annonet_infer_main.cpp:283-538 on the drop-in
+"""annonet_infer_hip (annonet_amd/host/infer_tool.cpp = the job of the reference's annonet_infer_main.cpp:283-538 on the drop-in
 headers) end to end on a synthetic anno directory: option parsing, annonet.dnn envelope, reader / writer pools, the tool's
 timing lines, result PNGs and both confusion matrices — against a numpy restatement fed with the label maps that the Python
 mirror of annonet_infer() produces from the same net in the bit-exact fp32 mode."""

@@ -364,38 +364,65 @@ def test_full_size_training_step_batch32_227():
         assert cos > 0.97, (L.cin, L.cout, cos)
 
 
-def test_large_image_tiled_inference_properties():
-    """BASELINE config [2] shape class (a multi-tile image with 1024^2 tiles), through size-independent properties:
-    fp32 labels bit-exact against the oracle on a sampled tile window, determinism, and label agreement bf16 vs fp32."""
-    o, net = pair(2, 3, 3, 0.25, 4, aa.ANH_FP32, seed=13)
+@pytest.mark.parametrize("H,W,scaler,min_filters", [(1500, 2100, 0.25, 4), (4096, 4096, 1.0, 1)])
+def test_large_image_tiled_inference_properties(H, W, scaler, min_filters):
+    """BASELINE config [2]: tiled sliding-window inference with 1024^2 tiles — a ragged multi-tile image on a narrow net, and THE
+    config itself (4096 x 4096, the benchmark net: levels 2, width 1.0, K = 3) — through size-independent properties: fp32 labels
+    and planes bit-exact against the oracle on windows deep inside several tiles, determinism, the device-resident entry point
+    equal to the host one, a two-replica run equal except at near-ties, and label agreement bf16 vs fp32."""
+    o, net = pair(2, 3, 3, scaler, min_filters, aa.ANH_FP32, seed=13)
     rng = np.random.default_rng(8)
-    H, W = 1500, 2100
     img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
     ov = o.required_input_dim()
     tp = aa.tiling.parameters(1024, 1024, ov, ov)
     labels, blended = aa.annonet_infer(net, img, tiling_parameters=tp, want_blended=True)
-    labels2 = aa.annonet_infer(net, img, tiling_parameters=tp)
-    np.testing.assert_array_equal(labels, labels2)                       # deterministic
+    labels2 = aa.annonet_infer(net, img, tiling_parameters=tp)            # the streamed host path (strips up, label rows down)
+    np.testing.assert_array_equal(labels, labels2)                       # deterministic, and both host paths agree
     assert labels.max() < 3 and blended.shape == (3, H, W)
-    # a pixel deep inside a tile's unique rect sees only real image data: its logits equal a plain forward of a crop around it
     tiles = aa.tiling.get_tiles(W, H, tp)
-    (fl, ft, fr, fb), (ul, ut, ur, ub) = tiles[0]
-    # the net input window of that tile (annonet_infer.cpp:46-66); the net is translation-equivariant only for shifts that
-    # are multiples of 2^levels (stride-2 grid phase), so the comparison crop is aligned to the window modulo 4
-    fw, fh = fr - fl + 1, fb - ft + 1
-    win_left = fl + fw // 2 - o.recommended_input_dim(fw) // 2
-    win_top = ft + fh // 2 - o.recommended_input_dim(fh) // 2
-    d = o.recommended_input_dim(2 * ov + 41)
-    cy, cx = (ut + ub) // 2, (ul + ur) // 2
-    top = win_top + ((cy - d // 2 - win_top) // 4) * 4
-    left = win_left + ((cx - d // 2 - win_left) // 4) * 4
-    crop = img[top:top + d, left:left + d]
-    want = o.forward(crop[None])[0]
-    m = ov  # margin: receptive field
-    np.testing.assert_array_equal(blended[:, top + m:top + d - m, left + m:left + d - m], want[:, m:d - m, m:d - m])
-    np.testing.assert_array_equal(labels[top + m:top + d - m, left + m:left + d - m], want[:, m:d - m, m:d - m].argmax(0))
+    assert len(tiles) == (6 if H == 1500 else 25)
+    # a pixel deep inside a tile's unique rect sees only real image data: its logits equal a plain forward of a crop around it
+    picks = [0] if H == 1500 else [0, 12, 24, 9]      # corner, centre, opposite corner and an edge tile of the 5 x 5 grid
+    for ti in picks:
+        (fl, ft, fr, fb), (ul, ut, ur, ub) = tiles[ti]
+        # the net input window of that tile (annonet_infer.cpp:46-66); the net is translation-equivariant only for shifts that
+        # are multiples of 2^levels (stride-2 grid phase), so the comparison crop is aligned to the window modulo 4
+        fw, fh = fr - fl + 1, fb - ft + 1
+        win_left = fl + fw // 2 - o.recommended_input_dim(fw) // 2
+        win_top = ft + fh // 2 - o.recommended_input_dim(fh) // 2
+        d = o.recommended_input_dim(2 * ov + 41)
+        cy, cx = (ut + ub) // 2, (ul + ur) // 2
+        top = win_top + ((cy - d // 2 - win_top) // 4) * 4
+        left = win_left + ((cx - d // 2 - win_left) // 4) * 4
+        crop = img[top:top + d, left:left + d]
+        want = o.forward(crop[None])[0]
+        m = ov  # margin: receptive field
+        np.testing.assert_array_equal(blended[:, top + m:top + d - m, left + m:left + d - m], want[:, m:d - m, m:d - m])
+        np.testing.assert_array_equal(labels[top + m:top + d - m, left + m:left + d - m], want[:, m:d - m, m:d - m].argmax(0))
+    assert np.isfinite(blended).all()
+    # the device-resident entry point (image, planes and label map in HBM) equals the host one
+    import torch
+    dev = torch.device("cuda:0")
+    d_img = torch.from_numpy(img).to(dev)
+    d_lab = torch.zeros((H, W), dtype=torch.int16, device=dev)
+    d_pl = torch.zeros((3, H, W), dtype=torch.float32, device=dev)
+    aa.annonet_infer_device(net, d_img.data_ptr(), H, W, d_lab.data_ptr(), d_pl.data_ptr(), tiling_parameters=tp)
+    net.synchronize()
+    np.testing.assert_array_equal(d_lab.cpu().numpy().view(np.uint16), labels)
+    np.testing.assert_array_equal(d_pl.cpu().numpy(), blended)
+    del d_img, d_lab, d_pl
+    # two replicas (device 0 twice on this box): one host label map, equal except where four tiles meet and the sum order differs
+    p, r = net.get_params()
+    aa.set_devices([0, 0])
+    try:
+        net2 = aa.RuntimeNet(aa.net_config(2, 3, 3, scaler, min_filters, aa.ANH_FP32))
+        net2.set_params(p, r)
+        sharded = aa.annonet_infer(net2, img, tiling_parameters=tp)
+    finally:
+        aa.set_devices([])
+    assert (sharded != labels).mean() < 1e-4
     # bf16 mode: label agreement
-    _, net16 = pair(2, 3, 3, 0.25, 4, aa.ANH_BF16, seed=13)
+    _, net16 = pair(2, 3, 3, scaler, min_filters, aa.ANH_BF16, seed=13)
     l16 = aa.annonet_infer(net16, img, tiling_parameters=tp)
     assert (l16 == labels).mean() > 0.97
 

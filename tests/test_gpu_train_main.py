@@ -1,4 +1,4 @@
-"""annonet_train_hip (annonet_amd/host/annonet_train_main.cpp = the reference's annonet_train_main.cpp:260-644 on the drop-in headers)
+"""annonet_train_hip (annonet_amd/host/train_tool.cpp = the job of the reference's annonet_train_main.cpp:260-644 on the drop-in headers)
 end to end on a synthetic anno directory: option echo, dataset scan, LRU cache + loader threads, device-cut mini-batches (default)
 and host-cut mini-batches (--host-crops, the reference's data path), annonet.dnn + trainer state file, resume, and the two-replica
 data-parallel mode.  The saved net is then read back by the inference tool."""

@@ -1,0 +1,19 @@
+#!/bin/bash
+# Collects the round's measurement set on ONE MI355X box into gpurun_out/prof (copy what is judged into profiles/ with
+# tools/publish_profiles.py): the bench line, rocprofv3 kernel stats + trace of the same command, the two HBM counter passes, one SQ
+# counter pass, and the inference lines.  Counter passes run on their own (never with a trace domain other than --kernel-trace).
+#   usage (on the GPU box): bash tools/collect_profiles.sh
+set -e
+out=gpurun_out/prof
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
+python3 bench.py --dump-launch-order $out/launch_order.json > $out/bench.json 2> $out/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline > $out/bench_under_rocprof.json 2> $out/kt.err
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline > /dev/null 2> $out/fetch.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline > /dev/null 2> $out/write.err
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d $out/sq -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2> $out/sq.err
+python3 bench.py --mode infer > $out/bench_infer_4096_bf16.json 2> $out/infer.err
+python3 bench.py --mode infer --precision fp32 --steps 5 --warmup 1 --no-cpu-baseline > $out/bench_infer_4096_fp32.json 2>> $out/infer.err
+python3 bench.py --mode infer --image-side 16384 --steps 5 --warmup 1 --no-cpu-baseline > $out/bench_infer_16384_bf16.json 2>> $out/infer.err
+ANH_CONCURRENT_WGRAD=0 rocprofv3 --kernel-trace --output-format csv -d $out/kt1 -- python3 bench.py --steps 40 --warmup 10 --no-cpu-baseline > $out/bench_one_stream.json 2> $out/kt1.err
+echo collected; du -sh $out
