@@ -114,6 +114,43 @@ class OverlapExchange:
         self.unpack(blended, packed)
 
 
+class LabelGather:
+    """ONE label map on one rank from the ranks' shares of a sharded annonet_infer().  After the overlap exchange a rank's labels
+    are right exactly where ITS tiles cover the image (elsewhere its planes hold nothing); two ranks that share a pixel hold the
+    same sums there, hence the same label.  So every rank codes its covered pixels as label + 1 (0 = "not mine", 255 = the
+    all-NaN label 65535) and ONE reduce(MAX) — a single collective of H x W bytes — assembles the map on `dst`."""
+
+    def __init__(self, tiles, world_size, rank, width, height, device, classes):
+        import torch
+        if classes > 253:
+            raise ValueError("LabelGather codes labels in one byte: at most 253 classes")
+        mask = np.zeros((height, width), dtype=bool)
+        for (full, _) in shard_tiles(tiles, rank, world_size):
+            l, t, r, b = max(full[0], 0), max(full[1], 0), min(full[2], width - 1), min(full[3], height - 1)
+            if l <= r and t <= b:
+                mask[t:b + 1, l:r + 1] = True
+        self.mask = torch.from_numpy(mask).to(device)
+
+    def code(self, labels):
+        import torch
+        wide = labels.to(torch.int32) & 0xFFFF
+        coded = torch.where(wide == 65535, torch.full_like(wide, 255), wide + 1)
+        return torch.where(self.mask, coded, torch.zeros_like(coded)).to(torch.uint8)
+
+    @staticmethod
+    def decode(coded):
+        import torch
+        wide = coded.to(torch.int32)
+        return torch.where(wide == 255, torch.full_like(wide, 65535), wide - 1).to(torch.int16)   # (u16 bit pattern in an int16 tensor)
+
+    def run(self, labels, group=None, dst=0):
+        """labels: this rank's [H, W] int16 map -> the assembled map on rank `dst` (None elsewhere)"""
+        import torch.distributed as dist
+        coded = self.code(labels)
+        dist.reduce(coded, dst=dst, op=dist.ReduceOp.MAX, group=group)
+        return self.decode(coded) if dist.get_rank(group) == dst else None
+
+
 def sharded_infer(net, image, labels, blended, tiles, rank, world_size, exchange, tiling_parameters=None, gains=None, group=None, stream=None):
     """annonet_infer() with the tile list sharded over the ranks of a job (image, labels [H, W] int16 and blended [K, H, W]
     float32 are torch tensors on this rank's GPU; `exchange` = OverlapExchange(tiles, world_size, W, H, device)).

@@ -320,11 +320,18 @@ def bench_infer(args, aa, aad, torch, dist, prec, rank, local_rank, world, use_d
     tiles = aa.tiling.get_tiles(side, side, tp)
     mine = aad.shard_tiles(tiles, rank, world)
     exchange = aad.OverlapExchange(tiles, world, side, side, dev)   # the pixels where tiles of different ranks overlap (none at world 1)
+    gather = aad.LabelGather(tiles, world, rank, side, side, dev, CLASSES) if world > 1 else None   # ONE label map on rank 0
     ranks_seen, devices = dist_facts(torch, dist, dev, local_rank, world, use_dist)
 
     def run(to_host=False):
         # blend this rank's tiles -> all-reduce the plane sums of the cross-rank overlaps -> label this rank's rows
         row0, row1 = aad.sharded_infer(net, image, labels, blended, tiles, rank, world, exchange, tiling_parameters=tp, stream=net_stream)
+        if gather is not None:   # N > 1: the result of annonet_infer() is one map — reduce the ranks' shares onto rank 0
+            with torch.cuda.stream(net_stream):
+                whole = gather.run(labels)
+            if whole is not None:
+                labels.copy_(whole)
+                row0, row1 = 0, side
         if to_host and row1 > row0:   # D2H on torch's own stream, ordered after the net's stream and before its next pass
             cur = torch.cuda.current_stream()
             cur.wait_stream(net_stream)
@@ -388,7 +395,7 @@ def bench_infer(args, aa, aad, torch, dist, prec, rank, local_rank, world, use_d
                "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline_infer(aa, cfg, ov)}
         print(json.dumps(out), flush=True)
     torch.cuda.synchronize()
-    del host_labels, exchange, net_stream   # torch-side objects that refer to the net's stream go before the net
+    del host_labels, exchange, gather, net_stream   # torch-side objects that refer to the net's stream go before the net
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

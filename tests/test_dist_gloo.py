@@ -149,6 +149,39 @@ def test_two_rank_overlap_exchange_over_gloo():
     np.testing.assert_array_equal(out["after"], want)
 
 
+def gather_worker(rank, world, port, out):
+    """The last step of a multi-rank annonet_infer(): every rank holds the right labels where its own tiles cover the image and
+    arbitrary values elsewhere; LabelGather.run leaves the ONE complete map on rank 0 (incl. the all-NaN label 65535)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    W, H, K = 301, 230, 5
+    tiles = orc.get_tiles(W, H, 96, 112, 19, 19)
+    truth = np.random.default_rng(99).integers(0, K, size=(H, W)).astype(np.uint16)
+    truth[::17, ::13] = 65535
+    mine = np.zeros((H, W), dtype=bool)
+    for (full, _) in aad.shard_tiles(tiles, rank, world):
+        mine[max(full[1], 0):min(full[3], H - 1) + 1, max(full[0], 0):min(full[2], W - 1) + 1] = True
+    held = np.where(mine, truth, np.uint16(K - 1 - rank % K))          # wrong on purpose outside this rank's tiles
+    gather = aad.LabelGather(tiles, world, rank, W, H, torch.device("cpu"), K)
+    whole = gather.run(torch.from_numpy(held.view(np.int16).copy()))
+    assert (whole is None) == (rank != 0)
+    if rank == 0:
+        out["whole"] = whole.numpy().view(np.uint16).copy()
+        out["truth"] = truth
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_three_rank_label_gather_over_gloo():
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(gather_worker, args=(3, free_port(), out), nprocs=3, join=True)
+    np.testing.assert_array_equal(out["whole"], out["truth"])
+    with pytest.raises(ValueError):
+        aad.LabelGather([], 1, 0, 4, 4, torch.device("cpu"), 300)
+
+
 def test_cross_rank_overlaps_are_exactly_the_pixels_shared_between_ranks():
     """The exchange step of sharded inference moves the plane sums of these pixels and no others."""
     W, H = 301, 230
