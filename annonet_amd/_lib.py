@@ -11,7 +11,7 @@ import subprocess
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libannonet_hip.so")
+LIB_PATH = os.environ.get("ANH_LIBRARY") or os.path.join(_HERE, "lib", "libannonet_hip.so")   # ANH_LIBRARY: an instrumented build (tools/ws_phase_profile.py)
 CSRC = os.path.join(_HERE, "csrc")
 
 ANH_FP32, ANH_BF16 = 0, 1

@@ -1109,41 +1109,44 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
     const int stat_mode = fuse_stats ? 1 : fuse_bnred ? 2 : 0;
     float* bnc = tab + c_red * (KIND == SRC_BNBWD ? 7 : 4);            // [scale | shift | mean | invstd][C_OUT] of this workgroup's channels
 
-    if (KIND != SRC_RAW) {  // SRC_BNBWD: [scale | shift | mean | invstd | coef0 | coef1 | coef2][c_red]
-        for (int i = threadIdx.x; i < c_red; i += 512) {
-            tab[i] = a.src.a_scale[i];
-            tab[c_red + i] = a.src.a_shift[i];
-            if (KIND == SRC_BNBWD) {
-                tab[2 * c_red + i] = a.src.bn_mean[i];
-                tab[3 * c_red + i] = a.src.bn_invstd[i];
-                tab[4 * c_red + i] = a.src.bn_coef[i];
-                tab[5 * c_red + i] = a.src.bn_coef[c_red + i];
-                tab[6 * c_red + i] = a.src.bn_coef[2 * c_red + i];
-            } else {
-                tab[2 * c_red + i] = KIND == SRC_ACT2 ? a.src.b_scale[i] : 0.f;
-                tab[3 * c_red + i] = KIND == SRC_ACT2 ? a.src.b_shift[i] : 0.f;
+    int tile = blockIdx.x, slab = 0, it = 0;
+    auto init_tables = [&]() __attribute__((always_inline)) {   // every thread of the workgroup, from either branch below
+        if (KIND != SRC_RAW) {  // SRC_BNBWD: [scale | shift | mean | invstd | coef0 | coef1 | coef2][c_red]
+            for (int i = threadIdx.x; i < c_red; i += 512) {
+                tab[i] = a.src.a_scale[i];
+                tab[c_red + i] = a.src.a_shift[i];
+                if (KIND == SRC_BNBWD) {
+                    tab[2 * c_red + i] = a.src.bn_mean[i];
+                    tab[3 * c_red + i] = a.src.bn_invstd[i];
+                    tab[4 * c_red + i] = a.src.bn_coef[i];
+                    tab[5 * c_red + i] = a.src.bn_coef[c_red + i];
+                    tab[6 * c_red + i] = a.src.bn_coef[2 * c_red + i];
+                } else {
+                    tab[2 * c_red + i] = KIND == SRC_ACT2 ? a.src.b_scale[i] : 0.f;
+                    tab[3 * c_red + i] = KIND == SRC_ACT2 ? a.src.b_shift[i] : 0.f;
+                }
             }
         }
-    }
-    if (fuse_bnred) {
-        for (int i = threadIdx.x; i < C_OUT; i += 512) {
-            bnc[i] = a.bnred_scale[co_base + i];
-            bnc[C_OUT + i] = a.bnred_shift[co_base + i];
-            bnc[2 * C_OUT + i] = a.bnred_mean[co_base + i];
-            bnc[3 * C_OUT + i] = a.bnred_invstd[co_base + i];
+        if (fuse_bnred) {
+            for (int i = threadIdx.x; i < C_OUT; i += 512) {
+                bnc[i] = a.bnred_scale[co_base + i];
+                bnc[C_OUT + i] = a.bnred_shift[co_base + i];
+                bnc[2 * C_OUT + i] = a.bnred_mean[co_base + i];
+                bnc[3 * C_OUT + i] = a.bnred_invstd[co_base + i];
+            }
         }
-    }
-    __syncthreads();
-
-    int tile = blockIdx.x, slab = 0, it = 0;
+        __syncthreads();
+    };
     if (producer) {
+        // The producers request their FIRST patch and the filter blocks before the tables are loaded and the workgroup meets:
+        // those round trips overlap instead of adding up.
         const bf16* wsrc = reinterpret_cast<const bf16*>(a.w_bf16);
         const bf16* xa = reinterpret_cast<const bf16*>(a.src.a);
         const bf16* xb = reinterpret_cast<const bf16*>(a.src.b);
         const size_t plane = (size_t)H * W * c_red;  // < 2^31 elements (host check)
         // ---- staging geometry, fixed per thread: patch chunk jj = record (tid >> 2) + 64 jj ----
         int pgeo[NP], pdst[NP];
-#pragma unroll
+    #pragma unroll
         for (int jj = 0; jj < NP; ++jj) {
             const int rec = min((tid >> 2) + 64 * jj, G::RECS - 1);
             int py, px, key;
@@ -1153,7 +1156,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
         }
         // filter chunk j = record (tid >> 2) + 64 j = (tap slot, co); slot t holds tap t, or 8 - t for mirrored taps
         int wsrc_off[NW], wdst[NW];
-#pragma unroll
+    #pragma unroll
         for (int j = 0; j < NW; ++j) {
             const int rec = min((tid >> 2) + 64 * j, 9 * C_OUT - 1);
             const int tl = rec / C_OUT, co = rec - tl * C_OUT;
@@ -1161,100 +1164,141 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
             wsrc_off[j] = (tap * a.c_out + co_base + co) * c_red + c16 * 8;
             wdst[j] = rec * 64 + ((c16 ^ ((co >> 2) & 3)) << 4);   // within a filter slab
         }
-        RawChunk<KIND> praw[NP];
+        // ---- two items in flight.  Item k lives in register set k & 1; the loads of item k + 2 are issued right after item k is
+        // committed, so a load has a whole item period to arrive instead of the hand-over barrier alone (the producers used to
+        // spend their commit phase waiting for loads issued one barrier earlier: r02_sq_counters, SQ_WAIT_ANY 40-55 %) ----
+        // The filter slab of the NEXT item is fetched one item ahead into one shared register set: it comes from L2 (every workgroup
+        // reads the same filter), and a second set would cost 36 VGPRs at 64 output channels.  Kinds with two operands per chunk
+        // and many chunks (or the seven-table bn-backward prologue) keep ONE patch set: two would spill.
+    #ifndef ANH_WS_DEEP2
+    #define ANH_WS_DEEP2 0
+    #endif
+        constexpr bool DEEP2 = ANH_WS_DEEP2 && KIND != SRC_BNBWD && !(KIND == SRC_ACT2 && NP > 6);
         u32x4 wraw[NW];  // a native vector type: hipcc keeps a HIP uint4 that is only copied (never unpacked) in scratch
-        unsigned pok = 0;
-        // SRC_BNBWD with ConvArgs::dy_out: the dy chunks this thread computes for the CORE pixels of its patch also go to memory
-        // (first channel group only: the groups stage the same patches) — poff / pcore / dyo describe the fetched item
+        struct Fetched {
+            RawChunk<KIND> praw[NP];
+            unsigned pok;
+            // SRC_BNBWD with ConvArgs::dy_out: the dy chunks this thread computes for the CORE pixels of its patch also go to memory
+            // (first channel group only: the groups stage the same patches) — poff / pcore / dyo describe the fetched item
+            int poff[KIND == SRC_BNBWD ? NP : 1];
+            unsigned pcore;
+            bf16* dyo;
+        };
+        Fetched R0, R1;
         const bool write_dy = KIND == SRC_BNBWD && a.dy_out != nullptr && blockIdx.y == 0;
-        int poff[KIND == SRC_BNBWD ? NP : 1];
-        unsigned pcore = 0;
-        bf16* dyo = nullptr;
-        auto fetch = [&](int tile_, int slab_, bool with_w) __attribute__((always_inline)) {
-            const int tx = tile_ % tiles_x, ty = (tile_ / tiles_x) % tiles_y, n = tile_ / (tiles_x * tiles_y);
-            const int x0 = G::in_x0(tx), y0 = G::in_y0(ty);
-            const bf16* pa = xa + (size_t)n * plane;
-            const bf16* pb = (KIND == SRC_ACT2 || KIND == SRC_BNBWD) ? xb + (size_t)n * plane : nullptr;
-            const int cc = slab_ * 32;
-            pok = 0;
-            if (KIND == SRC_BNBWD) { pcore = 0; dyo = reinterpret_cast<bf16*>(a.dy_out) + (size_t)n * plane; }
-#pragma unroll
+        // the fetch cursor runs two items ahead of the commits.  Its tile coordinates advance incrementally (no division per item)
+        // and the chunk offsets / validity bits of its tile are computed once per tile, not once per (tile, slab) item.
+        const int gstep = (int)gridDim.x, per_img = tiles_x * tiles_y;
+        const int step_x = gstep % tiles_x, step_y = (gstep / tiles_x) % tiles_y, step_n = gstep / per_img;
+        int ftile = blockIdx.x, fslab = 0;
+        int ftx = ftile % tiles_x, fty = (ftile / tiles_x) % tiles_y, fn = ftile / per_img;
+        int foff[NP];
+        unsigned fpok = 0, fpcore = 0;
+        auto enter_tile = [&]() __attribute__((always_inline)) {
+            const int x0 = G::in_x0(ftx), y0 = G::in_y0(fty);
+            fpok = 0; fpcore = 0;
+    #pragma unroll
             for (int jj = 0; jj < NP; ++jj) {
                 const int iy = y0 + (pgeo[jj] & 255), ix = x0 + (pgeo[jj] >> 8);
                 const int cy = min(max(iy, 0), H - 1), cx = min(max(ix, 0), W - 1);
-                const int off = (cy * W + cx) * c_red + cc + c16 * 8;
-                praw[jj] = side_load_at<KIND>(pa, pb, off);
-                pok |= ((iy == cy && ix == cx) ? 1u : 0u) << jj;
-                if (KIND == SRC_BNBWD) {
-                    poff[jj] = off;
-                    pcore |= (G::core(pgeo[jj] & 255, pgeo[jj] >> 8, ty == tiles_y - 1, tx == tiles_x - 1) ? 1u : 0u) << jj;
-                }
-            }
-            if (with_w) {
-#pragma unroll
-                for (int j = 0; j < NW; ++j) wraw[j] = *reinterpret_cast<const u32x4*>(wsrc + wsrc_off[j] + cc);
+                foff[jj] = (cy * W + cx) * c_red + c16 * 8;
+                fpok |= ((iy == cy && ix == cx) ? 1u : 0u) << jj;
+                if (KIND == SRC_BNBWD) fpcore |= (G::core(pgeo[jj] & 255, pgeo[jj] >> 8, fty == tiles_y - 1, ftx == tiles_x - 1) ? 1u : 0u) << jj;
             }
         };
+        auto fetch = [&](Fetched& R) __attribute__((always_inline)) {
+            const bf16* pa = xa + (size_t)fn * plane;
+            const bf16* pb = (KIND == SRC_ACT2 || KIND == SRC_BNBWD) ? xb + (size_t)fn * plane : nullptr;
+            const int cc = fslab * 32;
+            R.pok = fpok;
+            if (KIND == SRC_BNBWD) { R.pcore = fpcore; R.dyo = reinterpret_cast<bf16*>(a.dy_out) + (size_t)fn * plane; }
+    #pragma unroll
+            for (int jj = 0; jj < NP; ++jj) {
+                R.praw[jj] = side_load_at<KIND>(pa, pb, foff[jj] + cc);
+                if (KIND == SRC_BNBWD) R.poff[jj] = foff[jj] + cc;
+            }
+            if (++fslab == n_slabs) {   // cursor -> the workgroup's next tile
+                fslab = 0; ftile += gstep;
+                ftx += step_x; if (ftx >= tiles_x) { ftx -= tiles_x; ++fty; }
+                fty += step_y; if (fty >= tiles_y) { fty -= tiles_y; ++fn; }
+                fn += step_n;
+                if (ftile < n_tiles) enter_tile();
+            }
+        };
+        auto fetch_w = [&](int slab_) __attribute__((always_inline)) {
+    #pragma unroll
+            for (int j = 0; j < NW; ++j) wraw[j] = *reinterpret_cast<const u32x4*>(wsrc + wsrc_off[j] + slab_ * 32);
+        };
+        auto commit = [&](Fetched& R) __attribute__((always_inline)) {
+            char* lbuf = smem + (it & 1) * x_stride;
+            char* wbuf = lbuf + X_BYTES_;     // streaming form only
+            // a single-slab layer's filter block goes into both buffers once (its registers are not refetched)
+            const bool stage_w = !wres && (it < 2 || n_slabs > 1);
+            float sa[8], ta[8], sb[8], tb[8], q0[8], q1[8], q2[8];
+            if (KIND != SRC_RAW) {
+                const float* t0 = tab + slab * 32 + c16 * 8;
+    #pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    sa[j] = t0[j]; ta[j] = t0[c_red + j];
+                    sb[j] = (KIND == SRC_ACT2 || KIND == SRC_BNBWD) ? t0[2 * c_red + j] : 0.f;
+                    tb[j] = (KIND == SRC_ACT2 || KIND == SRC_BNBWD) ? t0[3 * c_red + j] : 0.f;
+                    q0[j] = KIND == SRC_BNBWD ? t0[4 * c_red + j] : 0.f;
+                    q1[j] = KIND == SRC_BNBWD ? t0[5 * c_red + j] : 0.f;
+                    q2[j] = KIND == SRC_BNBWD ? t0[6 * c_red + j] : 0.f;
+                }
+            }
+    #pragma unroll
+            for (int jj = 0; jj < NP; ++jj) {
+                uint4 v = KIND == SRC_BNBWD ? chunk_bnbwd(R.praw[jj].a, R.praw[jj].b, sa, ta, sb, tb, q0, q1, q2) : chunk_convert<KIND>(R.praw[jj], sa, ta, sb, tb);
+                if (!((R.pok >> jj) & 1u)) v = make_uint4(0u, 0u, 0u, 0u);
+                if ((tid >> 2) + 64 * jj < G::RECS) *reinterpret_cast<uint4*>(lbuf + pdst[jj]) = v;
+                if (KIND == SRC_BNBWD) {
+                    if (write_dy && ((R.pok & R.pcore) >> jj & 1u) && (tid >> 2) + 64 * jj < G::RECS) *reinterpret_cast<uint4*>(R.dyo + R.poff[jj]) = v;
+                }
+            }
+            if (stage_w) {
+    #pragma unroll
+                for (int j = 0; j < NW; ++j)
+                    if ((tid >> 2) + 64 * j < 9 * C_OUT) *reinterpret_cast<u32x4*>(wbuf + wdst[j]) = wraw[j];
+            }
+        };
+        if (ftile < n_tiles) { enter_tile(); fetch(R0); if (!wres) fetch_w(0); }
         if (wres && tile < n_tiles) {   // resident form: every filter slab goes to its own LDS block once
             for (int sl = 0; sl < n_slabs; ++sl) {
-#pragma unroll
-                for (int j = 0; j < NW; ++j) wraw[j] = *reinterpret_cast<const u32x4*>(wsrc + wsrc_off[j] + sl * 32);
+                fetch_w(sl);
 #pragma unroll
                 for (int j = 0; j < NW; ++j)
                     if ((tid >> 2) + 64 * j < 9 * C_OUT) *reinterpret_cast<u32x4*>(smem + 2 * X_BYTES_ + sl * W_BYTES + wdst[j]) = wraw[j];
             }
         }
-        if (tile < n_tiles) fetch(tile, 0, !wres);
-        while (tile < n_tiles) {
-            int ntile = tile, nslab = slab + 1;
-            if (nslab == n_slabs) { nslab = 0; ntile += gridDim.x; }
-            char* lbuf = smem + (it & 1) * x_stride;
-            char* wbuf = lbuf + X_BYTES_;     // streaming form only
+        init_tables();
+        if (DEEP2 && ftile < n_tiles) fetch(R1);
+        auto one_item = [&](Fetched& R) __attribute__((always_inline)) {
             TICK();
-            // a single-slab layer's filter block goes into both buffers once (its registers are not refetched)
-            const bool stage_w = !wres && (it < 2 || n_slabs > 1);
-            {
-                float sa[8], ta[8], sb[8], tb[8], q0[8], q1[8], q2[8];
-                if (KIND != SRC_RAW) {
-                    const float* t0 = tab + slab * 32 + c16 * 8;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        sa[j] = t0[j]; ta[j] = t0[c_red + j];
-                        sb[j] = (KIND == SRC_ACT2 || KIND == SRC_BNBWD) ? t0[2 * c_red + j] : 0.f;
-                        tb[j] = (KIND == SRC_ACT2 || KIND == SRC_BNBWD) ? t0[3 * c_red + j] : 0.f;
-                        q0[j] = KIND == SRC_BNBWD ? t0[4 * c_red + j] : 0.f;
-                        q1[j] = KIND == SRC_BNBWD ? t0[5 * c_red + j] : 0.f;
-                        q2[j] = KIND == SRC_BNBWD ? t0[6 * c_red + j] : 0.f;
-                    }
-                }
-#pragma unroll
-                for (int jj = 0; jj < NP; ++jj) {
-                    uint4 v = KIND == SRC_BNBWD ? chunk_bnbwd(praw[jj].a, praw[jj].b, sa, ta, sb, tb, q0, q1, q2) : chunk_convert<KIND>(praw[jj], sa, ta, sb, tb);
-                    if (!((pok >> jj) & 1u)) v = make_uint4(0u, 0u, 0u, 0u);
-                    if ((tid >> 2) + 64 * jj < G::RECS) *reinterpret_cast<uint4*>(lbuf + pdst[jj]) = v;
-                    if (KIND == SRC_BNBWD) {
-                        if (write_dy && ((pok & pcore) >> jj & 1u) && (tid >> 2) + 64 * jj < G::RECS) *reinterpret_cast<uint4*>(dyo + poff[jj]) = v;
-                    }
-                }
-                if (stage_w) {
-#pragma unroll
-                    for (int j = 0; j < NW; ++j)
-                        if ((tid >> 2) + 64 * j < 9 * C_OUT) *reinterpret_cast<u32x4*>(wbuf + wdst[j]) = wraw[j];
-                }
-            }
+            commit(R);
 #ifdef ANH_WS_PROFILE
-            __builtin_amdgcn_s_waitcnt(0xc07f);  // the commit figure includes the load wait and the LDS write drain
+            __builtin_amdgcn_s_waitcnt(0xc07f);  // the commit figure includes the LDS write drain
 #endif
             TOCK(t_a);
             TICK();
-            if (ntile < n_tiles) fetch(ntile, nslab, !wres && n_slabs > 1);
+            if (ftile < n_tiles) fetch(R);
+            if (!wres && n_slabs > 1 && (slab + 1 < n_slabs || tile + gstep < n_tiles)) fetch_w(slab + 1 < n_slabs ? slab + 1 : 0);
             TOCK(t_b);
             TICK();
             __syncthreads();  // buffer it & 1 is full; the consumers are done with buffer (it + 1) & 1
             TOCK(t_c);
-            tile = ntile; slab = nslab; ++it;
+            if (++slab == n_slabs) { slab = 0; tile += gstep; }
+            ++it;
+        };
+        while (tile < n_tiles) {
+            one_item(R0);
+            if (DEEP2) {
+                if (tile >= n_tiles) break;
+                one_item(R1);
+            }
         }
     } else {
+        init_tables();
         typename G::Bases b0;
         G::init(b0, smem, wave, col, half);
         const char* wb0[2];
