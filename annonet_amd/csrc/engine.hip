@@ -432,6 +432,7 @@ void Engine::backward(const uint16_t* d_labels, const float* d_weights, double l
     const bool fused_head = head_is_fused();
     for (auto& s : ls) s.dact_written = false;
     int head_bnred_blocks_ = 0;
+    bool head_da_virtual = false;
     if (fused_head) {
         HeadTrainArgs t;
         t.src = layer_source(nl - 1, last_image); t.c_in = head.cin; t.k = head.cout;
@@ -452,8 +453,14 @@ void Engine::backward(const uint16_t* d_labels, const float* d_weights, double l
             head_bnred_blocks = head_train_blocks(P);
             hp.bwd_partials.reserve((size_t)head_bnred_blocks * 2 * head.cin * sizeof(double));
             t.bnred_mean = hp.mean; t.bnred_invstd = hp.invstd; t.bnred_partials = hp.bwd_partials.as<double>();
+            // ... and then nothing needs da in memory: the layer's bn_bwd_apply pass recomputes it from the dlogits (k floats per pixel
+            // instead of 32 storage elements written here and read there).  The rejected fusions read da through a conv prologue: not for them.
+            static const bool virtual_da = !(getenv("ANH_HEAD_DA_VIRTUAL") && atoi(getenv("ANH_HEAD_DA_VIRTUAL")) == 0);
+            int readers = 0;   // a second consumer of that layer would ADD its gradient to the da in memory
+            for (const anh_layer_desc& X : spec.layers) readers += (X.in_a == head.in_a) + (X.in_b == head.in_a);
+            if (virtual_da && readers == 1 && bn_bwd_apply_fusion_mode() == 0 && !getenv("ANH_FORCE_FUSED_APPLY")) { t.da = nullptr; t.dlogits = dlogits.as<float>(); head_da_virtual = true; }
         }
-        const int tok = prof.begin(stream, "head_fused_fwd_loss_bwd", 2.0 * 3 * head.cin * head.cout * (double)P, (double)P * (head.cin * es * 2 + head.cout * 4.0 + 6.0));
+        const int tok = prof.begin(stream, "head_fused_fwd_loss_bwd", 2.0 * 3 * head.cin * head.cout * (double)P, (double)P * (head.cin * es * (head_da_virtual ? 1 : 2) + head.cout * (head_da_virtual ? 8.0 : 4.0) + 6.0));
         launch_head_train(t, stream);
         prof.end(stream, tok);
         head_bnred_blocks_ = head_bnred_blocks;
@@ -510,6 +517,7 @@ void Engine::backward(const uint16_t* d_labels, const float* d_weights, double l
             b.gamma = master.as<float>() + L.g_off; b.mean = s.mean; b.invstd = s.invstd; b.scale = s.scale; b.shift = s.shift;
             b.dgamma = grad.as<float>() + L.g_off; b.dbeta = grad.as<float>() + L.beta_off;
             b.partials = bn_partials.as<double>(); b.coef = s.coef;
+            if (head_da_virtual && li == head.in_a) { b.head_g = dlogits.as<float>(); b.head_w_tm = w_tm_f32.as<float>() + head.w_off; b.head_k = head.cout; }
             // one profiler entry per kernel: reduce reads da and y; apply reads both and writes dy
             int tok;
             if (s.fused_bwd_blocks > 0) {   // the conv that wrote da last left the partial sums
@@ -549,7 +557,7 @@ void Engine::backward(const uint16_t* d_labels, const float* d_weights, double l
             probe.k = L.k; probe.stride = L.stride; probe.pad = L.pad; probe.gather = L.type;
             wgrad_computes_dy = !has_dgrad && wgrad_accepts_bnbwd(probe, dtype);
             if (!wgrad_computes_dy && !dgrad_writes_dy) {
-                tok = prof.begin(apply_on, "bn_bwd_apply", 0, (double)p_out * L.cout * es * 3);
+                tok = prof.begin(apply_on, "bn_bwd_apply", 0, b.head_g ? (double)p_out * (L.cout * es * 2 + head.cout * 4.0) : (double)p_out * L.cout * es * 3);
                 launch_bn_bwd_apply(b, apply_on);
                 prof.end(apply_on, tok);
             }

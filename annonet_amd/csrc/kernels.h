@@ -120,6 +120,9 @@ struct BnBwdArgs {
     float* dgamma = nullptr; float* dbeta = nullptr;  // destinations in the gradient blob
     double* partials = nullptr;
     float* coef = nullptr;  // scratch 3*c floats
+    // apply with the gradient of the 1x1 head NOT materialised: da[p][ch] = round(sum_k head_g[p][k] * head_w_tm[ch][k]) is recomputed
+    // per pixel from the head's dlogits (k floats per pixel instead of c storage elements), with the fused head kernel's own expression
+    const float* head_g = nullptr; const float* head_w_tm = nullptr; int head_k = 0;
     void* dy_out = nullptr; // apply: destination (default: in place over da)
     int partial_blocks = 0; // finalize: partials per channel when the reduction came from a conv epilogue (0 = bn_partial_blocks(pixels))
 };
@@ -230,7 +233,8 @@ struct HeadTrainArgs {
     Src src; int c_in = 0;
     const float* w_tm = nullptr; const float* w_km = nullptr; const float* bias = nullptr;
     const uint16_t* labels = nullptr; const float* weights = nullptr;
-    float* logits = nullptr; void* da = nullptr;
+    float* logits = nullptr; void* da = nullptr;   // da may be null when bnred_partials is set: see BnBwdArgs::head_g
+    float* dlogits = nullptr;                      // optional: [P][k] fp32, the loss gradient at the logits
     int64_t pixels = 0; int k = 0; double scale = 0;
     double* partials = nullptr;
     double* loss_out = nullptr; float* loss_out_f32 = nullptr; float* dbias = nullptr; float* dw = nullptr;

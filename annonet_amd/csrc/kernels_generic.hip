@@ -1114,6 +1114,45 @@ __global__ __launch_bounds__(64) void loss_finalize_kernel(const double* partial
 // ---------------------------------------------------------------------------------------------------
 constexpr int kHeadC = 32, kHeadKMax = 4;
 
+// the same pass for the layer under the fused 1x1 head, whose da is not in memory: a thread recomputes its 8 channels of
+// da = round_T(sum_k g[p][k] * w_tm[ch][k]) from the pixel's dlogits (head_train_kernel's expression and order)
+template <typename T, int KM>
+__global__ __launch_bounds__(256) void bn_bwd_apply_head_kernel(const float* g, const float* w_tm, int K, T* out, const T* y, int64_t chunks, const float* mean,
+                                                                const float* invstd, const float* scale, const float* shift, const float* coef) {
+    constexpr int C = kHeadC, groups = C >> 3;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int cg = (int)(first % groups);
+    float m[8], is[8], sc[8], sf[8], k0[8], k1[8], k2[8], w[8][KM];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int ch = cg * 8 + j;
+        m[j] = mean[ch]; is[j] = invstd[ch]; sc[j] = scale[ch]; sf[j] = shift[ch];
+        k0[j] = coef[ch]; k1[j] = coef[C + ch]; k2[j] = coef[2 * C + ch];
+#pragma unroll
+        for (int k = 0; k < KM; ++k) w[j][k] = k < K ? w_tm[ch * K + k] : 0.f;
+    }
+    for (int64_t i = first; i < chunks; i += stride) {
+        const int64_t p = i / groups;
+        float gk[KM];
+#pragma unroll
+        for (int k = 0; k < KM; ++k) gk[k] = k < K ? g[(size_t)p * K + k] : 0.f;
+        float yv[8], r[8];
+        load8<T>(y + (size_t)i * 8, yv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < KM; ++k) acc = fmaf(gk[k], w[j][k], acc);
+            const float dz = fmaf(yv[j], sc[j], sf[j]) > 0.f ? operand_round<T>(acc) : 0.f;
+            const float xhat = (yv[j] - m[j]) * is[j];
+            r[j] = k0[j] * (dz - k1[j] - xhat * k2[j]);
+        }
+        store8<T>(out + (size_t)i * 8, r);
+    }
+}
+
+
 struct HeadArgs {
     Src src;                       // SRC_ACT or SRC_ACT2, 32 channels
     const float* w_tm;             // [ci][k]   (tap-major with one tap), bf16-rounded values in bf16 mode
@@ -1121,7 +1160,8 @@ struct HeadArgs {
     const float* bias;
     const uint16_t* labels; const float* weights;
     float* logits;                 // [P][K] fp32 (kept for inspection)
-    void* da;                      // [P][32] storage type
+    void* da;                      // [P][32] storage type (null: not materialised)
+    float* dlogits;                // [P][K] fp32 or null
     int64_t pixels; int k;
     double scale;
     double* partials;              // [blocks][1 + K + 32*K]
@@ -1244,7 +1284,11 @@ __global__ __launch_bounds__(256, 2) void head_train_kernel(HeadArgs a) {
 #pragma unroll
             for (int k = 0; k < KM; ++k) db[k] += g[k];
         }
-        store8<T>(da + (size_t)p * C + c0, dx);
+        if (da) store8<T>(da + (size_t)p * C + c0, dx);
+        if (a.dlogits && sub == 0) {
+#pragma unroll
+            for (int k = 0; k < KM; ++k) if (k < K) a.dlogits[(size_t)p * K + k] = g[k];
+        }
         if (bnred) {
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
@@ -1702,7 +1746,7 @@ void launch_head_train(const HeadTrainArgs& t, hipStream_t s) {
     ANH_REQUIRE(head_train_supported(t), "head_train: unsupported shape");
     HeadArgs a;
     a.src = t.src; a.w_tm = t.w_tm; a.w_km = t.w_km; a.bias = t.bias; a.labels = t.labels; a.weights = t.weights;
-    a.logits = t.logits; a.da = t.da; a.pixels = t.pixels; a.k = t.k; a.scale = t.scale; a.partials = t.partials; a.error_flag = t.error_flag;
+    a.logits = t.logits; a.da = t.da; a.dlogits = t.dlogits; a.pixels = t.pixels; a.k = t.k; a.scale = t.scale; a.partials = t.partials; a.error_flag = t.error_flag;
     a.bn_mean = t.bnred_mean; a.bn_invstd = t.bnred_invstd; a.bn_partials = t.src.kind == SRC_ACT ? t.bnred_partials : nullptr;
     const int blocks = head_train_blocks(t.pixels);
     const bool bf = t.src.dtype == DT_BF16;
@@ -1795,6 +1839,20 @@ void launch_bn_bwd_apply(const BnBwdArgs& a, hipStream_t s) {
     const int64_t total = a.pixels * a.c;
     const bool bf = a.dtype == DT_BF16;
     void* out = a.dy_out ? a.dy_out : a.da;
+    if (a.head_g) {   // da of the layer under the fused head is recomputed from the head's dlogits
+        ANH_REQUIRE(a.c == kHeadC && a.head_k >= 1 && a.head_k <= kHeadKMax && out != nullptr, "bn_bwd_apply: head form needs 32 channels and at most 4 classes");
+        const int64_t chunks = total / 8;
+        const int blocks = (int)std::min<int64_t>((chunks + 255) / 256, 256 * 8);
+        auto go = [&](auto kernel, auto tag) {
+            using T = decltype(tag);
+            hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, s, a.head_g, a.head_w_tm, a.head_k, reinterpret_cast<T*>(out), reinterpret_cast<const T*>(a.y), chunks,
+                               a.mean, a.invstd, a.scale, a.shift, a.coef);
+        };
+        if (a.head_k <= 2) { if (bf) go(bn_bwd_apply_head_kernel<bf16, 2>, bf16{}); else go(bn_bwd_apply_head_kernel<float, 2>, float{}); }
+        else { if (bf) go(bn_bwd_apply_head_kernel<bf16, 4>, bf16{}); else go(bn_bwd_apply_head_kernel<float, 4>, float{}); }
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
     if (bn_vec_ok(a.c)) {
         const int64_t chunks = total / 8;
         const int apply_blocks = (int)std::min<int64_t>((chunks + 255) / 256, 256 * 8);  // 256 threads: a multiple of every group count

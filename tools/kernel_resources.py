@@ -11,7 +11,7 @@ cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fP
        "-c", src, "-o", "/dev/null"] + sys.argv[3:]
 run = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
 t = run.stderr
-names = re.findall(r"Function Name: (\S+)", t)
+names = re.findall(r"Function Name: ([A-Za-z0-9_]+)", t)
 if run.returncode != 0 or not names:   # (c++filt with no arguments would wait on stdin)
     sys.exit("\n".join(l for l in t.splitlines() if "error" in l) or t[-2000:])
 dem = dict(zip(names, subprocess.run(["c++filt"] + names, capture_output=True, text=True, stdin=subprocess.DEVNULL).stdout.splitlines()))
