@@ -67,9 +67,15 @@ Engine::Engine(const anh_net_config& cfg, bool training_) : spec(Spec::build(cfg
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count == 0) { (void)hipGetLastError(); fail(ANH_ERR_DEVICE, "no MI355X / HIP device visible"); }
     HIP_CHECK(hipGetDevice(&device));
-    HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    // experiment switch: ANH_STREAM_PRIORITY=1 puts the main (critical-path) stream above the filter-gradient stream
+    static const int prio = getenv("ANH_STREAM_PRIORITY") ? atoi(getenv("ANH_STREAM_PRIORITY")) : 0;
+    int lo = 0, hi = 0;
+    HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));   // lo = least urgent (numerically greatest)
+    if (prio && training) HIP_CHECK(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, hi));
+    else HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     if (training) {
-        HIP_CHECK(hipStreamCreateWithFlags(&aux_stream, hipStreamNonBlocking));
+        if (prio) HIP_CHECK(hipStreamCreateWithPriority(&aux_stream, hipStreamNonBlocking, prio == 2 ? hi : lo));
+        else HIP_CHECK(hipStreamCreateWithFlags(&aux_stream, hipStreamNonBlocking));
         HIP_CHECK(hipEventCreateWithFlags(&ev_dy_ready, hipEventDisableTiming));
         HIP_CHECK(hipEventCreateWithFlags(&ev_aux_done, hipEventDisableTiming));
         const char* e = getenv("ANH_CONCURRENT_WGRAD");

@@ -65,6 +65,22 @@ __device__ __forceinline__ float relu_affine(float y, float s, float t) {
     return z > 0.f ? z : 0.f;
 }
 
+// relu of two packed bf16: rounding to bf16 keeps the sign, so relu(round(z)) == round(relu(z)) bit for bit, and on the packed pair
+// the relu is ONE v_pk_max_i16 against zero (a negative bf16, -0 included, is a negative int16)
+typedef __attribute__((ext_vector_type(2))) short s16x2;
+__device__ __forceinline__ unsigned relu_bf16x2(unsigned packed) {
+    const s16x2 zero = {0, 0};
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, packed), zero));
+}
+// one chunk through a single producer's bn + relu: affine in fp32, pack, relu on the packed pairs (5 VALU per pair instead of 7)
+__device__ __forceinline__ uint4 affine_relu_pack8(const uint4& raw, const float* sc, const float* sh) {
+    const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
+    unsigned o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = relu_bf16x2(pack2(fmaf(lo_f(w[i]), sc[2 * i], sh[2 * i]), fmaf(hi_f(w[i]), sc[2 * i + 1], sh[2 * i + 1])));
+    return make_uint4(o[0], o[1], o[2], o[3]);
+}
+
 // 8 bf16 (one 16-byte chunk) through the producer's bn+relu
 __device__ __forceinline__ void affine8(const uint4& raw, const float* sc, const float* sh, float v[8]) {
     const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
@@ -230,6 +246,7 @@ __device__ __forceinline__ RawChunk<KIND> side_load(const WgSide& s, size_t pix,
 template <int KIND>
 __device__ __forceinline__ uint4 side_convert(const WgSide& s, const RawChunk<KIND>& r, int ch) {
     if (KIND == SRC_RAW) return r.a;
+    if (KIND == SRC_ACT) return affine_relu_pack8(r.a, s.a_scale + ch, s.a_shift + ch);
     float v[8];
     affine8(r.a, s.a_scale + ch, s.a_shift + ch, v);
     if (KIND == SRC_ACT2) {
@@ -314,6 +331,7 @@ __device__ __forceinline__ void side_commit(const SideRegs<KIND, ITEMS>& R, char
 template <int KIND>
 __device__ __forceinline__ uint4 chunk_convert(const RawChunk<KIND>& r, const float* sa, const float* ta, const float* sb, const float* tb) {
     if (KIND == SRC_RAW || KIND == SRC_BNBWD) return r.a;  // (SRC_BNBWD goes through chunk_bnbwd)
+    if (KIND == SRC_ACT) return affine_relu_pack8(r.a, sa, ta);
     float v[8];
     affine8(r.a, sa, ta, v);
     if (KIND == SRC_ACT2) {
@@ -1075,7 +1093,7 @@ struct GeoUp {
 // FWD: the forward-only form — no prefetched epilogue operands (old values of an accumulating destination, y of the
 // layer behind `out`), whose registers the four-accumulator-group geometry at NT = 2 needs for its bn statistics sums.
 template <class G, int NT, int KIND, bool FWD = false>
-__global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tiles_x, int tiles_y, int flip, long long* prof, int wres) {
+__global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tiles_x, int tiles_y, int flip, long long* prof, int wres_) {
     // per-phase wall-clock accounting, compiled in with -DANH_WS_PROFILE (ANH_WS_PROF=1 then prints one line per launch)
 #ifdef ANH_WS_PROFILE
     long long t_a = 0, t_b = 0, t_c = 0, t0_;
@@ -1087,6 +1105,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
 #endif
     constexpr int C_OUT = NT * 32, NP = (G::RECS * 4 + 255) / 256, W_ITEMS = 9 * C_OUT * 4, NW = (W_ITEMS + 255) / 256;
     constexpr int X_BYTES_ = G::RECS * 64, W_BYTES = 9 * C_OUT * 64, BUF = X_BYTES_ + W_BYTES;
+    const int wres = wres_ & 1, role_map = wres_ >> 1;   // (see the role map below)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // LDS layout.  Streaming form: [X | W] [X | W] tables — the filter slab of every item travels with its patch.
     // Resident form (wres; the filter slabs of ALL reduction slabs fit beside two patches, i.e. 64 reduction channels):
@@ -1096,9 +1115,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
     const int tab_off = wres ? 2 * X_BYTES_ + n_slabs_l * W_BYTES : 2 * BUF;
     float* tab = reinterpret_cast<float*>(smem + tab_off);  // [a_scale | a_shift | b_scale | b_shift][c_red]
 
-    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    const bool producer = wave >= 4;
-    const int tid = threadIdx.x & 255, lane = tid & 63, c16 = tid & 3;
+    // wres_ bit 0: filter-resident form; bit 1: role map.  The hardware deals the eight waves of a workgroup round the four SIMDs
+    // (wave w -> SIMD w & 3).  Map 0 puts one producer and one consumer on every SIMD (all four matrix cores in use); map 1 puts
+    // the consumers on SIMDs 0-1 and the producers on SIMDs 2-3, so the staging VALU work never queues behind an MFMA.
+    const int hw_wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const bool producer = role_map ? ((hw_wave >> 1) & 1) != 0 : hw_wave >= 4;
+    const int wave = role_map ? ((hw_wave & 1) | ((hw_wave >> 2) << 1)) : (hw_wave & 3);   // index within the role (0..3)
+    const int lane = threadIdx.x & 63, tid = wave * 64 + lane, c16 = tid & 3;
     const int half = lane >> 5, col = lane & 31;
     const int co_base = blockIdx.y * C_OUT;
     const int H = a.h_in, W = a.w_in, c_red = a.c_red;
@@ -1440,7 +1463,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
         }
     }
 #ifdef ANH_WS_PROFILE
-    if (prof && lane == 0) { long long* o = prof + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * 4; o[0] = t_a; o[1] = t_b; o[2] = t_c; o[3] = it; }
+    if (prof && lane == 0) { long long* o = prof + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (producer ? 4 : 0) + wave) * 4; o[0] = t_a; o[1] = t_b; o[2] = t_c; o[3] = it; }
 #endif
 #undef TICK
 #undef TOCK
@@ -1461,15 +1484,19 @@ void launch_ws(const ConvArgs& a, int tiles_x, int tiles_y, int flip, hipStream_
     const size_t resident_lds = 2 * x_bytes + (size_t)n_slabs * w_bytes + tables;
     const int wres = resident_on && n_slabs >= 2 && resident_lds <= 160 * 1024 && 2 * x_bytes + (size_t)n_slabs * w_bytes >= (size_t)32 * 1024 * NT;
     const size_t lds = wres ? resident_lds : 2 * (x_bytes + w_bytes) + tables;
+    // ANH_WS_ROLE_MAP: 0 = one producer + one consumer per SIMD, 1 = consumers on SIMDs 0-1 / producers on SIMDs 2-3, 2 = map 1 for the
+    // 32-output-channel kernels only (their MFMA phase is short; the 64-channel kernels need all four matrix cores)
+    static const int role_env = getenv("ANH_WS_ROLE_MAP") ? atoi(getenv("ANH_WS_ROLE_MAP")) : 0;
+    const int role_map = role_env == 1 || (role_env == 2 && NT == 1) ? 1 : 0;
     auto launch = [&](auto kernel) {
         ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), lds);
 #ifndef ANH_WS_PROFILE
-        hipLaunchKernelGGL(kernel, grid, block, lds, s, a, tiles_x, tiles_y, flip, (long long*)nullptr, wres);
+        hipLaunchKernelGGL(kernel, grid, block, lds, s, a, tiles_x, tiles_y, flip, (long long*)nullptr, wres | (role_map << 1));
 #else
         static const int prof_on = getenv("ANH_WS_PROF") ? atoi(getenv("ANH_WS_PROF")) : 0;
         static long long* prof = nullptr;
         if (prof_on && !prof) HIP_CHECK(hipMalloc(&prof, 1024 * 8 * 4 * sizeof(long long)));
-        hipLaunchKernelGGL(kernel, grid, block, lds, s, a, tiles_x, tiles_y, flip, prof_on ? prof : nullptr, wres);
+        hipLaunchKernelGGL(kernel, grid, block, lds, s, a, tiles_x, tiles_y, flip, prof_on ? prof : nullptr, wres | (role_map << 1));
         if (prof_on) {
             HIP_CHECK(hipStreamSynchronize(s));
             const int nwg = grid.x * grid.y;
@@ -1715,7 +1742,7 @@ WgPlan wgrad_plan_mfma(const WgradArgs& a) {
     else p.lds = (2 * p.lds + tab <= 160 * 1024 ? 2 * p.lds : p.lds) + tab;  // double-buffered when it fits (the kernel makes the same decision)
     // one workgroup per CU: these kernels share the chip with the backward-data chain (second stream), and every
     // workgroup writes a full partial, so fewer workgroups also means less partial-sum traffic
-    const int target = 256;
+    static const int target = getenv("ANH_WGRAD_WGS") ? atoi(getenv("ANH_WGRAD_WGS")) : 256;
     p.splits = std::max(1, std::min(p.total, target / (p.slabs * p.zgroups)));
     return p;
 }
