@@ -561,14 +561,23 @@ void infer_streamed(anh_runtime* h, const uint8_t* image, int H, int W, const do
     std::vector<int> final_after(tiles.size());
     int lowest_top = H;
     for (size_t i = tiles.size(); i-- > 0;) { final_after[i] = std::min(lowest_top, H); lowest_top = std::min(lowest_top, (int)std::max(0l, (long)tiles[i].full_rect.top)); }
-    for (size_t i = 0; i < tiles.size(); ++i) {
+    auto rows_needed = [&](const TileWindow& w) { return std::min(H, std::max(1, w.top + w.height)); };   // clamp-to-edge reads reach row 0 / row H-1 at most
+    for (size_t i = 0; i < tiles.size();) {
+        // the tiles of one tile row (equal windows, same image rows) run as batches (Engine::infer_tiles)
         const TileWindow win = tile_window(tiles[i], e.spec.cfg.levels);
-        const int need = std::min(H, std::max(1, win.top + win.height));   // clamp-to-edge reads reach row 0 / row H-1 at most
+        const int need = rows_needed(win), limit = e.tile_batch(win.height, win.width);
+        size_t j = i + 1;
+        while (j < tiles.size() && j - i < (size_t)limit) {
+            const TileWindow wj = tile_window(tiles[j], e.spec.cfg.levels);
+            if (wj.height != win.height || wj.width != win.width || rows_needed(wj) != need) break;
+            ++j;
+        }
         upload_until(need);
         HIP_CHECK(hipStreamWaitEvent(e.stream, h->strip_events[(need - 1) / strip_rows], 0));
-        e.infer_tile(tiles[i], d_image, H, W, d_blended);
-        upload_until(uploaded + strip_rows);   // stay a few strips ahead of the tiles: one more strip per tile enqueued
-        if (final_after[i] > labels_done) send_labels(final_after[i]);
+        e.infer_tiles(&tiles[i], (int)(j - i), d_image, H, W, d_blended);
+        upload_until(uploaded + strip_rows * (int)(j - i));   // stay a few strips ahead of the tiles: one more strip per tile enqueued
+        if (final_after[j - 1] > labels_done) send_labels(final_after[j - 1]);
+        i = j;
     }
     upload_until(H);        // an image larger than its tiles' windows cannot occur, but keep the invariant
     send_labels(H);

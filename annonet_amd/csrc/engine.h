@@ -100,7 +100,10 @@ class Engine {
     void layer_tensor(int layer, int which, float* out_host, int64_t capacity, int dims[4]);
 
     // ---- tiled inference: annonet_infer.cpp:42-214 with image, blended planes and labels resident in HBM ----
+    static constexpr int kMaxTileBatch = 8;   // Src::img_win holds eight windows
     void infer_tile(const anh_tile& t, const uint8_t* d_image, int H, int W, float* d_blended);
+    void infer_tiles(const anh_tile* ts, int count, const uint8_t* d_image, int H, int W, float* d_blended);
+    int tile_batch(int h, int w) const;
     const double* upload_gains(const double* gains_host);   // -> device pointer (or nullptr)
     void infer_device(const uint8_t* d_image, int H, int W, const double* gains_host, const std::vector<anh_tile>& tiles,
                       uint16_t* d_labels, float* d_blended);

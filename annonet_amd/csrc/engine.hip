@@ -689,12 +689,27 @@ void Engine::layer_tensor(int layer, int which, float* out_host, int64_t capacit
 // tiled inference (annonet_infer.cpp:42-214)
 // ---------------------------------------------------------------------------------------------------
 // one tile of annonet_infer(): clamp-to-edge window of the resident image -> net forward -> blend into the resident planes
-void Engine::infer_tile(const anh_tile& t, const uint8_t* d_image, int H, int W, float* d_blended) {
+void Engine::infer_tile(const anh_tile& t, const uint8_t* d_image, int H, int W, float* d_blended) { infer_tiles(&t, 1, d_image, H, W, d_blended); }
+
+// `count` (<= kMaxTileBatch) tiles whose input windows have the same size run through the net as ONE batch — every conv launch
+// then carries count times the work, so its fixed ramp and tail (a third of a 30-us launch on a 1024^2 tile) is paid once —
+// and are blended one after the other, in list order: the additive blended_output sees exactly the sequence of the per-tile loop
+// (annonet_infer.cpp:116-164), so the result does not depend on the batch size.
+void Engine::infer_tiles(const anh_tile* ts, int count, const uint8_t* d_image, int H, int W, float* d_blended) {
+    ANH_REQUIRE(count >= 1 && count <= kMaxTileBatch, "infer_tiles: batch size out of range");
     const int K = spec.cfg.classes;
-    const TileWindow win = tile_window(t, spec.cfg.levels);
+    const TileWindow win = tile_window(ts[0], spec.cfg.levels);
     Src image;
     image.kind = SRC_IMAGE;
     image.img = d_image; image.img_h = H; image.img_w = W; image.img_left = win.left; image.img_top = win.top;
+    if (count > 1) {
+        image.img_nwin = count;   // (img_sample_stride stays 0: the samples are windows of the same image)
+        for (int i = 0; i < count; ++i) {
+            const TileWindow wi = tile_window(ts[i], spec.cfg.levels);
+            ANH_REQUIRE(wi.height == win.height && wi.width == win.width, "infer_tiles: tiles of one batch must have equal windows");
+            image.img_win[2 * i] = wi.left; image.img_win[2 * i + 1] = wi.top;
+        }
+    }
     // bf16 mode: the 1x1 head and the blend run as one kernel over the last hidden tensor (the tile's logits stay on chip)
     const anh_layer_desc& head = spec.layers.back();
     HeadBlendArgs hb;
@@ -702,31 +717,56 @@ void Engine::infer_tile(const anh_tile& t, const uint8_t* d_image, int H, int W,
     const bool fuse_head = !training && head.k == 1 && head.has_bias && head.in_a >= 0 && head_blend_supported(hb);
     if (fuse_head) {
         prof.start_pass();
-        plan_dims(1, win.height, win.width);
+        plan_dims(count, win.height, win.width);
         for (size_t li = 0; li + 1 < spec.layers.size(); ++li) run_conv_forward((int)li, image, false, nullptr);
     } else {
-        tile_out.reserve((size_t)K * win.height * win.width * 4);
-        forward_inference(image, 1, win.height, win.width, tile_out.as<float>());
+        tile_out.reserve((size_t)count * K * win.height * win.width * 4);
+        forward_inference(image, count, win.height, win.width, tile_out.as<float>());
     }
-    BlendArgs b;
-    b.logits_nchw = fuse_head ? nullptr : tile_out.as<float>(); b.blended = d_blended;
-    b.k = K; b.tile_h = win.height; b.tile_w = win.width; b.tile_left = win.left; b.tile_top = win.top;
-    b.img_h = H; b.img_w = W;
-    b.full[0] = t.full_rect.left; b.full[1] = t.full_rect.top; b.full[2] = t.full_rect.right; b.full[3] = t.full_rect.bottom;
-    b.unique[0] = t.unique_rect.left; b.unique[1] = t.unique_rect.top; b.unique[2] = t.unique_rect.right; b.unique[3] = t.unique_rect.bottom;
-    if (fuse_head) {
-        hb.src = layer_source((int)spec.layers.size() - 1, image);   // (scale/shift pointers are stable; the tensors were just written)
-        hb.w_tm = w_tm_f32.as<float>() + head.w_off; hb.bias = master.as<float>() + head.b_off;
-        hb.blend = b;
-        const int tok = prof.begin(stream, "head_blend_fused", 2.0 * head.cin * head.cout * (double)win.height * win.width,
-                                   (double)win.height * win.width * (head.cin * 2.0 + K * 8.0));
-        launch_head_blend(hb, stream);
+    const size_t es = elem_size(dtype);
+    for (int i = 0; i < count; ++i) {
+        const anh_tile& t = ts[i];
+        const TileWindow wi = tile_window(t, spec.cfg.levels);
+        BlendArgs b;
+        b.logits_nchw = fuse_head ? nullptr : tile_out.as<float>() + (size_t)i * K * win.height * win.width; b.blended = d_blended;
+        b.k = K; b.tile_h = wi.height; b.tile_w = wi.width; b.tile_left = wi.left; b.tile_top = wi.top;
+        b.img_h = H; b.img_w = W;
+        b.full[0] = t.full_rect.left; b.full[1] = t.full_rect.top; b.full[2] = t.full_rect.right; b.full[3] = t.full_rect.bottom;
+        b.unique[0] = t.unique_rect.left; b.unique[1] = t.unique_rect.top; b.unique[2] = t.unique_rect.right; b.unique[3] = t.unique_rect.bottom;
+        if (fuse_head) {
+            hb.src = layer_source((int)spec.layers.size() - 1, image);   // (scale/shift pointers are stable; the tensors were just written)
+            const size_t plane = (size_t)win.height * win.width * head.cin * es;   // sample i of the last hidden tensor
+            hb.src.a = static_cast<const char*>(hb.src.a) + (size_t)i * plane;
+            if (hb.src.b) hb.src.b = static_cast<const char*>(hb.src.b) + (size_t)i * plane;
+            hb.w_tm = w_tm_f32.as<float>() + head.w_off; hb.bias = master.as<float>() + head.b_off;
+            hb.blend = b;
+            const int tok = prof.begin(stream, "head_blend_fused", 2.0 * head.cin * head.cout * (double)win.height * win.width,
+                                       (double)win.height * win.width * (head.cin * 2.0 + K * 8.0));
+            launch_head_blend(hb, stream);
+            prof.end(stream, tok);
+            continue;
+        }
+        const int tok = prof.begin(stream, "blend_accumulate", 0, (double)K * win.height * win.width * 12);
+        launch_blend(b, stream);
         prof.end(stream, tok);
-        return;
     }
-    const int tok = prof.begin(stream, "blend_accumulate", 0, (double)K * win.height * win.width * 12);
-    launch_blend(b, stream);
-    prof.end(stream, tok);
+}
+
+// how many tiles with a window of h x w run as one batch: ANH_INFER_TILE_BATCH, or as many (at most kMaxTileBatch) as keep the
+// batch's layer tensors under 16 GiB (1024^2 tiles: 8 x 0.4 GB in bf16; a 4096^2 tile alone is 6 GB)
+int Engine::tile_batch(int h, int w) const {
+    static const int batch_env = getenv("ANH_INFER_TILE_BATCH") ? atoi(getenv("ANH_INFER_TILE_BATCH")) : 0;
+    int batch = batch_env;
+    if (batch <= 0) {
+        double per_px = 0, scale = 1.0;   // storage elements per input pixel over all layer outputs
+        for (const anh_layer_desc& L : spec.layers) {
+            if (L.stride == 2) scale *= L.type == 0 ? 0.25 : 4.0;
+            per_px += L.cout * scale;
+        }
+        const double bytes = per_px * (double)elem_size(dtype) * (double)h * (double)w;
+        batch = (int)std::floor(16.0 * 1024 * 1024 * 1024 / std::max(bytes, 1.0));
+    }
+    return std::max(1, std::min(kMaxTileBatch, batch));
 }
 
 const double* Engine::upload_gains(const double* gains_host) {
@@ -743,7 +783,19 @@ void Engine::infer_device(const uint8_t* d_image, int H, int W, const double* ga
     const int K = spec.cfg.classes;
     const int64_t pixels = (int64_t)H * W;
     launch_fill_zero(d_blended, (size_t)K * pixels * 4, stream);
-    for (const anh_tile& t : tiles) infer_tile(t, d_image, H, W, d_blended);
+    // consecutive tiles with equal input windows (all of them, on a regular tiling) run as batches
+    for (size_t i = 0; i < tiles.size();) {
+        const TileWindow w0 = tile_window(tiles[i], spec.cfg.levels);
+        const int batch = tile_batch(w0.height, w0.width);
+        size_t j = i + 1;
+        while (j < tiles.size() && j - i < (size_t)batch) {
+            const TileWindow wj = tile_window(tiles[j], spec.cfg.levels);
+            if (wj.height != w0.height || wj.width != w0.width) break;
+            ++j;
+        }
+        infer_tiles(&tiles[i], (int)(j - i), d_image, H, W, d_blended);
+        i = j;
+    }
     const double* d_gains = upload_gains(gains_host);
     if (d_labels) {
         const int tok = prof.begin(stream, "argmax_gain", 0, (double)pixels * (K * 4.0 + 2.0));

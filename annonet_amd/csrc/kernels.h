@@ -34,6 +34,12 @@ struct Src {
     const uint8_t* img = nullptr;
     int img_h = 0, img_w = 0, img_left = 0, img_top = 0;
     int64_t img_sample_stride = 0;
+    // several windows of ONE image as the samples of a batch (annonet_infer() runs tiles of equal size together): sample n
+    // starts at (img_win[2n], img_win[2n+1]); img_nwin = 0 means the single window above
+    int img_nwin = 0;
+    int img_win[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    __host__ __device__ int win_left(int n) const { return img_nwin ? img_win[2 * n] : img_left; }
+    __host__ __device__ int win_top(int n) const { return img_nwin ? img_win[2 * n + 1] : img_top; }
 };
 
 // out[n,oy,ox,co] = sum_{ky,kx,cr} src(n, iy, ix, cr) * w[(ky*k+kx)][cr][co]   (+ bias[co])

@@ -89,8 +89,8 @@ template <> __device__ __forceinline__ void store8<bf16>(bf16* p, const float v[
 template <typename T, int KIND>
 __device__ __forceinline__ float fetch1(const Src& s, int n, int y, int x, int h, int w, int c_total, int c) {
     if (KIND == SRC_IMAGE) {
-        const int sy = min(max(s.img_top + y, 0), s.img_h - 1);
-        const int sx = min(max(s.img_left + x, 0), s.img_w - 1);
+        const int sy = min(max(s.win_top(n) + y, 0), s.img_h - 1);
+        const int sx = min(max(s.win_left(n) + x, 0), s.img_w - 1);
         const uint8_t v = s.img[(size_t)n * s.img_sample_stride + ((size_t)sy * s.img_w + sx) * c_total + c];
         return (float)v * (1.0f / 256.0f);  // dlib input<>::to_tensor
     }

@@ -1620,7 +1620,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_stem_mfma_kernel(WgradArgs a, Wg
         for (int jj = 0; jj < NI; ++jj) {
             const int c = igeo[jj] & 15, px = (igeo[jj] >> 4) & 255, py = igeo[jj] >> 12;
             const int iy = y0 - 2 + py, ix = x0 - 2 + px;
-            const int sy = min(max(a.src.img_top + iy, 0), a.src.img_h - 1), sx = min(max(a.src.img_left + ix, 0), a.src.img_w - 1);
+            const int sy = min(max(a.src.win_top(n) + iy, 0), a.src.img_h - 1), sx = min(max(a.src.win_left(n) + ix, 0), a.src.img_w - 1);
             ipx[jj] = img[((size_t)sy * a.src.img_w + sx) * CIN + c];
             iok |= ((iy >= 0 && iy < a.h_in && ix >= 0 && ix < a.w_in) ? 1u : 0u) << jj;
         }
@@ -1993,7 +1993,7 @@ __global__ __launch_bounds__(256, 2) void stem_mfma_kernel(ConvArgs a, int tiles
             const int iy = y0 - 2 + py, ix = x0 - 2 + px;
             unsigned long long v = 0ull;
             if (iy >= 0 && iy < a.h_in && ix >= 0 && ix < a.w_in) {
-                const int sy = min(max(a.src.img_top + iy, 0), a.src.img_h - 1), sx = min(max(a.src.img_left + ix, 0), a.src.img_w - 1);
+                const int sy = min(max(a.src.win_top(n) + iy, 0), a.src.img_h - 1), sx = min(max(a.src.win_left(n) + ix, 0), a.src.img_w - 1);
                 const uint8_t* src = a.src.img + (size_t)n * a.src.img_sample_stride + ((size_t)sy * a.src.img_w + sx) * CIN;
                 unsigned short c[4] = {0, 0, 0, 0};
 #pragma unroll

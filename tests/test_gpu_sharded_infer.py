@@ -115,3 +115,26 @@ def test_the_default_stream_cannot_be_named_by_set_stream():
     assert aad.handle_stream(t).cuda_stream == side.cuda_stream
     t.set_stream(None)
     assert t.stream_ptr() not in (0, side.cuda_stream)
+
+
+def test_tile_batch_size_does_not_change_the_result(tmp_path):
+    """annonet_infer() runs tiles of equal size through the net as batches (ANH_INFER_TILE_BATCH, default 4) and blends them one after the
+    other in list order: label map and blended planes are BIT-identical to the tile-by-tile loop of annonet_infer.cpp:116-164, in both
+    precisions, and the streamed host form (strips up, label rows down, batches within a tile row) gives the same label map."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    runs = {}
+    for batch in ("1", "4", "3"):
+        out = str(tmp_path / f"b{batch}.npz")
+        r = subprocess.run([sys.executable, os.path.join(here, "helpers", "run_tiled_infer.py"), out], env=dict(os.environ, ANH_INFER_TILE_BATCH=batch),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        runs[batch] = np.load(out)
+    assert int(runs["1"]["bf16_tiles"]) >= 9
+    for batch in ("4", "3"):
+        for key in ("bf16_labels", "bf16_blended", "fp32_labels", "fp32_blended", "bf16_labels_streamed", "fp32_labels_streamed"):
+            np.testing.assert_array_equal(runs[batch][key], runs["1"][key], err_msg=f"batch {batch}: {key}")
+    for prec in ("bf16", "fp32"):
+        np.testing.assert_array_equal(runs["4"][prec + "_labels_streamed"], runs["4"][prec + "_labels"])
