@@ -1484,14 +1484,16 @@ __global__ __launch_bounds__(256) void head_blend_kernel(HeadBlendArgs a) {
     const bf16* xb = reinterpret_cast<const bf16*>(a.src.b);
     const int64_t pixels = (int64_t)b.tile_h * b.tile_w;
     const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 2;
-    for (int64_t p = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2; p < pixels; p += stride) {
+    const int f0 = (int)b.full[0], f1 = (int)b.full[1], f2 = (int)b.full[2], f3 = (int)b.full[3];
+    const int u0 = (int)b.unique[0], u1 = (int)b.unique[1], u2 = (int)b.unique[2], u3 = (int)b.unique[3];
+    auto process = [&](int64_t p, const Raw8<bf16>& ra, const Raw8<bf16>& rb) __attribute__((always_inline)) {
         float x[8];
-        load8<bf16>(xa + (size_t)p * C + c0, x);
+        raw_to_float(ra, x);
 #pragma unroll
         for (int c = 0; c < 8; ++c) x[c] = relu_affine(x[c], sa[c], ta[c]);
         if (KIND == SRC_ACT2) {
             float u[8];
-            load8<bf16>(xb + (size_t)p * C + c0, u);
+            raw_to_float(rb, u);
 #pragma unroll
             for (int c = 0; c < 8; ++c) x[c] += relu_affine(u[c], sb[c], tb[c]);
         }
@@ -1508,20 +1510,38 @@ __global__ __launch_bounds__(256) void head_blend_kernel(HeadBlendArgs a) {
             z[k] = acc + bias[k];
         }
         // blend (annonet_infer.cpp:116-164): lane `sub` owns class `sub`
-        const int y = (int)(p / b.tile_w), xx = (int)(p - (int64_t)y * b.tile_w);
-        const long long bx = (long long)b.tile_left + xx, by = (long long)b.tile_top + y;
-        if (sub >= K || by < b.full[1] || by > b.full[3] || by < 0 || by >= b.img_h || bx < b.full[0] || bx > b.full[2] || bx < 0 || bx >= b.img_w) continue;
+        // (a tile has < 2^31 pixels and its rectangles lie within int range: 32-bit arithmetic — the 64-bit division and compares
+        // of the first version were a third of this kernel's instructions)
+        const unsigned up = (unsigned)p, uw = (unsigned)b.tile_w;
+        const int y = (int)(up / uw), xx = (int)(up - (unsigned)y * uw);
+        const int bx = b.tile_left + xx, by = b.tile_top + y;
+        if (sub >= K || by < f1 || by > f3 || by < 0 || by >= b.img_h || bx < f0 || bx > f2 || bx < 0 || bx >= b.img_w) return;
         float in = z[0];
 #pragma unroll
         for (int k = 1; k < KM; ++k) in = sub == k ? z[k] : in;
         float* out = b.blended + ((size_t)sub * b.img_h + by) * b.img_w + bx;
-        const bool inside_unique = bx >= b.unique[0] && bx <= b.unique[2] && by >= b.unique[1] && by <= b.unique[3];
+        const bool inside_unique = bx >= u0 && bx <= u2 && by >= u1 && by <= u3;
         if (inside_unique) *out = in;
         else {
             const double th = ramp(bx, b.full[0], b.unique[0], b.unique[2], b.full[2]);
             const double tv = ramp(by, b.full[1], b.unique[1], b.unique[3], b.full[3]);
             *out = (float)__dadd_rn((double)*out, __dmul_rn(__dmul_rn(th, tv), (double)in));  // float += double * float
         }
+    };
+    // four pixel records per thread in flight (unconditional loads from clamped indices), then the four are processed: the pass is a
+    // stream of 64-byte records, and one dependent load -> compute -> store chain per iteration left it at a third of the HBM rate
+    constexpr int U = 4;
+    for (int64_t p0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2; p0 < pixels; p0 += U * stride) {
+        Raw8<bf16> ra[U], rb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t pc = min(p0 + u * stride, pixels - 1);
+            ra[u] = raw_load8(xa + (size_t)pc * C + c0);
+            if (KIND == SRC_ACT2) rb[u] = raw_load8(xb + (size_t)pc * C + c0); else rb[u] = ra[u];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (p0 + u * stride < pixels) process(p0 + u * stride, ra[u], rb[u]);   // the four lanes of a pixel agree on this branch
     }
 }
 
@@ -1907,7 +1927,7 @@ void launch_head_blend(const HeadBlendArgs& a, hipStream_t s) {
     ANH_REQUIRE(head_blend_supported(a), "head_blend: unsupported shape");
     const int64_t pixels = (int64_t)a.blend.tile_h * a.blend.tile_w;
     if (pixels <= 0) return;
-    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((pixels * 4 + 255) / 256, 4096));
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((pixels * 4 + 255) / 256, 2048));   // 8 workgroups per CU, >= 5 rounds of four pixels per thread on a 1024^2 tile
     if (a.src.kind == SRC_ACT) hipLaunchKernelGGL(head_blend_kernel<SRC_ACT>, dim3(blocks), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(head_blend_kernel<SRC_ACT2>, dim3(blocks), dim3(256), 0, s, a);
     HIP_CHECK(hipGetLastError());
