@@ -117,25 +117,38 @@ class OverlapExchange:
 class LabelGather:
     """ONE label map on one rank from the ranks' shares of a sharded annonet_infer().  After the overlap exchange a rank's labels
     are right exactly where ITS tiles cover the image (elsewhere its planes hold nothing); two ranks that share a pixel hold the
-    same sums there, hence the same label.  So every rank codes its covered pixels as label + 1 (0 = "not mine", 255 = the
-    all-NaN label 65535) and ONE reduce(MAX) — a single collective of H x W bytes — assembles the map on `dst`."""
+    same sums there, hence the same label.  Every rank codes its covered pixels as label + 1 (0 = "not mine", 255 = the all-NaN
+    label 65535) and sends the ROWS its tiles touch — one byte per pixel, point to point — to `dst`, which merges each band with an
+    elementwise maximum.  `dst` receives H x W bytes (plus the overlap rows) over its direct xGMI links to the other ranks; a
+    reduce(MAX) of full-size maps would move H x W bytes per rank around the ring."""
 
     def __init__(self, tiles, world_size, rank, width, height, device, classes):
         import torch
         if classes > 253:
             raise ValueError("LabelGather codes labels in one byte: at most 253 classes")
-        mask = np.zeros((height, width), dtype=bool)
+        self.rank, self.world, self.width, self.height = rank, world_size, width, height
+        self.rows = []                                    # [row0, row1) of every rank's tiles (the same list on every rank)
+        for r in range(world_size):
+            mine = shard_tiles(tiles, r, world_size)
+            if mine:
+                self.rows.append((max(0, min(t[0][1] for t in mine)), min(height, max(t[0][3] for t in mine) + 1)))
+            else:
+                self.rows.append((0, 0))
+        row0, row1 = self.rows[rank]
+        mask = np.zeros((max(row1 - row0, 0), width), dtype=bool)
         for (full, _) in shard_tiles(tiles, rank, world_size):
             l, t, r, b = max(full[0], 0), max(full[1], 0), min(full[2], width - 1), min(full[3], height - 1)
             if l <= r and t <= b:
-                mask[t:b + 1, l:r + 1] = True
-        self.mask = torch.from_numpy(mask).to(device)
+                mask[t - row0:b + 1 - row0, l:r + 1] = True
+        self.mask = torch.from_numpy(mask).to(device)     # which pixels of this rank's row band its tiles cover
 
     def code(self, labels):
+        """this rank's row band of `labels` ([H, W] int16) as bytes: label + 1 where its tiles cover the pixel, else 0"""
         import torch
-        wide = labels.to(torch.int32) & 0xFFFF
+        row0, row1 = self.rows[self.rank]
+        wide = labels[row0:row1].to(torch.int32) & 0xFFFF
         coded = torch.where(wide == 65535, torch.full_like(wide, 255), wide + 1)
-        return torch.where(self.mask, coded, torch.zeros_like(coded)).to(torch.uint8)
+        return torch.where(self.mask, coded, torch.zeros_like(coded)).to(torch.uint8).contiguous()
 
     @staticmethod
     def decode(coded):
@@ -143,12 +156,40 @@ class LabelGather:
         wide = coded.to(torch.int32)
         return torch.where(wide == 255, torch.full_like(wide, 65535), wide - 1).to(torch.int16)   # (u16 bit pattern in an int16 tensor)
 
+    def merge(self, bands):
+        """bands[r] = rank r's coded row band (or None for a rank without tiles) -> the coded [H, W] map"""
+        import torch
+        first = next(b for b in bands if b is not None)
+        whole = torch.zeros((self.height, self.width), dtype=torch.uint8, device=first.device)
+        for (row0, row1), band in zip(self.rows, bands):
+            if band is not None and row1 > row0:
+                torch.maximum(whole[row0:row1], band, out=whole[row0:row1])
+        return whole
+
     def run(self, labels, group=None, dst=0):
         """labels: this rank's [H, W] int16 map -> the assembled map on rank `dst` (None elsewhere)"""
+        import torch
         import torch.distributed as dist
-        coded = self.code(labels)
-        dist.reduce(coded, dst=dst, op=dist.ReduceOp.MAX, group=group)
-        return self.decode(coded) if dist.get_rank(group) == dst else None
+        mine = self.code(labels)
+        if self.rank != dst:
+            if mine.numel():
+                for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, mine, dst, group)]):
+                    w.wait()
+            return None
+        bands, ops = [], []
+        for r, (row0, row1) in enumerate(self.rows):
+            if r == dst:
+                bands.append(mine if mine.numel() else None)
+            elif row1 > row0:
+                buf = torch.empty((row1 - row0, self.width), dtype=torch.uint8, device=mine.device)
+                bands.append(buf)
+                ops.append(dist.P2POp(dist.irecv, buf, r, group))
+            else:
+                bands.append(None)
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        return self.decode(self.merge(bands))
 
 
 def sharded_infer(net, image, labels, blended, tiles, rank, world_size, exchange, tiling_parameters=None, gains=None, group=None, stream=None):

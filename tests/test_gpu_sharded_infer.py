@@ -46,15 +46,16 @@ def test_sharded_inference_assembles_the_single_process_result(world):
         owner = aad.tile_owner(len(tiles), world)
         got_lab = np.full((H, W), -1, dtype=np.int64)
         got_pl = np.zeros((3, H, W), dtype=np.float32)
-        coded = None                 # step 4: LabelGather — what dist.reduce(MAX) of the ranks' coded maps leaves on rank 0
+        bands, gather0 = [], None    # step 4: LabelGather — the coded row bands rank 0 receives, merged there
         for r in range(world):       # steps 2b + 3: scatter the sums back, label the rank's rows
             ex.unpack(planes[r], total)
             lab = torch.zeros((H, W), dtype=torch.int16, device=dev)
             mine = aad.shard_tiles(tiles, r, world)
             row0, row1 = max(0, min(x[0][1] for x in mine)), min(H, max(x[0][3] for x in mine) + 1)
             aa.argmax_device(net, planes[r].data_ptr(), H, W, row0, row1, lab.data_ptr(), gains=gains)
-            c = aad.LabelGather(tiles, world, r, W, H, dev, 3).code(lab)
-            coded = c if coded is None else torch.maximum(coded, c)
+            g = aad.LabelGather(tiles, world, r, W, H, dev, 3)
+            gather0 = gather0 or g
+            bands.append(g.code(lab))
             torch.cuda.synchronize()
             lab_np, pl_np = lab.cpu().numpy().view(np.uint16), planes[r].cpu().numpy()
             for i, (full, _) in enumerate(tiles):   # a rank answers for the pixels its tiles cover
@@ -67,7 +68,7 @@ def test_sharded_inference_assembles_the_single_process_result(world):
                 got_lab[tp_:b + 1, l:rr + 1] = new
                 got_pl[:, tp_:b + 1, l:rr + 1] = pl_np[:, tp_:b + 1, l:rr + 1]
     assert (got_lab >= 0).all()
-    np.testing.assert_array_equal(aad.LabelGather.decode(coded).cpu().numpy().view(np.uint16).astype(np.int64), got_lab)   # the ONE map of the job
+    np.testing.assert_array_equal(aad.LabelGather.decode(gather0.merge(bands)).cpu().numpy().view(np.uint16).astype(np.int64), got_lab)   # the ONE map of the job
     want_pl_np, want_lab_np = want_pl.cpu().numpy(), want_lab.cpu().numpy().view(np.uint16).astype(np.int64)
     span = float(want_pl_np.max() - want_pl_np.min())
     np.testing.assert_allclose(got_pl, want_pl_np, rtol=0, atol=2e-6 * span)      # (a+b)+(c+d) vs ((a+b)+c)+d in four-tile corners
