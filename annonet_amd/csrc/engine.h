@@ -43,7 +43,6 @@ class Profiler {
 struct LayerState {
     DevBuf raw;    // raw conv output y (storage dtype), [n][h][w][cout]
     DevBuf dact;   // gradient w.r.t. this layer's post-activation output; becomes dy in place on the unfused path
-    DevBuf dyp;    // dy written out of place (second stream) when the backward-data conv applies bn backward in its prologue
     DevBuf bn;     // mean, invstd, scale, shift (4*C floats) then var (C doubles)
     float* mean = nullptr; float* invstd = nullptr; float* scale = nullptr; float* shift = nullptr; double* var = nullptr;
     float* coef = nullptr;  // bn backward coefficients [3][C] of this layer (its own slot: two streams read them)

@@ -276,7 +276,7 @@ void Engine::plan_dims(int n, int h, int w) {
         const size_t elems = (size_t)n * s.h * s.w * L.cout;
         if (L.has_bn) {
             s.raw.reserve(elems * es);
-            if (training) { s.dact.reserve(elems * es); if (bn_bwd_apply_fusion_enabled()) s.dyp.reserve(elems * es); }
+            if (training) s.dact.reserve(elems * es);
             // the conv kernels that fuse the statistics write one partial per workgroup (at most 1024 workgroups)
             bn_need = std::max(bn_need, (size_t)std::max(bn_partial_blocks((int64_t)n * s.h * s.w), 1024) * 2 * L.cout * sizeof(double));
         }
@@ -460,11 +460,11 @@ void Engine::backward(const uint16_t* d_labels, const float* d_weights, double l
             hp.bwd_partials.reserve((size_t)head_bnred_blocks * 2 * head.cin * sizeof(double));
             t.bnred_mean = hp.mean; t.bnred_invstd = hp.invstd; t.bnred_partials = hp.bwd_partials.as<double>();
             // ... and then nothing needs da in memory: the layer's bn_bwd_apply pass recomputes it from the dlogits (k floats per pixel
-            // instead of 32 storage elements written here and read there).  The rejected fusions read da through a conv prologue: not for them.
+            // instead of 32 storage elements written here and read there).
             static const bool virtual_da = !(getenv("ANH_HEAD_DA_VIRTUAL") && atoi(getenv("ANH_HEAD_DA_VIRTUAL")) == 0);
             int readers = 0;   // a second consumer of that layer would ADD its gradient to the da in memory
             for (const anh_layer_desc& X : spec.layers) readers += (X.in_a == head.in_a) + (X.in_b == head.in_a);
-            if (virtual_da && readers == 1 && bn_bwd_apply_fusion_mode() == 0 && !getenv("ANH_FORCE_FUSED_APPLY")) { t.da = nullptr; t.dlogits = dlogits.as<float>(); head_da_virtual = true; }
+            if (virtual_da && readers == 1) { t.da = nullptr; t.dlogits = dlogits.as<float>(); head_da_virtual = true; }
         }
         const int tok = prof.begin(stream, "head_fused_fwd_loss_bwd", 2.0 * 3 * head.cin * head.cout * (double)P, (double)P * (head.cin * es * (head_da_virtual ? 1 : 2) + head.cout * (head_da_virtual ? 8.0 : 4.0) + 6.0));
         launch_head_train(t, stream);
@@ -512,10 +512,11 @@ void Engine::backward(const uint16_t* d_labels, const float* d_weights, double l
             dg.out = ls[L.in_a].dact.p; dg.out_dtype = dtype; dg.out_accumulate = ls[L.in_a].dact_written ? 1 : 0;
             if (L.in_b >= 0) { dg.out2 = ls[L.in_b].dact.p; dg.out2_accumulate = ls[L.in_b].dact_written ? 1 : 0; }
         }
-        // Fused schedule (two streams, MFMA path): the main stream runs reduce -> finalize -> backward-data conv, the conv
-        // applying bn + relu backward to (da, y) while staging; the elementwise apply pass — needed by the filter gradient
-        // only — runs out of place on the second stream ahead of that layer's wgrad.
-        bool fused_apply = false, wgrad_computes_dy = false, dgrad_writes_dy = false;
+        // bn + relu backward of this layer: sums (left by the conv that wrote da, else a reduce pass) -> finalize -> one elementwise
+        // apply pass that turns da into dy in place, read by the backward-data conv (this stream) and the filter gradient (second
+        // stream).  Every attempt to fold that pass into a conv's staging lost; the stem, which has no backward-data
+        // conv, folds it into its filter-gradient kernel.
+        bool wgrad_computes_dy = false;
         if (L.has_bn) {
             ANH_REQUIRE(s.dact_written, "internal: layer output has no consumer");
             BnBwdArgs b;
@@ -536,25 +537,6 @@ void Engine::backward(const uint16_t* d_labels, const float* d_weights, double l
             tok = prof.begin(stream, "bn_bwd_finalize", 0, (double)(b.partial_blocks > 0 ? b.partial_blocks : bn_partial_blocks(p_out)) * L.cout * 16.0);
             launch_bn_bwd_finalize(b, stream);
             prof.end(stream, tok);
-            const bool dgrad_fuses = has_dgrad && dtype == DT_BF16 && conv_takes_mfma(dg, dtype) && conv_accepts_bnbwd(dg);
-            static const bool force_fused = getenv("ANH_FORCE_FUSED_APPLY") != nullptr;  // experiment: fused schedule on one stream
-            if (dgrad_fuses && bn_bwd_apply_fusion_mode() == 2) {
-                // the backward-data conv computes dy = bn + relu backward of (da, y) while staging and also WRITES it: no apply
-                // pass; the filter gradient (second stream) starts once that conv is done
-                ConvArgs probe = dg;
-                probe.src.kind = SRC_BNBWD;
-                dgrad_writes_dy = conv_writes_dy(probe);
-            }
-            fused_apply = dgrad_writes_dy || (two_streams && dgrad_fuses) || (force_fused && dgrad_fuses);
-            hipStream_t apply_on = stream;
-            if (fused_apply && !two_streams) b.dy_out = s.dyp.p;
-            if (fused_apply && two_streams && !dgrad_writes_dy) {
-                HIP_CHECK(hipEventRecord(ev_dy_ready, stream));   // coefficients final: the second stream may produce dy
-                HIP_CHECK(hipStreamWaitEvent(aux_stream, ev_dy_ready, 0));
-                apply_on = aux_stream;
-                if (has_dgrad) b.dy_out = s.dyp.p;               // da stays intact for the conv on the main stream
-            }
-            if (dgrad_writes_dy) b.dy_out = s.dyp.p;
             // a layer without backward-data conv (the stem): only its filter gradient consumes dy, and the stem wgrad
             // kernel can compute dy from (da, y) while staging -> no apply pass on the critical path
             WgradArgs probe;
@@ -562,18 +544,13 @@ void Engine::backward(const uint16_t* d_labels, const float* d_weights, double l
             probe.n = s.n; probe.h_in = s.h_in; probe.w_in = s.w_in; probe.c_in = L.cin; probe.h_out = s.h; probe.w_out = s.w; probe.c_out = L.cout;
             probe.k = L.k; probe.stride = L.stride; probe.pad = L.pad; probe.gather = L.type;
             wgrad_computes_dy = !has_dgrad && wgrad_accepts_bnbwd(probe, dtype);
-            if (!wgrad_computes_dy && !dgrad_writes_dy) {
-                tok = prof.begin(apply_on, "bn_bwd_apply", 0, b.head_g ? (double)p_out * (L.cout * es * 2 + head.cout * 4.0) : (double)p_out * L.cout * es * 3);
-                launch_bn_bwd_apply(b, apply_on);
-                prof.end(apply_on, tok);
+            if (!wgrad_computes_dy) {
+                tok = prof.begin(stream, "bn_bwd_apply", 0, b.head_g ? (double)p_out * (L.cout * es * 2 + head.cout * 4.0) : (double)p_out * L.cout * es * 3);
+                launch_bn_bwd_apply(b, stream);
+                prof.end(stream, tok);
             }
-            dy = b.dy_out ? b.dy_out : s.dact.p; dy_dt = dtype;
-            if (fused_apply && has_dgrad) {
-                dg.src.kind = SRC_BNBWD; dg.src.a = s.dact.p; dg.src.b = s.raw.p;
-                dg.src.a_scale = s.scale; dg.src.a_shift = s.shift;
-                dg.src.bn_mean = s.mean; dg.src.bn_invstd = s.invstd; dg.src.bn_coef = s.coef;
-                if (dgrad_writes_dy) dg.dy_out = s.dyp.p;
-            } else if (has_dgrad) dg.src.a = dy;
+            dy = s.dact.p; dy_dt = dtype;
+            if (has_dgrad) dg.src.a = dy;
         } else { dy = dlogits.p; dy_dt = DT_F32; if (has_dgrad) dg.src.a = dy; }
 
         auto run_wgrad = [&]() {   // filter gradient
@@ -596,10 +573,8 @@ void Engine::backward(const uint16_t* d_labels, const float* d_weights, double l
             static const bool tail_on_main = getenv("ANH_STEM_WGRAD_MAIN") ? atoi(getenv("ANH_STEM_WGRAD_MAIN")) != 0 : true;
             const bool on_main = two_streams && !has_dgrad && tail_on_main;
             if (two_streams && !on_main) {
-                if (!fused_apply || dgrad_writes_dy) {   // dy of this layer is final on the main stream: let the second stream pick it up
-                    HIP_CHECK(hipEventRecord(ev_dy_ready, stream));
-                    HIP_CHECK(hipStreamWaitEvent(aux_stream, ev_dy_ready, 0));
-                }
+                HIP_CHECK(hipEventRecord(ev_dy_ready, stream));   // dy of this layer is final on the main stream: let the second stream pick it up
+                HIP_CHECK(hipStreamWaitEvent(aux_stream, ev_dy_ready, 0));
                 on = aux_stream;
             }
             wgrad_dispatch(g, (std::string("wgrad_") + layer_tag(li, L)).c_str(), flops, bytes, on, on_main ? wgrad_partials_main : wgrad_partials);
@@ -619,13 +594,12 @@ void Engine::backward(const uint16_t* d_labels, const float* d_weights, double l
                     P.fused_bwd_blocks = blocks;
                 }
             }
-            const double bytes = (double)p_out * L.cout * (L.has_bn ? es : 4.0) * (dg.src.kind == SRC_BNBWD ? (dg.dy_out ? 3 : 2) : 1) +
+            const double bytes = (double)p_out * L.cout * (L.has_bn ? es : 4.0) +
                                  (double)p_in * L.cin * es * (L.in_b >= 0 ? 2 : 1) * (dg.out_accumulate ? 2 : 1);
             conv_dispatch(dg, (std::string("dgrad_") + layer_tag(li, L)).c_str(), flops, bytes);
         };
-        // the filter gradient reads dy: when the backward-data conv is the kernel that writes dy, it goes first
-        if (dgrad_writes_dy) { run_dgrad(); run_wgrad(); }
-        else { run_wgrad(); if (has_dgrad) run_dgrad(); }
+        run_wgrad();
+        if (has_dgrad) run_dgrad();
     }
     if (concurrent_wgrad && aux_stream) {  // gradients are complete on the main stream only after the aux stream drains
         HIP_CHECK(hipEventRecord(ev_aux_done, aux_stream));

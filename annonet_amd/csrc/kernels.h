@@ -15,13 +15,10 @@ enum SrcKind {
     SRC_RAW = 0,    // value = a[i]
     SRC_ACT = 1,    // value = relu(a[i]*scale_a[c] + shift_a[c])
     SRC_ACT2 = 2,   // value = relu(a[i]*scale_a[c]+shift_a[c]) + relu(b[i]*scale_b[c]+shift_b[c])   (skip add)
-    SRC_IMAGE = 3,  // value = u8 image / 256, read through a clamp-to-edge window (annonet_infer.cpp:68-75)
-    // value = the batch-norm + relu BACKWARD of a layer, applied on the fly (backward-data convs on the MFMA path):
-    //   a = da (gradient w.r.t. the layer's post-activation output), b = y (its raw conv output),
-    //   dz = (y*scale + shift > 0) ? da : 0,  value = coef0 * (dz - coef1 - (y - mean)*invstd * coef2)
-    // with a_scale/a_shift = the layer's folded (scale, shift) and bn_mean / bn_invstd / bn_coef ([3][C], from the
-    // bn backward finalize kernel) — the same expression, in the same order, as the bn_bwd_apply kernels.
-    SRC_BNBWD = 4
+    SRC_IMAGE = 3   // value = u8 image / 256, read through a clamp-to-edge window (annonet_infer.cpp:68-75)
+    // (A fifth kind — the bn + relu BACKWARD of a layer applied by a backward-data conv while staging, in three schedules — was built
+    // and measured in rounds 1 and 2 and lost every time; it is gone.  The stem's filter gradient, which has no
+    // backward-data conv beside it, still applies that expression while staging: WgradArgs::dy_y.)
 };
 
 struct Src {
@@ -29,7 +26,6 @@ struct Src {
     int dtype = DT_F32;
     const void* a = nullptr; const float* a_scale = nullptr; const float* a_shift = nullptr;
     const void* b = nullptr; const float* b_scale = nullptr; const float* b_shift = nullptr;
-    const float* bn_mean = nullptr; const float* bn_invstd = nullptr; const float* bn_coef = nullptr;  // SRC_BNBWD
     // SRC_IMAGE: sample n lives at img + n*img_sample_stride; the net input window starts at (img_left, img_top)
     const uint8_t* img = nullptr;
     int img_h = 0, img_w = 0, img_left = 0, img_top = 0;
@@ -64,10 +60,6 @@ struct ConvArgs {
     const void* bnred_y = nullptr;
     const float* bnred_scale = nullptr; const float* bnred_shift = nullptr; const float* bnred_mean = nullptr; const float* bnred_invstd = nullptr;
     double* bnred_partials = nullptr;
-    // SRC_BNBWD only: the staging waves also write the dy they compute ([n][h_in][w_in][c_red], storage dtype) — every
-    // input pixel belongs to the core of exactly one pixel tile — so that the layer's filter gradient reads dy instead of
-    // recomputing it and no separate bn backward apply pass runs (conv_writes_dy() says whether the layer's kernel does)
-    void* dy_out = nullptr;
 };
 
 // dw[tap][ci][co] = sum_pixels src(n, iy, ix, ci) * dy[n,oy,ox,co]; same gather convention as ConvArgs.
@@ -82,7 +74,8 @@ struct WgradArgs {
     int64_t partials_capacity = 0;
     int* splits_out = nullptr;  // when set: the partial-sum pass is left to the caller (launch_reduce_partials with *splits_out)
     // dy not materialised (wgrad_accepts_bnbwd): `dy` points at da, and dy = bn + relu backward of (da, dy_y) is applied
-    // while staging — the expression of SRC_BNBWD / bn_bwd_apply with this layer's constants
+    // while staging — the expression of the bn_bwd_apply kernels with this layer's constants:
+    //   dz = (y*scale + shift > 0) ? da : 0,  dy = coef0 * (dz - coef1 - (y - mean)*invstd * coef2)
     const void* dy_y = nullptr;
     const float* dy_scale = nullptr; const float* dy_shift = nullptr; const float* dy_mean = nullptr; const float* dy_invstd = nullptr;
     const float* dy_coef = nullptr;
@@ -261,13 +254,6 @@ void launch_conv_mfma(const ConvArgs& a, hipStream_t s);
 // value is the number of partials per channel to pass to launch_bn_forward_finalize)
 int conv_fused_stat_blocks(const ConvArgs& a);
 int conv_fused_bnred_blocks(const ConvArgs& a);   // same for ConvArgs::bnred_partials (backward-data convs)
-// the layer's MFMA kernel can read its input through SRC_BNBWD (decided on the args with src.kind = SRC_RAW)
-bool conv_accepts_bnbwd(const ConvArgs& a);
-// ANH_FUSE_BN_BWD_APPLY: 0 = separate apply pass, 1 = backward-data conv applies bn backward in its prologue and the apply
-// pass runs on the second stream, 2 = that conv also writes dy (ConvArgs::dy_out): no apply pass at all
-int bn_bwd_apply_fusion_mode();
-inline bool bn_bwd_apply_fusion_enabled() { return bn_bwd_apply_fusion_mode() != 0; }
-bool conv_writes_dy(const ConvArgs& a);   // decided on the args with src.kind = SRC_BNBWD
 bool mfma_wgrad_supported(const WgradArgs& a);
 void launch_wgrad_mfma(const WgradArgs& a, hipStream_t s);
 int64_t wgrad_mfma_scratch_floats(const WgradArgs& a);

@@ -523,7 +523,7 @@ bool conv_f32_mfma_ok(const ConvArgs& a) {
     static const int on = getenv("ANH_FP32_MFMA") ? atoi(getenv("ANH_FP32_MFMA")) : 1;
     const bool in_f32 = a.src.kind == SRC_IMAGE || a.src.dtype == DT_F32;
     const bool out_f32 = a.out_nchw || a.out_dtype == DT_F32;
-    return on && in_f32 && out_f32 && a.src.kind != SRC_BNBWD && !a.out_accumulate && !a.out2 && !a.stat_partials && !a.bnred_partials;
+    return on && in_f32 && out_f32 && !a.out_accumulate && !a.out2 && !a.stat_partials && !a.bnred_partials;
 }
 
 template <int NT>

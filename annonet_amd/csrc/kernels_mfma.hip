@@ -330,7 +330,7 @@ __device__ __forceinline__ void side_commit(const SideRegs<KIND, ITEMS>& R, char
 // prologue of one 16-byte chunk with the per-channel constants given as pointers (registers or an LDS table)
 template <int KIND>
 __device__ __forceinline__ uint4 chunk_convert(const RawChunk<KIND>& r, const float* sa, const float* ta, const float* sb, const float* tb) {
-    if (KIND == SRC_RAW || KIND == SRC_BNBWD) return r.a;  // (SRC_BNBWD goes through chunk_bnbwd)
+    if (KIND == SRC_RAW) return r.a;
     if (KIND == SRC_ACT) return affine_relu_pack8(r.a, sa, ta);
     float v[8];
     affine8(r.a, sa, ta, v);
@@ -343,7 +343,7 @@ __device__ __forceinline__ uint4 chunk_convert(const RawChunk<KIND>& r, const fl
     return make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
 }
 
-// SRC_BNBWD prologue of one 16-byte chunk: a = da, b = y; the expression and its order are those of bn_bwd_apply_vec_kernel
+// bn + relu backward of one 16-byte chunk (the stem's filter gradient applies it while staging): a = da, b = y; the expression and its order are those of bn_bwd_apply_vec_kernel
 __device__ __forceinline__ uint4 chunk_bnbwd(const uint4& da, const uint4& y, const float* sc, const float* sf, const float* m, const float* is,
                                              const float* k0, const float* k1, const float* k2) {
     const unsigned wd[4] = {da.x, da.y, da.z, da.w}, wy[4] = {y.x, y.y, y.z, y.w};
@@ -575,7 +575,7 @@ template <int KIND>
 __device__ __forceinline__ RawChunk<KIND> side_load_at(const bf16* a, const bf16* b, int off) {
     RawChunk<KIND> r;
     r.a = *reinterpret_cast<const uint4*>(a + off);
-    if (KIND == SRC_ACT2 || KIND == SRC_BNBWD) r.b = *reinterpret_cast<const uint4*>(b + off);
+    if (KIND == SRC_ACT2) r.b = *reinterpret_cast<const uint4*>(b + off);
     return r;
 }
 
@@ -944,8 +944,6 @@ struct GeoS1 {
     __device__ static void decode(int rec, int& py, int& px, int& key) { py = rec / PW; px = rec - py * PW; key = (px >> 2) & 3; }
     __device__ static int in_y0(int ty) { return ty * TH - 1; }
     __device__ static int in_x0(int tx) { return tx * TW - 1; }
-    // core of a patch = the input pixels no other tile's core holds (the rest is halo): every in-tensor pixel is core once
-    __device__ static bool core(int py, int px, bool, bool) { return py >= 1 && py <= TH && px >= 1 && px <= TW; }
     static constexpr int NB = 3;  // one lane base per kx
     struct Bases { const char* x[3][2]; };
     __device__ static void init(Bases& b, const char* lds_x, int wave, int col, int half) {
@@ -997,8 +995,6 @@ struct GeoDown {
     }
     __device__ static int in_y0(int ty) { return ty * 8; }
     __device__ static int in_x0(int tx) { return tx * 64; }
-    // the ninth row / 65th column is the next tile's first one, except behind the last tile row / column
-    __device__ static bool core(int py, int px, bool last_y, bool last_x) { return (py < 8 || last_y) && (px < 64 || last_x); }
     static constexpr int NB = 2;
     struct Bases { const char* x[2][2]; };  // [kx >> 1][ks]
     __device__ static void init(Bases& b, const char* lds_x, int wave, int col, int half) {
@@ -1037,7 +1033,6 @@ struct GeoUp {
     __device__ static void decode(int rec, int& py, int& px, int& key) { py = rec / 33; px = rec - py * 33; key = (px >> 2) & 3; }
     __device__ static int in_y0(int ty) { return ty * 4 - 1; }
     __device__ static int in_x0(int tx) { return tx * 32 - 1; }
-    __device__ static bool core(int py, int px, bool, bool) { return py >= 1 && px >= 1; }
     static constexpr int NB = 2;
     struct Bases { const char* x[2][2]; };  // [ib][ks]: input column j - ib, row i - 1 (the immediate adds a row for ia = 0)
     __device__ static void init(Bases& b, const char* lds_x, int wave, int col, int half) {
@@ -1130,24 +1125,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
     const bool fuse_stats = CAN_STATS && a.stat_partials != nullptr;   // forward: bn statistics of the output
     const bool fuse_bnred = !FWD && CAN_STATS && a.bnred_partials != nullptr;  // backward-data: dgamma / dbeta sums of the layer `out` belongs to
     const int stat_mode = fuse_stats ? 1 : fuse_bnred ? 2 : 0;
-    float* bnc = tab + c_red * (KIND == SRC_BNBWD ? 7 : 4);            // [scale | shift | mean | invstd][C_OUT] of this workgroup's channels
+    float* bnc = tab + c_red * 4;            // [scale | shift | mean | invstd][C_OUT] of this workgroup's channels
 
     int tile = blockIdx.x, slab = 0, it = 0;
     auto init_tables = [&]() __attribute__((always_inline)) {   // every thread of the workgroup, from either branch below
-        if (KIND != SRC_RAW) {  // SRC_BNBWD: [scale | shift | mean | invstd | coef0 | coef1 | coef2][c_red]
+        if (KIND != SRC_RAW) {
             for (int i = threadIdx.x; i < c_red; i += 512) {
                 tab[i] = a.src.a_scale[i];
                 tab[c_red + i] = a.src.a_shift[i];
-                if (KIND == SRC_BNBWD) {
-                    tab[2 * c_red + i] = a.src.bn_mean[i];
-                    tab[3 * c_red + i] = a.src.bn_invstd[i];
-                    tab[4 * c_red + i] = a.src.bn_coef[i];
-                    tab[5 * c_red + i] = a.src.bn_coef[c_red + i];
-                    tab[6 * c_red + i] = a.src.bn_coef[2 * c_red + i];
-                } else {
-                    tab[2 * c_red + i] = KIND == SRC_ACT2 ? a.src.b_scale[i] : 0.f;
-                    tab[3 * c_red + i] = KIND == SRC_ACT2 ? a.src.b_shift[i] : 0.f;
-                }
+                tab[2 * c_red + i] = KIND == SRC_ACT2 ? a.src.b_scale[i] : 0.f;
+                tab[3 * c_red + i] = KIND == SRC_ACT2 ? a.src.b_shift[i] : 0.f;
             }
         }
         if (fuse_bnred) {
@@ -1191,24 +1178,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
         // committed, so a load has a whole item period to arrive instead of the hand-over barrier alone (the producers used to
         // spend their commit phase waiting for loads issued one barrier earlier: r02_sq_counters, SQ_WAIT_ANY 40-55 %) ----
         // The filter slab of the NEXT item is fetched one item ahead into one shared register set: it comes from L2 (every workgroup
-        // reads the same filter), and a second set would cost 36 VGPRs at 64 output channels.  Kinds with two operands per chunk
-        // and many chunks (or the seven-table bn-backward prologue) keep ONE patch set: two would spill.
+        // reads the same filter), and a second set would cost 36 VGPRs at 64 output channels.  The skip-add kind on the 594-record
+        // patch keeps ONE patch set: two would spill.
     #ifndef ANH_WS_DEEP2
     #define ANH_WS_DEEP2 0
     #endif
-        constexpr bool DEEP2 = ANH_WS_DEEP2 && KIND != SRC_BNBWD && !(KIND == SRC_ACT2 && NP > 6);
+        constexpr bool DEEP2 = ANH_WS_DEEP2 && !(KIND == SRC_ACT2 && NP > 6);
         u32x4 wraw[NW];  // a native vector type: hipcc keeps a HIP uint4 that is only copied (never unpacked) in scratch
         struct Fetched {
             RawChunk<KIND> praw[NP];
             unsigned pok;
-            // SRC_BNBWD with ConvArgs::dy_out: the dy chunks this thread computes for the CORE pixels of its patch also go to memory
-            // (first channel group only: the groups stage the same patches) — poff / pcore / dyo describe the fetched item
-            int poff[KIND == SRC_BNBWD ? NP : 1];
-            unsigned pcore;
-            bf16* dyo;
         };
         Fetched R0, R1;
-        const bool write_dy = KIND == SRC_BNBWD && a.dy_out != nullptr && blockIdx.y == 0;
         // the fetch cursor runs two items ahead of the commits.  Its tile coordinates advance incrementally (no division per item)
         // and the chunk offsets / validity bits of its tile are computed once per tile, not once per (tile, slab) item.
         const int gstep = (int)gridDim.x, per_img = tiles_x * tiles_y;
@@ -1216,30 +1197,25 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
         int ftile = blockIdx.x, fslab = 0;
         int ftx = ftile % tiles_x, fty = (ftile / tiles_x) % tiles_y, fn = ftile / per_img;
         int foff[NP];
-        unsigned fpok = 0, fpcore = 0;
+        unsigned fpok = 0;
         auto enter_tile = [&]() __attribute__((always_inline)) {
             const int x0 = G::in_x0(ftx), y0 = G::in_y0(fty);
-            fpok = 0; fpcore = 0;
+            fpok = 0;
     #pragma unroll
             for (int jj = 0; jj < NP; ++jj) {
                 const int iy = y0 + (pgeo[jj] & 255), ix = x0 + (pgeo[jj] >> 8);
                 const int cy = min(max(iy, 0), H - 1), cx = min(max(ix, 0), W - 1);
                 foff[jj] = (cy * W + cx) * c_red + c16 * 8;
                 fpok |= ((iy == cy && ix == cx) ? 1u : 0u) << jj;
-                if (KIND == SRC_BNBWD) fpcore |= (G::core(pgeo[jj] & 255, pgeo[jj] >> 8, fty == tiles_y - 1, ftx == tiles_x - 1) ? 1u : 0u) << jj;
             }
         };
         auto fetch = [&](Fetched& R) __attribute__((always_inline)) {
             const bf16* pa = xa + (size_t)fn * plane;
-            const bf16* pb = (KIND == SRC_ACT2 || KIND == SRC_BNBWD) ? xb + (size_t)fn * plane : nullptr;
+            const bf16* pb = KIND == SRC_ACT2 ? xb + (size_t)fn * plane : nullptr;
             const int cc = fslab * 32;
             R.pok = fpok;
-            if (KIND == SRC_BNBWD) { R.pcore = fpcore; R.dyo = reinterpret_cast<bf16*>(a.dy_out) + (size_t)fn * plane; }
     #pragma unroll
-            for (int jj = 0; jj < NP; ++jj) {
-                R.praw[jj] = side_load_at<KIND>(pa, pb, foff[jj] + cc);
-                if (KIND == SRC_BNBWD) R.poff[jj] = foff[jj] + cc;
-            }
+            for (int jj = 0; jj < NP; ++jj) R.praw[jj] = side_load_at<KIND>(pa, pb, foff[jj] + cc);
             if (++fslab == n_slabs) {   // cursor -> the workgroup's next tile
                 fslab = 0; ftile += gstep;
                 ftx += step_x; if (ftx >= tiles_x) { ftx -= tiles_x; ++fty; }
@@ -1257,27 +1233,21 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
             char* wbuf = lbuf + X_BYTES_;     // streaming form only
             // a single-slab layer's filter block goes into both buffers once (its registers are not refetched)
             const bool stage_w = !wres && (it < 2 || n_slabs > 1);
-            float sa[8], ta[8], sb[8], tb[8], q0[8], q1[8], q2[8];
+            float sa[8], ta[8], sb[8], tb[8];
             if (KIND != SRC_RAW) {
                 const float* t0 = tab + slab * 32 + c16 * 8;
     #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     sa[j] = t0[j]; ta[j] = t0[c_red + j];
-                    sb[j] = (KIND == SRC_ACT2 || KIND == SRC_BNBWD) ? t0[2 * c_red + j] : 0.f;
-                    tb[j] = (KIND == SRC_ACT2 || KIND == SRC_BNBWD) ? t0[3 * c_red + j] : 0.f;
-                    q0[j] = KIND == SRC_BNBWD ? t0[4 * c_red + j] : 0.f;
-                    q1[j] = KIND == SRC_BNBWD ? t0[5 * c_red + j] : 0.f;
-                    q2[j] = KIND == SRC_BNBWD ? t0[6 * c_red + j] : 0.f;
+                    sb[j] = KIND == SRC_ACT2 ? t0[2 * c_red + j] : 0.f;
+                    tb[j] = KIND == SRC_ACT2 ? t0[3 * c_red + j] : 0.f;
                 }
             }
     #pragma unroll
             for (int jj = 0; jj < NP; ++jj) {
-                uint4 v = KIND == SRC_BNBWD ? chunk_bnbwd(R.praw[jj].a, R.praw[jj].b, sa, ta, sb, tb, q0, q1, q2) : chunk_convert<KIND>(R.praw[jj], sa, ta, sb, tb);
+                uint4 v = chunk_convert<KIND>(R.praw[jj], sa, ta, sb, tb);
                 if (!((R.pok >> jj) & 1u)) v = make_uint4(0u, 0u, 0u, 0u);
                 if ((tid >> 2) + 64 * jj < G::RECS) *reinterpret_cast<uint4*>(lbuf + pdst[jj]) = v;
-                if (KIND == SRC_BNBWD) {
-                    if (write_dy && ((R.pok & R.pcore) >> jj & 1u) && (tid >> 2) + 64 * jj < G::RECS) *reinterpret_cast<uint4*>(R.dyo + R.poff[jj]) = v;
-                }
             }
             if (stage_w) {
     #pragma unroll
@@ -1475,7 +1445,7 @@ template <class G, int NT>
 void launch_ws(const ConvArgs& a, int tiles_x, int tiles_y, int flip, hipStream_t s) {
     const int n_tiles = tiles_x * tiles_y * a.n, groups = a.c_out / (NT * 32);
     const dim3 grid((unsigned)std::max(1, std::min(n_tiles, ws_target_wgs() / groups)), (unsigned)groups), block(512);
-    const size_t tables = (size_t)a.c_red * (a.src.kind == SRC_BNBWD ? 28 : 16) + (size_t)NT * 32 * 16;
+    const size_t tables = (size_t)a.c_red * 16 + (size_t)NT * 32 * 16;
     const size_t x_bytes = (size_t)G::RECS * 64, w_bytes = (size_t)9 * NT * 32 * 64;
     // filter-resident form: two reduction slabs (64 channels) whose filter blocks fit beside two patches; the end-of-kernel
     // statistics reduction borrows 32 NT KiB from the start of the buffer
@@ -1533,7 +1503,6 @@ void launch_ws(const ConvArgs& a, int tiles_x, int tiles_y, int flip, hipStream_
     switch (a.src.kind) {
         case SRC_RAW: launch(conv3x3_ws_kernel<G, NT, SRC_RAW>); break;
         case SRC_ACT: launch(conv3x3_ws_kernel<G, NT, SRC_ACT>); break;
-        case SRC_BNBWD: launch(conv3x3_ws_kernel<G, NT, SRC_BNBWD>); break;
         default: launch(conv3x3_ws_kernel<G, NT, SRC_ACT2>); break;
     }
     HIP_CHECK(hipGetLastError());
@@ -2101,14 +2070,13 @@ void launch_up(const ConvArgs& a, hipStream_t s) {
 
 }  // namespace
 
-namespace { bool bnbwd_form_ok(const ConvArgs& a); bool ws_form_ok(const ConvArgs& a); }
+namespace { bool ws_form_ok(const ConvArgs& a); }
 
 bool mfma_conv_supported(const ConvArgs& a) {
     if (stem_mfma_ok(a)) return true;
     if (a.k != 3 || !a.w_bf16) return false;
     if (a.src.kind == SRC_IMAGE || a.src.dtype != DT_BF16 || a.out_dtype != DT_BF16 || a.out_nchw || a.bias) return false;
     if (a.c_red % 32 != 0) return false;
-    if (a.src.kind == SRC_BNBWD && !bnbwd_form_ok(a)) return false;  // only the warp-specialised kernels carry that prologue
     // output channels: 32, or any multiple of 64 up to 256 (workgroup groups of 64 channels: levels = 3 reaches 256)
     const bool c_ok = a.c_out == 32 || a.c_out == 64 || a.c_out == 128 || a.c_out == 256;
     if (a.stride == 1 && a.pad == 1)
@@ -2148,28 +2116,8 @@ ConvPlan conv_plan(const ConvArgs& a) {
 
 namespace {
 bool ws_form_ok(const ConvArgs& a) { return a.k == 3 && conv_plan(a).form == 2; }
-bool bnbwd_form_ok(const ConvArgs& a) {
-    // Off by default.  Measured: with the apply pass moved to the second stream the backward step gets
-    // SLOWER (2.34 vs 2.01 ms) — the backward pass is HBM-bound as a whole, and this schedule adds a read of y per layer.
-    return bn_bwd_apply_fusion_enabled() && a.k == 3 && conv_plan(a).form == 2;
-}
 }  // namespace
 
-int bn_bwd_apply_fusion_mode() {
-    static const int on = getenv("ANH_FUSE_BN_BWD_APPLY") ? atoi(getenv("ANH_FUSE_BN_BWD_APPLY")) : 0;
-    return on;
-}
-
-bool conv_writes_dy(const ConvArgs& a) { return bn_bwd_apply_fusion_mode() == 2 && a.src.kind == SRC_BNBWD && mfma_conv_supported(a) && !stem_mfma_ok(a); }
-
-bool conv_accepts_bnbwd(const ConvArgs& a) {
-    ConvArgs b = a;
-    b.src.kind = SRC_BNBWD;
-    return mfma_conv_supported(b) && !stem_mfma_ok(b);
-}
-
-// Number of per-workgroup statistic partials the conv kernel will write when ConvArgs::stat_partials is set
-// (layout [channel][sum | sum of squares][workgroup]); 0 when this layer's kernel does not fuse the statistics.
 int conv_fused_stat_blocks(const ConvArgs& a) {
     if (!mfma_conv_supported(a) || (int64_t)a.n * a.h_out * a.w_out == 0) return 0;
     static const int on = getenv("ANH_FUSE_BN_STATS") ? atoi(getenv("ANH_FUSE_BN_STATS")) : 1;

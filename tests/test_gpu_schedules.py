@@ -3,9 +3,10 @@
 The switches are environment variables read once per process, so each variant runs
 tests/helpers/run_train_steps.py in its own process: 3 bf16 steps on a seeded batch of 6 tiles 99x99.
   * variants that only move work between streams or kernels WITHOUT changing any summation order are bit-identical to
-    the default: one stream instead of two; the bn + relu backward applied in the backward-data conv's prologue; the
-    stem's filter gradient queued on the second stream instead of the main one; the conv filter slabs streamed through LDS
-    with every patch instead of staying resident;
+    the default: one stream instead of two; the stem's filter gradient queued on the second stream instead of the main one;
+    the conv filter slabs streamed through LDS with every patch instead of staying resident; the gradient under the fused
+    head written to memory instead of recomputed by its bn backward pass; stream priorities; the conv kernels' producer /
+    consumer waves mapped to separate SIMDs;
   * variants that change a summation order (bn statistics / bn backward sums in a conv epilogue vs. the separate
     kernels; the classic one-tile conv kernels; dy materialised for the stem) agree to bf16-training tolerance.
 """
@@ -37,9 +38,9 @@ def default_run(tmp_path_factory):
 
 @pytest.mark.parametrize("name,env", [
     ("one_stream", {"ANH_CONCURRENT_WGRAD": "0"}),
-    ("bn_backward_in_conv_prologue", {"ANH_FUSE_BN_BWD_APPLY": "1"}),
-    ("backward_data_conv_writes_dy", {"ANH_FUSE_BN_BWD_APPLY": "2"}),
-    ("backward_data_conv_writes_dy_one_stream", {"ANH_FUSE_BN_BWD_APPLY": "2", "ANH_CONCURRENT_WGRAD": "0"}),
+    ("head_gradient_materialised", {"ANH_HEAD_DA_VIRTUAL": "0"}),
+    ("main_stream_above_filter_gradient_stream", {"ANH_STREAM_PRIORITY": "1"}),
+    ("conv_roles_on_separate_simds", {"ANH_WS_ROLE_MAP": "1"}),
     ("stem_filter_gradient_on_second_stream", {"ANH_STEM_WGRAD_MAIN": "0"}),
     ("conv_filters_streamed_with_every_patch", {"ANH_WS_WEIGHT_RESIDENT": "0"}),
 ])
