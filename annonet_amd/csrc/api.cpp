@@ -1063,6 +1063,21 @@ int anh_trainer_set_stream(anh_trainer* h, void* s) {
     return guarded([&] { ANH_REQUIRE(h, "null handle"); ANH_REQUIRE(h->replicas() == 1, "a handle that drives several devices keeps its own streams"); h->engine().set_stream((hipStream_t)s); });
 }
 int anh_trainer_get_stream(anh_trainer* h, void** s) { return guarded([&] { ANH_REQUIRE(h && s, "null argument"); *s = (void*)h->engine().stream; }); }
+int anh_trainer_early_grads(anh_trainer* h, int64_t* first) {
+    return guarded([&] {
+        ANH_REQUIRE(h && first, "null argument");
+        Engine& e = h->engine();
+        *first = h->replicas() > 1 ? (int64_t)e.spec.n_params + 1 : e.early_grad_first();   // (several replicas: the library reduces the buckets itself)
+    });
+}
+int anh_trainer_wait_early_grads(anh_trainer* h, void* hip_stream) {
+    return guarded([&] {
+        ANH_REQUIRE(h && hip_stream, "null argument");
+        Engine& e = h->engine();
+        ANH_REQUIRE(e.early_grad_first() <= e.spec.n_params, "this net has no early gradient part");
+        HIP_CHECK(hipStreamWaitEvent((hipStream_t)hip_stream, e.ev_early_grads, 0));
+    });
+}
 int anh_trainer_synchronize(anh_trainer* h) {
     return guarded([&] {
         ANH_REQUIRE(h, "null handle");

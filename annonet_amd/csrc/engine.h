@@ -71,6 +71,12 @@ class Engine {
     // filter gradients run on a second stream, concurrently with the backward-data / bn chain (both only read dy)
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_dy_ready = nullptr, ev_aux_done = nullptr;
+    // Data-parallel hosts start the gradient all-reduce before backward has finished: the filter gradients come out last layer
+    // first, so once layer kEarlyLayer's is reduced every gradient element from that layer's first parameter to the end of the
+    // bucket (deeper layers, head, loss slot) is final.  ev_early_grads fires there (on the stream that ran that filter gradient).
+    static constexpr int kEarlyLayer = 2;
+    hipEvent_t ev_early_grads = nullptr;
+    int64_t early_grad_first() const;   // first bucket element covered by ev_early_grads; n_params + 1 when there is no early part
     bool concurrent_wgrad = true;
     Profiler prof;
     unsigned long bn_window = 100;           // SetAllBatchNormalizationRunningStatsWindowSizes

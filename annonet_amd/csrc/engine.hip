@@ -78,6 +78,7 @@ Engine::Engine(const anh_net_config& cfg, bool training_) : spec(Spec::build(cfg
         else HIP_CHECK(hipStreamCreateWithFlags(&aux_stream, hipStreamNonBlocking));
         HIP_CHECK(hipEventCreateWithFlags(&ev_dy_ready, hipEventDisableTiming));
         HIP_CHECK(hipEventCreateWithFlags(&ev_aux_done, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&ev_early_grads, hipEventDisableTiming));
         const char* e = getenv("ANH_CONCURRENT_WGRAD");
         if (e && e[0] == '0') concurrent_wgrad = false;
     }
@@ -132,6 +133,7 @@ Engine::~Engine() {
     if (aux_stream) { (void)hipStreamSynchronize(aux_stream); (void)hipStreamDestroy(aux_stream); }
     if (ev_dy_ready) (void)hipEventDestroy(ev_dy_ready);
     if (ev_aux_done) (void)hipEventDestroy(ev_aux_done);
+    if (ev_early_grads) (void)hipEventDestroy(ev_early_grads);
     if (stream && own_stream) (void)hipStreamDestroy(stream);
 }
 
@@ -409,6 +411,13 @@ bool Engine::head_is_fused() const {
     return training && head.k == 1 && head.in_a >= 0 && head_train_supported(t);
 }
 
+int64_t Engine::early_grad_first() const {
+    // parameters are laid out in layer order, so "layers >= kEarlyLayer" is a suffix of the bucket; a net too shallow to have an
+    // early part reports none
+    if (!training || (int)spec.layers.size() <= kEarlyLayer + 1 || spec.layers[kEarlyLayer].in_a < 0) return spec.n_params + 1;
+    return spec.layers[kEarlyLayer].w_off;
+}
+
 void Engine::forward_inference(const Src& image, int n, int h, int w, float* d_out_nchw) {
     prof.start_pass();
     ANH_REQUIRE(!training, "forward_inference on a training net: take a runtime snapshot first");
@@ -599,6 +608,8 @@ void Engine::backward(const uint16_t* d_labels, const float* d_weights, double l
             conv_dispatch(dg, (std::string("dgrad_") + layer_tag(li, L)).c_str(), flops, bytes);
         };
         run_wgrad();
+        if (li == kEarlyLayer && early_grad_first() <= spec.n_params)   // gradients of layers >= kEarlyLayer, head and loss are final here
+            HIP_CHECK(hipEventRecord(ev_early_grads, (two_streams && has_dgrad) ? aux_stream : stream));
         if (has_dgrad) run_dgrad();
     }
     if (concurrent_wgrad && aux_stream) {  // gradients are complete on the main stream only after the aux stream drains

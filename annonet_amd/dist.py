@@ -29,18 +29,50 @@ def handle_stream(handle):
     return torch.cuda.ExternalStream(handle.stream_ptr(), device=torch.device("cuda", torch.cuda.current_device()))
 
 
-def data_parallel_step(trainer, bucket, d_images, d_labels, d_weights, n, h, w, world_size, group=None, force_collective=False, stream=None):
+class EarlyReduce:
+    """The all-reduce of the gradient bucket split in two so that most of it overlaps the end of backward: the filter gradients
+    come out last layer first, so the bucket's tail [first, n + 1) — every layer but the first two, the head, the loss slot — is
+    final while the last backward-data convs and the first layers' filter gradients still run (anh_trainer_early_grads).  That
+    part is reduced on a side stream gated by the library's event; the short head [0, first) follows on the trainer's stream."""
+
+    def __init__(self, trainer, bucket):
+        import torch
+        self.first = trainer.early_grads() if bucket.is_cuda else bucket.numel()
+        self.split = 0 < self.first < bucket.numel() - 1
+        self.side = torch.cuda.Stream(device=bucket.device) if self.split else None
+
+    def run(self, trainer, bucket, main_stream, group=None):
+        import torch
+        import torch.distributed as dist
+        if not self.split:
+            with torch.cuda.stream(main_stream):
+                dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=group)
+            return
+        trainer.wait_early_grads(self.side.cuda_stream)
+        with torch.cuda.stream(self.side):
+            dist.all_reduce(bucket[self.first:], op=dist.ReduceOp.SUM, group=group)
+        with torch.cuda.stream(main_stream):
+            dist.all_reduce(bucket[:self.first], op=dist.ReduceOp.SUM, group=group)
+        main_stream.wait_stream(self.side)      # the update reads the whole bucket
+
+
+def data_parallel_step(trainer, bucket, d_images, d_labels, d_weights, n, h, w, world_size, group=None, force_collective=False, stream=None, early=None):
     """One optimiser step of a data-parallel job.  The loss scale uses the GLOBAL batch (n * world_size), so the
     all-reduce is a plain SUM and every rank then applies the identical update.  The collective is
     enqueued on the trainer's own stream (`stream` = handle_stream(trainer), made once by the caller): backward ->
-    all-reduce -> SGD is one stream-ordered chain with no host synchronisation."""
+    all-reduce -> SGD is one stream-ordered chain with no host synchronisation.  With `early` (an EarlyReduce made once by the
+    caller) the bulk of the bucket is reduced while backward is still running."""
     trainer.forward_backward_device(d_images, d_labels, d_weights, n, h, w, n * world_size)
     if world_size > 1 or force_collective:
         import torch
         import torch.distributed as dist
         if bucket.is_cuda:
-            with torch.cuda.stream(stream if stream is not None else handle_stream(trainer)):
-                dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=group)
+            main = stream if stream is not None else handle_stream(trainer)
+            if early is not None:
+                early.run(trainer, bucket, main, group)
+            else:
+                with torch.cuda.stream(main):
+                    dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=group)
         else:   # CPU rehearsal of the same logic over gloo (tests/test_dist_gloo.py)
             dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=group)
     trainer.apply_update(1.0)

@@ -524,6 +524,17 @@ class TrainingNet(_Profiled):
         check(self.L.anh_trainer_get_stream(self.h, C.byref(s)))
         return s.value or 0
 
+    def early_grads(self):
+        """first element of the gradient bucket's EARLY part: [first, n_params + 1) is final before backward has finished
+        (anh_trainer_early_grads); first > n_params means there is none"""
+        first = C.c_int64()
+        check(self.L.anh_trainer_early_grads(self.h, C.byref(first)))
+        return int(first.value)
+
+    def wait_early_grads(self, stream_ptr):
+        """makes the caller's HIP stream wait until the early part of the bucket is final"""
+        check(self.L.anh_trainer_wait_early_grads(self.h, stream_ptr))
+
     def layer_tensor(self, layer, which=0):
         dims = (C.c_int * 4)()
         check(self.L.anh_trainer_layer_tensor(self.h, layer, which, None, 0, dims))

@@ -455,8 +455,13 @@ def main():
     d_w = torch.from_numpy(w).to(dev)
     ranks_seen, devices = dist_facts(torch, dist, dev, local_rank, world, use_dist)
 
+    # N > 1: the tail of the bucket (all layers but the first two) is all-reduced on a side stream while backward still runs
+    # (two collectives cost ~20 us more than one: only worth it where the all-reduce moves data, i.e. N > 1; ANH_EARLY_REDUCE=0/1 forces)
+    er = os.environ.get("ANH_EARLY_REDUCE")
+    early = aad.EarlyReduce(t, bucket) if use_dist and (er == "1" or (er is None and world > 1)) else None
+
     def step():
-        aad.data_parallel_step(t, bucket, d_img.data_ptr(), d_lab.data_ptr(), d_w.data_ptr(), BATCH, TILE, TILE, world, force_collective=use_dist, stream=t_stream)
+        aad.data_parallel_step(t, bucket, d_img.data_ptr(), d_lab.data_ptr(), d_w.data_ptr(), BATCH, TILE, TILE, world, force_collective=use_dist, stream=t_stream, early=early)
 
     def fence():
         torch.cuda.synchronize()

@@ -185,6 +185,13 @@ int anh_trainer_save_state(anh_trainer* h, const char* path); /* trainer synchro
 int anh_trainer_load_state(anh_trainer* h, const char* path);
 int anh_trainer_set_stream(anh_trainer* h, void* hip_stream);
 int anh_trainer_get_stream(anh_trainer* h, void** hip_stream);
+/* Overlapping the gradient all-reduce with the end of backward (data-parallel hosts; annonet_train_main.cpp:583-614 hands the
+ * mini-batch to dlib's multi-GPU trainer, whose averaging this replaces): after forward_backward the bucket elements
+ * [*first, n_params + 1) — every layer but the first two, the head and the loss slot — become final while the last
+ * backward-data convs still run.  wait_early_grads makes `hip_stream` (a stream of the caller's) wait for exactly that point;
+ * the elements [0, *first) are final when the handle's own stream has drained.  *first > n_params: no early part. */
+int anh_trainer_early_grads(anh_trainer* h, int64_t* first);
+int anh_trainer_wait_early_grads(anh_trainer* h, void* hip_stream);
 int anh_trainer_synchronize(anh_trainer* h);
 /* debugging / parity taps: raw conv output (which=0) or gradient w.r.t. the layer's activation (which=1), as fp32 NHWC */
 int anh_trainer_layer_tensor(anh_trainer* h, int layer, int which, float* out, int64_t capacity, int dims4[4]);
