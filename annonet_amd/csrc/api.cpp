@@ -602,7 +602,7 @@ void infer_multi(anh_runtime* h, const uint8_t* image, int H, int W, const doubl
     std::vector<float*> packed(R, nullptr);
     std::vector<hipStream_t> streams(R);
     std::vector<int64_t> lo(R), hi(R);
-    for (size_t r = 0; r < R; ++r) {
+    for_each_replica(R, [&](size_t r) {
         DeviceScope scope(h->device_of(r));
         Engine& e = h->replica(r);
         shard_range((int64_t)tiles.size(), (int)R, (int)r, lo[r], hi[r]);
@@ -623,13 +623,13 @@ void infer_multi(anh_runtime* h, const uint8_t* image, int H, int W, const doubl
             launch_pack_rects(e.stage_blended.as<float>(), K, H, W, x.rects.as<anh_rect>(), x.offsets.as<int64_t>(), (int)table.rects.size(), total, x.packed.as<float>(), e.stream);
             packed[r] = x.packed.as<float>();
         }
-    }
+    });
     // the table's host vectors must outlive the async uploads: every replica's stream passes the uploads before the collective returns control below
     if (total > 0) h->coll->all_reduce_sum(packed, (size_t)K * total, streams);   // the ONE exchange step of the path
-    for (size_t r = 0; r < R; ++r) {
+    for_each_replica(R, [&](size_t r) {
         DeviceScope scope(h->device_of(r));
         Engine& e = h->replica(r);
-        if (hi[r] == lo[r]) continue;
+        if (hi[r] == lo[r]) return;
         if (total > 0) {
             anh_runtime::Exchange& x = h->exchange[r];
             launch_unpack_rects(e.stage_blended.as<float>(), K, H, W, x.rects.as<anh_rect>(), x.offsets.as<int64_t>(), (int)table.rects.size(), total, x.packed.as<float>(), e.stream);
@@ -651,7 +651,7 @@ void infer_multi(anh_runtime* h, const uint8_t* image, int H, int W, const doubl
                     HIP_CHECK(hipMemcpy2DAsync(blended_out + k * plane + off, (size_t)W * 4, e.stage_blended.as<float>() + k * plane + off, (size_t)W * 4,
                                                (size_t)(rt - l + 1) * 4, (size_t)(b - t + 1), hipMemcpyDeviceToHost, e.stream));
         }
-    }
+    });
     for (size_t r = 0; r < R; ++r) { DeviceScope scope(h->device_of(r)); h->replica(r).synchronize(); }
 }
 }  // namespace
@@ -889,12 +889,12 @@ int anh_trainer_step(anh_trainer* h, const uint8_t* const* images, const anh_wla
         // data parallel (annonet_train_main.cpp:583-614): replica r takes samples [n r / R, n (r+1) / R); the loss
         // scale 1/(N nr nc) uses the WHOLE batch, so the exchange step is a plain sum of the gradient buckets
         std::vector<anh_trainer::StageSet*> used(R, nullptr);
-        for (size_t r = 0; r < R; ++r) {
+        for_each_replica(R, [&](size_t r) {   // packing, upload and the step's launches of every replica in parallel
             DeviceScope scope(h->device_of(r));
             int64_t lo, hi;
             shard_range(n, (int)R, (int)r, lo, hi);
             used[r] = &stage_and_run(h, h->replica(r), h->stage_of(r), h->copy_stream_of(r), images + lo, labels + lo, (int)(hi - lo), height, width, (double)n);
-        }
+        });
         if (R > 1) {
             std::vector<float*> buckets(R);
             std::vector<hipStream_t> streams(R);
