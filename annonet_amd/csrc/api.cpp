@@ -899,7 +899,29 @@ int anh_trainer_step(anh_trainer* h, const uint8_t* const* images, const anh_wla
             std::vector<float*> buckets(R);
             std::vector<hipStream_t> streams(R);
             for (size_t r = 0; r < R; ++r) { buckets[r] = h->replica(r).grad_bucket(); streams[r] = h->replica(r).stream; }
-            h->coll->all_reduce_sum(buckets, (size_t)h->eng->spec.n_params + 1, streams);   // the trailing slot carries the loss
+            const int64_t count = (int64_t)h->eng->spec.n_params + 1, first = h->eng->early_grad_first();   // the trailing slot carries the loss
+            static const bool early_on = !(getenv("ANH_EARLY_REDUCE") && atoi(getenv("ANH_EARLY_REDUCE")) == 0);
+            if (early_on && first > 0 && first < count - 1) {
+                // the tail of the bucket (every layer but the first two, head, loss) is final while backward still runs
+                // (Engine::ev_early_grads): reduce it on side streams now, the short head on the replicas' own streams afterwards
+                std::vector<float*> tails(R);
+                std::vector<hipStream_t> side(R);
+                for (size_t r = 0; r < R; ++r) {
+                    DeviceScope scope(h->device_of(r));
+                    Engine& e = h->replica(r);
+                    side[r] = e.early_reduce_stream();
+                    HIP_CHECK(hipStreamWaitEvent(side[r], e.ev_early_grads, 0));
+                    tails[r] = buckets[r] + first;
+                }
+                h->coll->all_reduce_sum(tails, (size_t)(count - first), side);
+                h->coll->all_reduce_sum(buckets, (size_t)first, streams);
+                for (size_t r = 0; r < R; ++r) {   // the update reads the whole bucket
+                    DeviceScope scope(h->device_of(r));
+                    Engine& e = h->replica(r);
+                    HIP_CHECK(hipEventRecord(e.ev_early_reduced, side[r]));
+                    HIP_CHECK(hipStreamWaitEvent(e.stream, e.ev_early_reduced, 0));
+                }
+            } else h->coll->all_reduce_sum(buckets, (size_t)count, streams);
         }
         const int rc = anh_trainer_apply_update(h, 1.0);
         if (rc != ANH_OK) fail(rc, g_error);

@@ -76,6 +76,9 @@ class Engine {
     // bucket (deeper layers, head, loss slot) is final.  ev_early_grads fires there (on the stream that ran that filter gradient).
     static constexpr int kEarlyLayer = 2;
     hipEvent_t ev_early_grads = nullptr;
+    hipStream_t early_stream = nullptr;       // where the in-library exchange reduces the early part (anh_set_devices), made on first use
+    hipEvent_t ev_early_reduced = nullptr;
+    hipStream_t early_reduce_stream();
     int64_t early_grad_first() const;   // first bucket element covered by ev_early_grads; n_params + 1 when there is no early part
     bool concurrent_wgrad = true;
     Profiler prof;

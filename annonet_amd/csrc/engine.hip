@@ -134,6 +134,8 @@ Engine::~Engine() {
     if (ev_dy_ready) (void)hipEventDestroy(ev_dy_ready);
     if (ev_aux_done) (void)hipEventDestroy(ev_aux_done);
     if (ev_early_grads) (void)hipEventDestroy(ev_early_grads);
+    if (ev_early_reduced) (void)hipEventDestroy(ev_early_reduced);
+    if (early_stream) (void)hipStreamDestroy(early_stream);
     if (stream && own_stream) (void)hipStreamDestroy(stream);
 }
 
@@ -409,6 +411,14 @@ bool Engine::head_is_fused() const {
     t.src = layer_source((int)spec.layers.size() - 1, Src{});
     t.c_in = head.cin; t.k = head.cout;
     return training && head.k == 1 && head.in_a >= 0 && head_train_supported(t);
+}
+
+hipStream_t Engine::early_reduce_stream() {
+    if (!early_stream) {
+        HIP_CHECK(hipStreamCreateWithFlags(&early_stream, hipStreamNonBlocking));
+        HIP_CHECK(hipEventCreateWithFlags(&ev_early_reduced, hipEventDisableTiming));
+    }
+    return early_stream;
 }
 
 int64_t Engine::early_grad_first() const {
