@@ -142,6 +142,7 @@ _SIGNATURES = {  # ConvDesc / OpInput are defined above
     "anh_trainer_load_state": (C.c_int, [_P, C.c_char_p]),
     "anh_trainer_set_stream": (C.c_int, [_P, _P]),
     "anh_trainer_get_stream": (C.c_int, [_P, C.POINTER(C.c_void_p)]),
+    "anh_runtime_stores_activations": (C.c_int, [_P, C.POINTER(C.c_int)]),
     "anh_trainer_early_grads": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "anh_trainer_wait_early_grads": (C.c_int, [_P, _P]),
     "anh_trainer_synchronize": (C.c_int, [_P]),

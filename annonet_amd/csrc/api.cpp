@@ -696,6 +696,7 @@ int anh_infer(anh_runtime* h, const uint8_t* image, int height, int width, const
 
 int anh_runtime_set_stream(anh_runtime* h, void* s) { return guarded([&] { ANH_REQUIRE(h, "null handle"); ANH_REQUIRE(h->replicas() == 1, "a handle that drives several devices keeps its own streams"); h->eng->set_stream((hipStream_t)s); }); }
 int anh_runtime_get_stream(anh_runtime* h, void** s) { return guarded([&] { ANH_REQUIRE(h && s, "null argument"); *s = (void*)h->eng->stream; }); }
+int anh_runtime_stores_activations(anh_runtime* h, int* yes) { return guarded([&] { ANH_REQUIRE(h && yes, "null argument"); *yes = h->eng->infer_post ? 1 : 0; }); }
 int anh_runtime_synchronize(anh_runtime* h) {
     return guarded([&] { ANH_REQUIRE(h, "null handle"); for (size_t r = 0; r < h->replicas(); ++r) { DeviceScope scope(h->device_of(r)); h->replica(r).synchronize(); } });
 }

@@ -111,6 +111,9 @@ class Engine {
     static constexpr int kMaxTileBatch = 8;   // Src::img_win holds eight windows
     void infer_tile(const anh_tile& t, const uint8_t* d_image, int H, int W, float* d_blended);
     void infer_tiles(const anh_tile* ts, int count, const uint8_t* d_image, int H, int W, float* d_blended);
+    bool infer_post = false;   // this inference pass stores post-activation tensors (choose_inference_form)
+    ConvArgs forward_conv_args(int li, const Src& image, bool training_pass, float* d_out_nchw) const;
+    void choose_inference_form(const Src& image);
     int tile_batch(int h, int w) const;
     const double* upload_gains(const double* gains_host);   // -> device pointer (or nullptr)
     void infer_device(const uint8_t* d_image, int H, int W, const double* gains_host, const std::vector<anh_tile>& tiles,

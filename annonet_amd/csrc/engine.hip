@@ -304,10 +304,48 @@ Src Engine::layer_source(int li, const Src& image) const {
     if (L.in_a < 0) return image;
     Src s;
     s.dtype = dtype;
+    if (infer_post) {   // the producers stored relu(bn(y)) (forward_conv_args): plain reads
+        s.kind = L.in_b >= 0 ? SRC_SUM2 : SRC_RAW;
+        s.a = ls[L.in_a].raw.p;
+        if (L.in_b >= 0) s.b = ls[L.in_b].raw.p;
+        return s;
+    }
     s.kind = L.in_b >= 0 ? SRC_ACT2 : SRC_ACT;
     s.a = ls[L.in_a].raw.p; s.a_scale = ls[L.in_a].scale; s.a_shift = ls[L.in_a].shift;
     if (L.in_b >= 0) { s.b = ls[L.in_b].raw.p; s.b_scale = ls[L.in_b].scale; s.b_shift = ls[L.in_b].shift; }
     return s;
+}
+
+// Arguments of layer li's forward conv.  bf16 inference with infer_post: bn layers store their post-activation output (the
+// epilogue applies the layer's own folded bn + relu to the fp32 accumulators), so no consumer re-applies it while staging.
+ConvArgs Engine::forward_conv_args(int li, const Src& image, bool training_pass, float* d_out_nchw) const {
+    const anh_layer_desc& L = spec.layers[li];
+    const LayerState& s = ls[li];
+    ConvArgs a;
+    a.src = layer_source(li, image);
+    a.n = s.n; a.h_in = s.h_in; a.w_in = s.w_in; a.c_red = L.cin;
+    a.h_out = s.h; a.w_out = s.w; a.c_out = L.cout;
+    a.k = L.k; a.stride = L.stride; a.pad = L.pad; a.gather = L.type;
+    a.w_f32 = w_tm_f32.as<float>() + L.w_off;
+    a.w_bf16 = dtype == DT_BF16 ? (const void*)(w_km_bf16.as<uint16_t>() + L.w_off) : nullptr;
+    a.bias = L.has_bias ? master.as<float>() + L.b_off : nullptr;
+    if (L.has_bn) { a.out = s.raw.p; a.out_dtype = dtype; if (infer_post) { a.out_scale = s.scale; a.out_shift = s.shift; } }
+    else if (training_pass) { a.out = logits.p; a.out_dtype = DT_F32; }
+    else { a.out = d_out_nchw; a.out_dtype = DT_F32; a.out_nchw = 1; }
+    return a;
+}
+
+// Decides infer_post for a pass whose dimensions are planned: every bn layer's kernel must be able to store activations and every
+// consumer to read them (the persistent MFMA kernels, the stem kernel, the fused head + blend or the generic 1x1 head).
+void Engine::choose_inference_form(const Src& image) {
+    static const bool on = !(getenv("ANH_INFER_POST_ACT") && atoi(getenv("ANH_INFER_POST_ACT")) == 0);
+    infer_post = false;
+    if (!on || training || dtype != DT_BF16 || spec.layers.back().in_b >= 0) return;
+    infer_post = true;
+    for (size_t li = 0; li + 1 < spec.layers.size(); ++li) {
+        const ConvArgs a = forward_conv_args((int)li, image, false, nullptr);
+        if (!spec.layers[li].has_bn || !conv_takes_mfma(a, dtype) || !conv_stores_activation(a)) { infer_post = false; return; }
+    }
 }
 
 void Engine::conv_dispatch(const ConvArgs& a, const char* tag, double flops, double bytes) {
@@ -350,18 +388,8 @@ static std::string layer_tag(int li, const anh_layer_desc& L) {
 void Engine::run_conv_forward(int li, const Src& image, bool training_pass, float* d_out_nchw) {
     const anh_layer_desc& L = spec.layers[li];
     LayerState& s = ls[li];
-    ConvArgs a;
-    a.src = layer_source(li, image);
-    a.n = s.n; a.h_in = s.h_in; a.w_in = s.w_in; a.c_red = L.cin;
-    a.h_out = s.h; a.w_out = s.w; a.c_out = L.cout;
-    a.k = L.k; a.stride = L.stride; a.pad = L.pad; a.gather = L.type;
-    a.w_f32 = w_tm_f32.as<float>() + L.w_off;
-    a.w_bf16 = dtype == DT_BF16 ? (const void*)(w_km_bf16.as<uint16_t>() + L.w_off) : nullptr;
-    a.bias = L.has_bias ? master.as<float>() + L.b_off : nullptr;
+    ConvArgs a = forward_conv_args(li, image, training_pass, d_out_nchw);
     const int64_t p_out = (int64_t)s.n * s.h * s.w, p_in = (int64_t)s.n * s.h_in * s.w_in;
-    if (L.has_bn) { a.out = s.raw.p; a.out_dtype = dtype; }
-    else if (training_pass) { a.out = logits.p; a.out_dtype = DT_F32; }
-    else { a.out = d_out_nchw; a.out_dtype = DT_F32; a.out_nchw = 1; }
     const double flops = 2.0 * L.k * L.k * L.cin * L.cout * (double)(L.type == 0 ? p_out : p_in);
     const double es = (double)elem_size(dtype);
     const double bytes = (double)p_in * L.cin * (L.in_a < 0 ? 1.0 : es) * (L.in_b >= 0 ? 2 : 1) + (double)p_out * L.cout * (L.has_bn ? es : 4.0) +
@@ -432,6 +460,7 @@ void Engine::forward_inference(const Src& image, int n, int h, int w, float* d_o
     prof.start_pass();
     ANH_REQUIRE(!training, "forward_inference on a training net: take a runtime snapshot first");
     plan_dims(n, h, w);
+    choose_inference_form(image);
     for (size_t li = 0; li < spec.layers.size(); ++li) run_conv_forward((int)li, image, false, d_out_nchw);
 }
 
@@ -713,6 +742,7 @@ void Engine::infer_tiles(const anh_tile* ts, int count, const uint8_t* d_image, 
     if (fuse_head) {
         prof.start_pass();
         plan_dims(count, win.height, win.width);
+        choose_inference_form(image);
         for (size_t li = 0; li + 1 < spec.layers.size(); ++li) run_conv_forward((int)li, image, false, nullptr);
     } else {
         tile_out.reserve((size_t)count * K * win.height * win.width * 4);

@@ -15,7 +15,10 @@ enum SrcKind {
     SRC_RAW = 0,    // value = a[i]
     SRC_ACT = 1,    // value = relu(a[i]*scale_a[c] + shift_a[c])
     SRC_ACT2 = 2,   // value = relu(a[i]*scale_a[c]+shift_a[c]) + relu(b[i]*scale_b[c]+shift_b[c])   (skip add)
-    SRC_IMAGE = 3   // value = u8 image / 256, read through a clamp-to-edge window (annonet_infer.cpp:68-75)
+    SRC_IMAGE = 3,  // value = u8 image / 256, read through a clamp-to-edge window (annonet_infer.cpp:68-75)
+    // Inference only (running statistics are known before a layer runs, so its epilogue CAN apply its own bn + relu:
+    // ConvArgs::out_scale): the producers stored post-activation tensors, a consumer reads a[i] (SRC_RAW) or the skip add:
+    SRC_SUM2 = 4    // value = a[i] + b[i]
     // (A fifth kind — the bn + relu BACKWARD of a layer applied by a backward-data conv while staging, in three schedules — was built
     // and measured in rounds 1 and 2 and lost every time; it is gone.  The stem's filter gradient, which has no
     // backward-data conv beside it, still applies that expression while staging: WgradArgs::dy_y.)
@@ -54,6 +57,9 @@ struct ConvArgs {
     void* out2 = nullptr; int out2_accumulate = 0;  // optional second destination (skip-add gradient)
     int out_nchw = 0;                               // fp32 NCHW destination (boundary layout)
     double* stat_partials = nullptr;                // fused bn statistics (MFMA path), else nullptr
+    // bf16 inference on the MFMA path: the epilogue stores relu(acc * out_scale[c] + out_shift[c]) — this layer's folded bn and its
+    // relu on the fp32 accumulator — instead of the raw output, so that its consumers stage plain copies (conv_stores_activation())
+    const float* out_scale = nullptr; const float* out_shift = nullptr;
     // Fused bn + relu backward REDUCTION (MFMA path, backward-data convs): `out` receives its final value da of a layer with
     // raw output bnred_y and folded constants; the kernel also writes that layer's dgamma / dbeta partial sums
     // ([channel][sum dz*xhat | sum dz][workgroup], dz = (y*scale+shift > 0) ? da : 0, xhat = (y-mean)*invstd).
@@ -254,6 +260,7 @@ void launch_conv_mfma(const ConvArgs& a, hipStream_t s);
 // value is the number of partials per channel to pass to launch_bn_forward_finalize)
 int conv_fused_stat_blocks(const ConvArgs& a);
 int conv_fused_bnred_blocks(const ConvArgs& a);   // same for ConvArgs::bnred_partials (backward-data convs)
+bool conv_stores_activation(const ConvArgs& a);   // the layer's MFMA kernel honours ConvArgs::out_scale / out_shift (src.kind SRC_RAW, SRC_SUM2 or SRC_IMAGE)
 bool mfma_wgrad_supported(const WgradArgs& a);
 void launch_wgrad_mfma(const WgradArgs& a, hipStream_t s);
 int64_t wgrad_mfma_scratch_floats(const WgradArgs& a);

@@ -1475,9 +1475,10 @@ __global__ __launch_bounds__(256) void head_blend_kernel(HeadBlendArgs a) {
 #pragma unroll
         for (int c = 0; c < 8; ++c) w[c][k] = k < K ? a.w_tm[(c0 + c) * K + k] : 0.f;
     }
+    constexpr bool PRE = KIND == SRC_ACT || KIND == SRC_ACT2;   // the input still needs its producer's bn + relu (else: stored post-activation)
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-        sa[c] = a.src.a_scale[c0 + c]; ta[c] = a.src.a_shift[c0 + c];
+        sa[c] = PRE ? a.src.a_scale[c0 + c] : 0.f; ta[c] = PRE ? a.src.a_shift[c0 + c] : 0.f;
         sb[c] = KIND == SRC_ACT2 ? a.src.b_scale[c0 + c] : 0.f; tb[c] = KIND == SRC_ACT2 ? a.src.b_shift[c0 + c] : 0.f;
     }
     const bf16* xa = reinterpret_cast<const bf16*>(a.src.a);
@@ -1489,13 +1490,15 @@ __global__ __launch_bounds__(256) void head_blend_kernel(HeadBlendArgs a) {
     auto process = [&](int64_t p, const Raw8<bf16>& ra, const Raw8<bf16>& rb) __attribute__((always_inline)) {
         float x[8];
         raw_to_float(ra, x);
+        if (PRE) {
 #pragma unroll
-        for (int c = 0; c < 8; ++c) x[c] = relu_affine(x[c], sa[c], ta[c]);
-        if (KIND == SRC_ACT2) {
+            for (int c = 0; c < 8; ++c) x[c] = relu_affine(x[c], sa[c], ta[c]);
+        }
+        if (KIND == SRC_ACT2 || KIND == SRC_SUM2) {
             float u[8];
             raw_to_float(rb, u);
 #pragma unroll
-            for (int c = 0; c < 8; ++c) x[c] += relu_affine(u[c], sb[c], tb[c]);
+            for (int c = 0; c < 8; ++c) x[c] += KIND == SRC_ACT2 ? relu_affine(u[c], sb[c], tb[c]) : u[c];
         }
 #pragma unroll
         for (int c = 0; c < 8; ++c) x[c] = operand_round<bf16>(x[c]);
@@ -1537,7 +1540,7 @@ __global__ __launch_bounds__(256) void head_blend_kernel(HeadBlendArgs a) {
         for (int u = 0; u < U; ++u) {
             const int64_t pc = min(p0 + u * stride, pixels - 1);
             ra[u] = raw_load8(xa + (size_t)pc * C + c0);
-            if (KIND == SRC_ACT2) rb[u] = raw_load8(xb + (size_t)pc * C + c0); else rb[u] = ra[u];
+            if (KIND == SRC_ACT2 || KIND == SRC_SUM2) rb[u] = raw_load8(xb + (size_t)pc * C + c0); else rb[u] = ra[u];
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
@@ -1921,15 +1924,20 @@ void launch_tm_to_canonical(const ParamSegment* segments, int n_segments, int64_
 
 bool head_blend_supported(const HeadBlendArgs& a) {
     static const bool on = !(getenv("ANH_FUSE_HEAD_BLEND") && atoi(getenv("ANH_FUSE_HEAD_BLEND")) == 0);
-    return on && a.c_in == kHeadC && a.k >= 1 && a.k <= kHeadKMax && a.src.dtype == DT_BF16 && (a.src.kind == SRC_ACT || a.src.kind == SRC_ACT2);
+    return on && a.c_in == kHeadC && a.k >= 1 && a.k <= kHeadKMax && a.src.dtype == DT_BF16 &&
+           (a.src.kind == SRC_ACT || a.src.kind == SRC_ACT2 || a.src.kind == SRC_RAW || a.src.kind == SRC_SUM2);
 }
 void launch_head_blend(const HeadBlendArgs& a, hipStream_t s) {
     ANH_REQUIRE(head_blend_supported(a), "head_blend: unsupported shape");
     const int64_t pixels = (int64_t)a.blend.tile_h * a.blend.tile_w;
     if (pixels <= 0) return;
     const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((pixels * 4 + 255) / 256, 2048));   // 8 workgroups per CU, >= 5 rounds of four pixels per thread on a 1024^2 tile
-    if (a.src.kind == SRC_ACT) hipLaunchKernelGGL(head_blend_kernel<SRC_ACT>, dim3(blocks), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(head_blend_kernel<SRC_ACT2>, dim3(blocks), dim3(256), 0, s, a);
+    switch (a.src.kind) {
+        case SRC_ACT: hipLaunchKernelGGL(head_blend_kernel<SRC_ACT>, dim3(blocks), dim3(256), 0, s, a); break;
+        case SRC_ACT2: hipLaunchKernelGGL(head_blend_kernel<SRC_ACT2>, dim3(blocks), dim3(256), 0, s, a); break;
+        case SRC_RAW: hipLaunchKernelGGL(head_blend_kernel<SRC_RAW>, dim3(blocks), dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL(head_blend_kernel<SRC_SUM2>, dim3(blocks), dim3(256), 0, s, a); break;
+    }
     HIP_CHECK(hipGetLastError());
 }
 

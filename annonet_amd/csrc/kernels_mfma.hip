@@ -209,6 +209,36 @@ __device__ __forceinline__ void store_pixel_tiles_rmw(const f32x16 (&acc)[NT], c
 }
 
 
+// Inference epilogue: this layer's folded bn and relu on the fp32 accumulators, then bf16 and the same 16-byte NHWC stores.
+// Register r of a tile holds channel 8 (r >> 2) + 4 half + (r & 3) BEFORE the permlane swap; act = [scale | shift][cw] of the
+// workgroup's channels (LDS table or global memory).
+template <int NT>
+__device__ __forceinline__ void store_pixel_tiles_act(const f32x16 (&acc)[NT], const ConvArgs& a, size_t pix, bool valid, int half, int co_base, const float* act, int cw) {
+    bf16* out = reinterpret_cast<bf16*>(a.out);
+    const size_t base = pix * a.c_out + co_base + 8 * half;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        float v[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 sc = *reinterpret_cast<const float4*>(act + nt * 32 + 8 * q + 4 * half);
+            const float4 sh = *reinterpret_cast<const float4*>(act + cw + nt * 32 + 8 * q + 4 * half);
+            v[4 * q + 0] = fmaf(acc[nt][4 * q + 0], sc.x, sh.x);
+            v[4 * q + 1] = fmaf(acc[nt][4 * q + 1], sc.y, sh.y);
+            v[4 * q + 2] = fmaf(acc[nt][4 * q + 2], sc.z, sh.z);
+            v[4 * q + 3] = fmaf(acc[nt][4 * q + 3], sc.w, sh.w);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const unsigned a0 = relu_bf16x2(pack2(v[8 * s + 0], v[8 * s + 1])), a1 = relu_bf16x2(pack2(v[8 * s + 2], v[8 * s + 3]));
+            const unsigned b0 = relu_bf16x2(pack2(v[8 * s + 4], v[8 * s + 5])), b1 = relu_bf16x2(pack2(v[8 * s + 6], v[8 * s + 7]));
+            auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+            auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+            if (valid) *reinterpret_cast<uint4*>(out + base + nt * 32 + 16 * s) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+        }
+    }
+}
+
 template <int NT>
 __device__ __forceinline__ void store_pixel_tiles(const f32x16 (&acc)[NT], const ConvArgs& a, size_t pix, bool valid, int half, int co_base = 0) {
     u32x4 none[NT][2];
@@ -331,6 +361,7 @@ __device__ __forceinline__ void side_commit(const SideRegs<KIND, ITEMS>& R, char
 template <int KIND>
 __device__ __forceinline__ uint4 chunk_convert(const RawChunk<KIND>& r, const float* sa, const float* ta, const float* sb, const float* tb) {
     if (KIND == SRC_RAW) return r.a;
+    if (KIND == SRC_SUM2) return add_bf16x8(r.a, r.b);
     if (KIND == SRC_ACT) return affine_relu_pack8(r.a, sa, ta);
     float v[8];
     affine8(r.a, sa, ta, v);
@@ -575,7 +606,7 @@ template <int KIND>
 __device__ __forceinline__ RawChunk<KIND> side_load_at(const bf16* a, const bf16* b, int off) {
     RawChunk<KIND> r;
     r.a = *reinterpret_cast<const uint4*>(a + off);
-    if (KIND == SRC_ACT2) r.b = *reinterpret_cast<const uint4*>(b + off);
+    if (KIND == SRC_ACT2 || KIND == SRC_SUM2) r.b = *reinterpret_cast<const uint4*>(b + off);
     return r;
 }
 
@@ -1087,7 +1118,8 @@ struct GeoUp {
 // ---------------------------------------------------------------------------------------------------------------
 // FWD: the forward-only form — no prefetched epilogue operands (old values of an accumulating destination, y of the
 // layer behind `out`), whose registers the four-accumulator-group geometry at NT = 2 needs for its bn statistics sums.
-template <class G, int NT, int KIND, bool FWD = false>
+// ACT (inference, with FWD): the epilogue applies this layer's own folded bn + relu (ConvArgs::out_scale) and stores the activation.
+template <class G, int NT, int KIND, bool FWD = false, bool ACT = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tiles_x, int tiles_y, int flip, long long* prof, int wres_) {
     // per-phase wall-clock accounting, compiled in with -DANH_WS_PROFILE (ANH_WS_PROF=1 then prints one line per launch)
 #ifdef ANH_WS_PROFILE
@@ -1122,19 +1154,25 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
     const int H = a.h_in, W = a.w_in, c_red = a.c_red;
     const int n_slabs = c_red >> 5, n_tiles = tiles_x * tiles_y * a.n;
     constexpr bool CAN_STATS = G::ACC * NT <= 4 || FWD;  // register budget of the consumer waves
-    const bool fuse_stats = CAN_STATS && a.stat_partials != nullptr;   // forward: bn statistics of the output
+    const bool fuse_stats = !ACT && CAN_STATS && a.stat_partials != nullptr;   // forward: bn statistics of the output
     const bool fuse_bnred = !FWD && CAN_STATS && a.bnred_partials != nullptr;  // backward-data: dgamma / dbeta sums of the layer `out` belongs to
     const int stat_mode = fuse_stats ? 1 : fuse_bnred ? 2 : 0;
     float* bnc = tab + c_red * 4;            // [scale | shift | mean | invstd][C_OUT] of this workgroup's channels
 
     int tile = blockIdx.x, slab = 0, it = 0;
     auto init_tables = [&]() __attribute__((always_inline)) {   // every thread of the workgroup, from either branch below
-        if (KIND != SRC_RAW) {
+        if (KIND == SRC_ACT || KIND == SRC_ACT2) {
             for (int i = threadIdx.x; i < c_red; i += 512) {
                 tab[i] = a.src.a_scale[i];
                 tab[c_red + i] = a.src.a_shift[i];
                 tab[2 * c_red + i] = KIND == SRC_ACT2 ? a.src.b_scale[i] : 0.f;
                 tab[3 * c_red + i] = KIND == SRC_ACT2 ? a.src.b_shift[i] : 0.f;
+            }
+        }
+        if (ACT) {
+            for (int i = threadIdx.x; i < C_OUT; i += 512) {
+                bnc[i] = a.out_scale[co_base + i];
+                bnc[C_OUT + i] = a.out_shift[co_base + i];
             }
         }
         if (fuse_bnred) {
@@ -1211,7 +1249,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
         };
         auto fetch = [&](Fetched& R) __attribute__((always_inline)) {
             const bf16* pa = xa + (size_t)fn * plane;
-            const bf16* pb = KIND == SRC_ACT2 ? xb + (size_t)fn * plane : nullptr;
+            const bf16* pb = (KIND == SRC_ACT2 || KIND == SRC_SUM2) ? xb + (size_t)fn * plane : nullptr;
             const int cc = fslab * 32;
             R.pok = fpok;
     #pragma unroll
@@ -1234,7 +1272,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
             // a single-slab layer's filter block goes into both buffers once (its registers are not refetched)
             const bool stage_w = !wres && (it < 2 || n_slabs > 1);
             float sa[8], ta[8], sb[8], tb[8];
-            if (KIND != SRC_RAW) {
+            if (KIND == SRC_ACT || KIND == SRC_ACT2) {
                 const float* t0 = tab + slab * 32 + c16 * 8;
     #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -1379,7 +1417,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
                 for (int g = 0; g < G::ACC; ++g) {
                     size_t pix; bool valid;
                     G::out_pixel(g, a, n, ty, tx, wave, col, pix, valid);
-                    store_pixel_tiles_rmw<NT>(acc[g], a, pix, valid, half, co_base, old[FWD ? 0 : g], rmw, stat, stat_mode, yraw[FWD ? 0 : g], bnc);
+                    if constexpr (ACT) store_pixel_tiles_act<NT>(acc[g], a, pix, valid, half, co_base, bnc, C_OUT);
+                    else store_pixel_tiles_rmw<NT>(acc[g], a, pix, valid, half, co_base, old[FWD ? 0 : g], rmw, stat, stat_mode, yraw[FWD ? 0 : g], bnc);
                 }
                 if constexpr (DEEP) {
                     if (pre_any) {
@@ -1486,6 +1525,16 @@ void launch_ws(const ConvArgs& a, int tiles_x, int tiles_y, int flip, hipStream_
     };
     // the forward-only form exists where it buys something: four accumulator groups at NT = 2 (cont forward), whose bn
     // statistics sums take the registers the backward forms spend on prefetched epilogue operands
+    if (a.out_scale) {   // inference: activation-storing epilogue, plain-copy (or skip-add) staging
+        ANH_REQUIRE(a.out_shift && !a.stat_partials && !a.bnred_partials && !a.out_accumulate && !a.out2, "conv_ws: the activation-storing form takes no training epilogue");
+        switch (a.src.kind) {
+            case SRC_RAW: launch(conv3x3_ws_kernel<G, NT, SRC_RAW, true, true>); break;
+            case SRC_SUM2: launch(conv3x3_ws_kernel<G, NT, SRC_SUM2, true, true>); break;
+            default: fail(ANH_ERR_INTERNAL, "conv_ws: the activation-storing form reads post-activation tensors");
+        }
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
     constexpr bool HAS_FWD_FORM = G::ACC * NT > 4;
     const bool fwd_form = HAS_FWD_FORM && a.stat_partials && !a.bnred_partials && !a.out_accumulate && !a.out2;
     if constexpr (HAS_FWD_FORM) {
@@ -1995,7 +2044,8 @@ __global__ __launch_bounds__(256, 2) void stem_mfma_kernel(ConvArgs a, int tiles
             const bool valid = oy < a.h_out && ox < a.w_out;
             const size_t pix = ((size_t)n * a.h_out + (valid ? oy : 0)) * a.w_out + (valid ? ox : 0);
             f32x16 one[1] = {acc[g]};
-            store_pixel_tiles_rmw<1>(one, a, pix, valid, half, 0, none, false, stat, fuse_stats ? 1 : 0);
+            if (a.out_scale) store_pixel_tiles_act<1>(one, a, pix, valid, half, 0, a.out_scale, 32);   // inference: [scale | shift][32] in global memory
+            else store_pixel_tiles_rmw<1>(one, a, pix, valid, half, 0, none, false, stat, fuse_stats ? 1 : 0);
         }
     }
     if (fuse_stats) {   // per-lane running sums -> one partial per workgroup, [channel][sum | sum of squares][workgroup] (as conv3x3_ws)
@@ -2033,6 +2083,7 @@ void launch_stem_mfma(const ConvArgs& a, hipStream_t s) {
     const int tiles_x = (a.w_out + 31) / 32, tiles_y = (a.h_out + 7) / 8;
     const int total = tiles_x * tiles_y * a.n;
     const dim3 grid((unsigned)stem_mfma_blocks(a)), block(256);
+    ANH_REQUIRE(!a.out_scale || (a.out_shift == a.out_scale + 32 && !a.stat_partials), "stem_mfma: the activation-storing form takes [scale | shift] as one table");
     if (a.c_red == 3) hipLaunchKernelGGL((stem_mfma_kernel<3>), grid, block, 0, s, a, tiles_x, tiles_y, total);
     else hipLaunchKernelGGL((stem_mfma_kernel<1>), grid, block, 0, s, a, tiles_x, tiles_y, total);
     HIP_CHECK(hipGetLastError());
@@ -2076,6 +2127,7 @@ bool mfma_conv_supported(const ConvArgs& a) {
     if (stem_mfma_ok(a)) return true;
     if (a.k != 3 || !a.w_bf16) return false;
     if (a.src.kind == SRC_IMAGE || a.src.dtype != DT_BF16 || a.out_dtype != DT_BF16 || a.out_nchw || a.bias) return false;
+    if ((a.src.kind == SRC_SUM2 || a.out_scale) && !ws_form_ok(a)) return false;   // inference forms: persistent kernels only
     if (a.c_red % 32 != 0) return false;
     // output channels: 32, or any multiple of 64 up to 256 (workgroup groups of 64 channels: levels = 3 reaches 256)
     const bool c_ok = a.c_out == 32 || a.c_out == 64 || a.c_out == 128 || a.c_out == 256;
@@ -2117,6 +2169,12 @@ ConvPlan conv_plan(const ConvArgs& a) {
 namespace {
 bool ws_form_ok(const ConvArgs& a) { return a.k == 3 && conv_plan(a).form == 2; }
 }  // namespace
+
+bool conv_stores_activation(const ConvArgs& a) {
+    if (a.out_dtype != DT_BF16 || !mfma_conv_supported(a)) return false;
+    if (stem_mfma_ok(a)) return a.c_out == 32;
+    return ws_form_ok(a) && (a.src.kind == SRC_RAW || a.src.kind == SRC_SUM2);
+}
 
 int conv_fused_stat_blocks(const ConvArgs& a) {
     if (!mfma_conv_supported(a) || (int64_t)a.n * a.h_out * a.w_out == 0) return 0;

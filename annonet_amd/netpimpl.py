@@ -315,6 +315,12 @@ class RuntimeNet(_Profiled):
         check(self.L.anh_runtime_get_stream(self.h, C.byref(s)))
         return s.value or 0
 
+    def stores_activations(self):
+        """whether the handle's last inference pass stored post-activation tensors (anh_runtime_stores_activations)"""
+        yes = C.c_int()
+        check(self.L.anh_runtime_stores_activations(self.h, C.byref(yes)))
+        return bool(yes.value)
+
 
 def annonet_infer(net, input_image, gains=None, detection_levels=None, tiling_parameters=None, want_blended=False):
     """annonet_infer() (annonet_infer.h:34-42): returns the u16 label image (and the blended class planes)."""

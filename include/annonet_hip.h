@@ -139,6 +139,11 @@ int anh_argmax_device(anh_runtime* h, const float* d_blended, int height, int wi
    gradient bucket, torch kernels on the blended planes) takes the handle's stream with _get_stream and enqueues that work on it. */
 int anh_runtime_set_stream(anh_runtime* h, void* hip_stream);
 int anh_runtime_get_stream(anh_runtime* h, void** hip_stream);
+/* bf16 inference has two forms: when every layer runs on a persistent MFMA kernel, each layer stores its post-activation output
+ * relu(bn(y)) (one rounding of the fp32 accumulator); otherwise layers store the raw conv output and consumers re-apply bn + relu.
+ * *yes = the form of the handle's LAST inference pass (parity tests pick the matching CPU restatement; ANH_INFER_POST_ACT=0 forces
+ * the second form). */
+int anh_runtime_stores_activations(anh_runtime* h, int* yes);
 int anh_runtime_synchronize(anh_runtime* h);
 
 /* ---- TrainingNet (annonet_train_main.cpp:396-410) ---- */

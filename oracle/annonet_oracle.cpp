@@ -300,7 +300,11 @@ struct Net {
     // hyper-parameters (annonet_train_main.cpp:396-410)
     double lr = 0.1, weight_decay = 0.0005, mom = 0.9;
     unsigned long bn_window = 100;
-    bool emulate_bf16 = false;  // round weights, conv inputs, stored conv outputs and stored gradients to bf16
+    // bf16 storage points of the HIP path (0 = fp32): weights, conv inputs and stored gradients rounded to bf16, and
+    //   training passes: the stored RAW conv outputs y (consumers re-apply bn + relu to the rounded y);
+    //   inference passes (1): the stored ACTIVATIONS relu(bn(y)) — the epilogue applies the layer's folded bn + relu to the fp32
+    //   accumulators and rounds once; (2): raw-output storage in inference as well (the library with ANH_INFER_POST_ACT=0)
+    int emulate_bf16 = 0;
     // scratch
     std::vector<Tensor> raw, act, dact;
     Tensor image;
@@ -362,7 +366,8 @@ void forward(Net& net, bool training, std::vector<BnBatch>* bn_out) {
         std::vector<float> wt = layer_weights(net, L);
         conv_forward(L, wt, x, net.raw[li]);
         Tensor& y = net.raw[li];
-        if (net.emulate_bf16 && L.has_bn) round_tensor(y.d);  // raw conv outputs are stored as bf16; logits stay fp32
+        const bool act_storage = net.emulate_bf16 == 1 && !training;
+        if (net.emulate_bf16 && !act_storage && L.has_bn) round_tensor(y.d);  // raw conv outputs are stored as bf16; logits stay fp32
         Tensor& a = net.act[li];
         a.resize(y.n, y.h, y.w, y.c);
         const size_t P = y.pixels();
@@ -396,6 +401,7 @@ void forward(Net& net, bool training, std::vector<BnBatch>* bn_out) {
                     const float z = fmaf(y.d[p * C + c], scale[c], shift[c]);
                     a.d[p * C + c] = z > 0.f ? z : 0.f;  // relu
                 }
+            if (act_storage) round_tensor(a.d);   // the activation is what is stored
         } else {
             const float* b = L.has_bias ? net.params.data() + L.b_off : nullptr;
             for (size_t p = 0; p < P; ++p)
@@ -654,7 +660,7 @@ double* orc_net_running_updates(void* h) { return ((Net*)h)->running_count.data(
 void orc_net_set_hyper(void* h, double lr, double wd, double mom, unsigned long bn_window) {
     Net* n = (Net*)h; n->lr = lr; n->weight_decay = wd; n->mom = mom; n->bn_window = bn_window;
 }
-void orc_net_set_bf16_emulation(void* h, int on) { ((Net*)h)->emulate_bf16 = on != 0; }
+void orc_net_set_bf16_emulation(void* h, int mode) { ((Net*)h)->emulate_bf16 = mode < 0 ? 0 : mode; }
 int orc_required_input_dim(void* h) { return required_dim(((Net*)h)->spec); }
 int orc_recommended_input_dim(int levels, int n) { return recommended_dim(levels, n); }
 

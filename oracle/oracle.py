@@ -148,7 +148,9 @@ class OracleNet:
         self.L.orc_net_set_hyper(self.h, lr, wd, mom, bn_window)
 
     def set_bf16_emulation(self, on=True):
-        """Round weights, conv inputs, stored conv outputs and stored gradients to bf16 (the ANH_BF16 storage points)."""
+        """Restate the ANH_BF16 storage points: weights, conv inputs and stored gradients rounded to bf16; training passes store the
+        raw conv outputs, inference passes the activations (on=2: raw outputs in inference too, the library under
+        ANH_INFER_POST_ACT=0)."""
         self.L.orc_net_set_bf16_emulation(self.h, int(on))
 
     def required_input_dim(self):

@@ -254,8 +254,10 @@ def test_bf16_forward(levels, scaler, minf):
     d = o.recommended_input_dim(45)
     img = rng.integers(0, 256, (2, d, d + (1 << levels), 3), dtype=np.uint8)
     got = net.Forward(img)
-    # (a) bf16-restating oracle: only fp32 accumulation order and rare rounding-boundary flips differ
-    o.set_bf16_emulation(True)
+    # (a) bf16-restating oracle: only fp32 accumulation order and rare rounding-boundary flips differ.  Nets whose layers all run on
+    # the persistent MFMA kernels store post-activation tensors in inference, the others raw conv outputs: the oracle restates either
+    assert net.stores_activations() or scaler != 1.0     # the full-width nets take the activation-storing form
+    o.set_bf16_emulation(1 if net.stores_activations() else 2)
     emu = o.forward(img)
     span = emu.max() - emu.min()
     assert np.abs(got - emu).max() <= 4e-3 * span, (np.abs(got - emu).max(), span)
@@ -286,7 +288,7 @@ def test_bf16_tiled_inference_full_width_net():
     labels, blended = aa.annonet_infer(net, img, tiling_parameters=tp, want_blended=True)
     streamed = aa.annonet_infer(net, img, tiling_parameters=tp)           # the streamed host path (no planes requested)
     np.testing.assert_array_equal(streamed, labels)
-    o.set_bf16_emulation(True)
+    o.set_bf16_emulation(1 if net.stores_activations() else 2)
     want_labels, want = o.infer(img, max_tile=(96, 128), overlap=ov, want_blended=True)
     span = want.max() - want.min()
     # the worst pixel is one bf16 rounding flip in the last hidden layer times a large head weight (identical with the

@@ -139,3 +139,15 @@ def test_tile_batch_size_does_not_change_the_result(tmp_path):
             np.testing.assert_array_equal(runs[batch][key], runs["1"][key], err_msg=f"batch {batch}: {key}")
     for prec in ("bf16", "fp32"):
         np.testing.assert_array_equal(runs["4"][prec + "_labels_streamed"], runs["4"][prec + "_labels"])
+    # the other bf16 inference form (raw conv outputs stored, consumers re-apply bn + relu: ANH_INFER_POST_ACT=0) differs by bf16
+    # rounding points only; the fp32 mode does not have two forms
+    out = str(tmp_path / "raw.npz")
+    r = subprocess.run([sys.executable, os.path.join(here, "helpers", "run_tiled_infer.py"), out], env=dict(os.environ, ANH_INFER_POST_ACT="0"),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    raw = np.load(out)
+    np.testing.assert_array_equal(raw["fp32_labels"], runs["4"]["fp32_labels"])
+    np.testing.assert_array_equal(raw["fp32_blended"], runs["4"]["fp32_blended"])
+    span = float(runs["4"]["bf16_blended"].max() - runs["4"]["bf16_blended"].min())
+    assert np.abs(raw["bf16_blended"] - runs["4"]["bf16_blended"]).max() <= 0.02 * span
+    assert (raw["bf16_labels"] != runs["4"]["bf16_labels"]).mean() <= 0.03     # random-init net: near-ties everywhere
