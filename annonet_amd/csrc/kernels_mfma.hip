@@ -1971,8 +1971,10 @@ WgSide side_of(const ConvArgs& a) { return side_of_src(a.src, a.h_in, a.w_in, a.
 // 16 contiguous, 8-byte aligned bytes: two ds_read_b64.  The padded weights (A operand, 10 fragments) are gathered
 // once per workgroup into registers; workgroups are persistent over a strided set of 8x32 tiles.
 // ---------------------------------------------------------------------------------------------------------------
-template <int CIN>
-__global__ __launch_bounds__(256, 2) void stem_mfma_kernel(ConvArgs a, int tiles_x, int tiles_y, int total_tiles) {
+// ACT: the inference form — the epilogue stores relu(bn(y)) (ConvArgs::out_scale), no statistics: 32 fewer registers and none of
+// the 32 KB reduction buffer, so four workgroups instead of three share a CU.
+template <int CIN, bool ACT = false>
+__global__ __launch_bounds__(256, (ACT ? 4 : 2)) void stem_mfma_kernel(ConvArgs a, int tiles_x, int tiles_y, int total_tiles) {
     constexpr int SPW = 48;                      // patch pixels per row: 36 used + padding read by the zero-weight positions
     __shared__ __attribute__((aligned(16))) unsigned long long patch[12 * SPW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
@@ -1992,7 +1994,7 @@ __global__ __launch_bounds__(256, 2) void stem_mfma_kernel(ConvArgs a, int tiles
                 wf[ky][ks][j] = (bf16)w;
             }
 
-    const bool fuse_stats = a.stat_partials != nullptr;   // training forward: bn statistics of the stored output, as conv3x3_ws
+    const bool fuse_stats = !ACT && a.stat_partials != nullptr;   // training forward: bn statistics of the stored output, as conv3x3_ws
     float stat[1][2][16];
     u32x4 none[1][2];
 #pragma unroll
@@ -2002,25 +2004,63 @@ __global__ __launch_bounds__(256, 2) void stem_mfma_kernel(ConvArgs a, int tiles
         for (int e = 0; e < 16; ++e) stat[0][s2][e] = 0.f;
     }
     for (int i = tid; i < 12 * SPW; i += 256) patch[i] = 0ull;
-    for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+    // The patch pixels of the NEXT tile are requested while the MFMAs and the epilogue of the current one run (two 12x36-pixel
+    // slots per thread, kept in registers as raw bytes): a tile no longer waits a memory round trip before its first MFMA.
+    // A pixel is ONE unaligned 4-byte load (its CIN bytes + bytes of the next pixel, masked off); the image's very last pixel, whose
+    // fourth byte would lie outside the buffer, is read byte by byte.
+    constexpr int NPX = 2;                        // ceil(12 * 36 / 256)
+    unsigned praw[NPX];
+    unsigned pvalid = 0;
+    int ppy[NPX], ppx[NPX];                       // this thread's patch positions: the same for every tile
+#pragma unroll
+    for (int u = 0; u < NPX; ++u) { const int i = min(tid + 256 * u, 12 * 36 - 1); ppy[u] = i / 36; ppx[u] = i - ppy[u] * 36; }
+    const size_t img_pixels = (size_t)a.src.img_h * a.src.img_w;
+    auto fetch = [&](int tile_) __attribute__((always_inline)) {
+        const int tx = tile_ % tiles_x, ty = (tile_ / tiles_x) % tiles_y, n = tile_ / (tiles_x * tiles_y);
+        const int x0 = tx * 32, y0 = ty * 8;
+        const uint8_t* img = a.src.img + (size_t)n * a.src.img_sample_stride;
+        pvalid = 0;
+#pragma unroll
+        for (int u = 0; u < NPX; ++u) {
+            const int iy = y0 - 2 + ppy[u], ix = x0 - 2 + ppx[u];
+            const int sy = min(max(a.src.win_top(n) + iy, 0), a.src.img_h - 1), sx = min(max(a.src.win_left(n) + ix, 0), a.src.img_w - 1);
+            const size_t pixel = (size_t)sy * a.src.img_w + sx;
+            const uint8_t* src = img + pixel * CIN;
+            unsigned v;
+            if (CIN == 3 && pixel + 1 < img_pixels) {
+                unsigned w;
+                __builtin_memcpy(&w, src, 4);     // one unaligned dword load
+                v = w & 0x00ffffffu;
+            } else {
+                v = src[0];
+                if (CIN == 3) v |= ((unsigned)src[1] << 8) | ((unsigned)src[2] << 16);
+            }
+            praw[u] = v;
+            pvalid |= ((iy >= 0 && iy < a.h_in && ix >= 0 && ix < a.w_in) ? 1u : 0u) << u;
+        }
+    };
+    int tile = blockIdx.x;
+    if (tile < total_tiles) fetch(tile);
+    for (; tile < total_tiles; tile += gridDim.x) {
         const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
         const int x0 = tx * 32, y0 = ty * 8;
         __syncthreads();
-        for (int i = tid; i < 12 * 36; i += 256) {
-            const int py = i / 36, px = i - py * 36;
-            const int iy = y0 - 2 + py, ix = x0 - 2 + px;
-            unsigned long long v = 0ull;
-            if (iy >= 0 && iy < a.h_in && ix >= 0 && ix < a.w_in) {
-                const int sy = min(max(a.src.win_top(n) + iy, 0), a.src.img_h - 1), sx = min(max(a.src.win_left(n) + ix, 0), a.src.img_w - 1);
-                const uint8_t* src = a.src.img + (size_t)n * a.src.img_sample_stride + ((size_t)sy * a.src.img_w + sx) * CIN;
-                unsigned short c[4] = {0, 0, 0, 0};
 #pragma unroll
-                for (int ch = 0; ch < CIN; ++ch) c[ch] = __builtin_bit_cast(unsigned short, (bf16)((float)src[ch] * (1.0f / 256.0f)));
-                v = (unsigned long long)c[0] | ((unsigned long long)c[1] << 16) | ((unsigned long long)c[2] << 32) | ((unsigned long long)c[3] << 48);
+        for (int u = 0; u < NPX; ++u) {
+            const int i = tid + 256 * u;
+            if (i < 12 * 36) {
+                unsigned long long v = 0ull;
+                if ((pvalid >> u) & 1u) {
+                    unsigned short c[4] = {0, 0, 0, 0};
+#pragma unroll
+                    for (int ch = 0; ch < CIN; ++ch) c[ch] = __builtin_bit_cast(unsigned short, (bf16)((float)((praw[u] >> (8 * ch)) & 0xffu) * (1.0f / 256.0f)));
+                    v = (unsigned long long)c[0] | ((unsigned long long)c[1] << 16) | ((unsigned long long)c[2] << 32) | ((unsigned long long)c[3] << 48);
+                }
+                patch[ppy[u] * SPW + ppx[u]] = v;
             }
-            patch[py * SPW + px] = v;
         }
         __syncthreads();
+        if (tile + (int)gridDim.x < total_tiles) fetch(tile + (int)gridDim.x);
         f32x16 acc[2];
 #pragma unroll
         for (int g = 0; g < 2; ++g)
@@ -2044,11 +2084,11 @@ __global__ __launch_bounds__(256, 2) void stem_mfma_kernel(ConvArgs a, int tiles
             const bool valid = oy < a.h_out && ox < a.w_out;
             const size_t pix = ((size_t)n * a.h_out + (valid ? oy : 0)) * a.w_out + (valid ? ox : 0);
             f32x16 one[1] = {acc[g]};
-            if (a.out_scale) store_pixel_tiles_act<1>(one, a, pix, valid, half, 0, a.out_scale, 32);   // inference: [scale | shift][32] in global memory
+            if constexpr (ACT) store_pixel_tiles_act<1>(one, a, pix, valid, half, 0, a.out_scale, 32);   // inference: [scale | shift][32] in global memory
             else store_pixel_tiles_rmw<1>(one, a, pix, valid, half, 0, none, false, stat, fuse_stats ? 1 : 0);
         }
     }
-    if (fuse_stats) {   // per-lane running sums -> one partial per workgroup, [channel][sum | sum of squares][workgroup] (as conv3x3_ws)
+    if constexpr (!ACT) if (fuse_stats) {   // per-lane running sums -> one partial per workgroup, [channel][sum | sum of squares][workgroup] (as conv3x3_ws)
         __shared__ float red[256 * 32];
         __syncthreads();
 #pragma unroll
@@ -2077,14 +2117,17 @@ bool stem_mfma_ok(const ConvArgs& a) {
 }
 int stem_mfma_blocks(const ConvArgs& a) {
     const int total = ((a.w_out + 31) / 32) * ((a.h_out + 7) / 8) * a.n;
-    return std::min(total, 1024);
+    return std::min(total, 1024);   // four workgroups per CU (the training form's registers admit three at a time)
 }
 void launch_stem_mfma(const ConvArgs& a, hipStream_t s) {
     const int tiles_x = (a.w_out + 31) / 32, tiles_y = (a.h_out + 7) / 8;
     const int total = tiles_x * tiles_y * a.n;
     const dim3 grid((unsigned)stem_mfma_blocks(a)), block(256);
     ANH_REQUIRE(!a.out_scale || (a.out_shift == a.out_scale + 32 && !a.stat_partials), "stem_mfma: the activation-storing form takes [scale | shift] as one table");
-    if (a.c_red == 3) hipLaunchKernelGGL((stem_mfma_kernel<3>), grid, block, 0, s, a, tiles_x, tiles_y, total);
+    if (a.out_scale) {
+        if (a.c_red == 3) hipLaunchKernelGGL((stem_mfma_kernel<3, true>), grid, block, 0, s, a, tiles_x, tiles_y, total);
+        else hipLaunchKernelGGL((stem_mfma_kernel<1, true>), grid, block, 0, s, a, tiles_x, tiles_y, total);
+    } else if (a.c_red == 3) hipLaunchKernelGGL((stem_mfma_kernel<3>), grid, block, 0, s, a, tiles_x, tiles_y, total);
     else hipLaunchKernelGGL((stem_mfma_kernel<1>), grid, block, 0, s, a, tiles_x, tiles_y, total);
     HIP_CHECK(hipGetLastError());
 }
