@@ -1124,6 +1124,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
     // per-phase wall-clock accounting, compiled in with -DANH_WS_PROFILE (ANH_WS_PROF=1 then prints one line per launch)
 #ifdef ANH_WS_PROFILE
     long long t_a = 0, t_b = 0, t_c = 0, t0_;
+    const long long t_entry = wall_clock64();   // absolute (the counter is chip-wide): launch skew, prologue and tail of the kernel
+    long long t_loop = 0, t_loop_end = 0;
 #define TICK() (t0_ = wall_clock64())
 #define TOCK(acc_) (acc_ += wall_clock64() - t0_)
 #else
@@ -1321,6 +1323,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
             if (++slab == n_slabs) { slab = 0; tile += gstep; }
             ++it;
         };
+#ifdef ANH_WS_PROFILE
+        t_loop = wall_clock64();
+#endif
         while (tile < n_tiles) {
             one_item(R0);
             if (DEEP2) {
@@ -1328,6 +1333,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
                 one_item(R1);
             }
         }
+#ifdef ANH_WS_PROFILE
+        t_loop_end = wall_clock64();
+#endif
     } else {
         init_tables();
         typename G::Bases b0;
@@ -1472,7 +1480,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
         }
     }
 #ifdef ANH_WS_PROFILE
-    if (prof && lane == 0) { long long* o = prof + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (producer ? 4 : 0) + wave) * 4; o[0] = t_a; o[1] = t_b; o[2] = t_c; o[3] = it; }
+    if (prof && lane == 0) {
+        long long* o = prof + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (producer ? 4 : 0) + wave) * 8;
+        o[0] = t_a; o[1] = t_b; o[2] = t_c; o[3] = it; o[4] = t_entry; o[5] = t_loop; o[6] = t_loop_end; o[7] = wall_clock64();
+    }
 #endif
 #undef TICK
 #undef TOCK
@@ -1504,22 +1515,32 @@ void launch_ws(const ConvArgs& a, int tiles_x, int tiles_y, int flip, hipStream_
 #else
         static const int prof_on = getenv("ANH_WS_PROF") ? atoi(getenv("ANH_WS_PROF")) : 0;
         static long long* prof = nullptr;
-        if (prof_on && !prof) HIP_CHECK(hipMalloc(&prof, 1024 * 8 * 4 * sizeof(long long)));
+        if (prof_on && !prof) HIP_CHECK(hipMalloc(&prof, 1024 * 8 * 8 * sizeof(long long)));
         hipLaunchKernelGGL(kernel, grid, block, lds, s, a, tiles_x, tiles_y, flip, prof_on ? prof : nullptr, wres | (role_map << 1));
         if (prof_on) {
             HIP_CHECK(hipStreamSynchronize(s));
             const int nwg = grid.x * grid.y;
-            std::vector<long long> h((size_t)nwg * 32);
+            std::vector<long long> h((size_t)nwg * 64);
             HIP_CHECK(hipMemcpy(h.data(), prof, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
             double pa = 0, pb = 0, pc = 0, ca = 0, cb = 0, cc = 0, items = 0;
+            long long first_entry = h[4], last_exit = h[7];
+            double entry = 0, pro = 0, loop = 0, tail = 0;   // over the consumer waves: entry skew, entry -> loop, loop, loop end -> exit
             for (int w = 0; w < nwg; ++w) {
-                for (int v = 0; v < 4; ++v) { ca += h[(w * 8 + v) * 4]; cb += h[(w * 8 + v) * 4 + 1]; cc += h[(w * 8 + v) * 4 + 2]; }
-                for (int v = 4; v < 8; ++v) { pa += h[(w * 8 + v) * 4]; pb += h[(w * 8 + v) * 4 + 1]; pc += h[(w * 8 + v) * 4 + 2]; }
-                items += h[(w * 8) * 4 + 3];
+                for (int v = 0; v < 8; ++v) { first_entry = std::min(first_entry, h[(w * 8 + v) * 8 + 4]); last_exit = std::max(last_exit, h[(w * 8 + v) * 8 + 7]); }
+                for (int v = 0; v < 4; ++v) { ca += h[(w * 8 + v) * 8]; cb += h[(w * 8 + v) * 8 + 1]; cc += h[(w * 8 + v) * 8 + 2]; }
+                for (int v = 4; v < 8; ++v) { pa += h[(w * 8 + v) * 8]; pb += h[(w * 8 + v) * 8 + 1]; pc += h[(w * 8 + v) * 8 + 2]; }
+                items += h[(w * 8) * 8 + 3];
             }
+            for (int w = 0; w < nwg; ++w)
+                for (int v = 4; v < 8; ++v) {   // producer waves carry the loop stamps
+                    const long long* o = &h[(w * 8 + v) * 8];
+                    entry += (double)(o[4] - first_entry); pro += (double)(o[5] - o[4]); loop += (double)(o[6] - o[5]); tail += (double)(o[7] - o[6]);
+                }
             const double k = 1.0 / (4.0 * nwg) / 100.0;  // wall clock = 100 MHz -> us per wave
-            fprintf(stderr, "[ws prof] geo_recs=%d NT=%d kind=%d c_red=%d wgs=%d items/wg=%.1f | producer us: commit %.1f fetch %.1f barrier %.1f | consumer us: mfma %.1f store %.1f barrier %.1f\n",
-                    G::RECS, NT, a.src.kind, a.c_red, nwg, items / nwg, pa * k, pb * k, pc * k, ca * k, cb * k, cc * k);
+            fprintf(stderr, "[ws prof] geo_recs=%d NT=%d kind=%d c_red=%d wgs=%d items/wg=%.1f | producer us: commit %.1f fetch %.1f barrier %.1f | consumer us: mfma %.1f store %.1f barrier %.1f"
+                            " | kernel %.1f us = launch skew %.1f + prologue %.1f + loop %.1f + tail %.1f (+ drain to the last wave)\n",
+                    G::RECS, NT, a.src.kind, a.c_red, nwg, items / nwg, pa * k, pb * k, pc * k, ca * k, cb * k, cc * k,
+                    (double)(last_exit - first_entry) / 100.0, entry * k, pro * k, loop * k, tail * k);
         }
 #endif
     };
