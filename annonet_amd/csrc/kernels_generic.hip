@@ -480,19 +480,32 @@ __global__ __launch_bounds__(256) void conv_f32_mfma_vec_kernel(ConvArgs a, int 
             for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(and_mask(it.wv[st][nt], co_m[nt]), b, acc[nt], 0, 0, 0);
         }
     };
-    Item A, B;
-    if (next()) {
-        load(A);
-        for (;;) {
-            const bool more_b = next();
-            if (more_b) load(B);
-            compute(A);
-            if (!more_b) break;
-            const bool more_a = next();
-            if (more_a) load(A);
-            compute(B);
-            if (!more_a) break;
-        }
+    // Four items in flight per wave: an item is only four 64-cycle matrix instructions, and at 3-5 waves per SIMD two items per wave
+    // cover a fraction of a memory round trip (the kernel ran at a third of the fp32 matrix rate).  The items are consumed strictly in
+    // walk order — the oracle's summation order.
+    Item I0, I1, I2, I3;
+    bool m0 = next();
+    if (m0) load(I0);
+    bool m1 = m0 && next();
+    if (m1) load(I1);
+    bool m2 = m1 && next();
+    if (m2) load(I2);
+    while (m0) {
+        const bool m3 = m2 && next();
+        if (m3) load(I3);
+        compute(I0);
+        if (!m1) break;
+        m0 = m3 && next();
+        if (m0) load(I0);
+        compute(I1);
+        if (!m2) break;
+        m1 = m0 && next();
+        if (m1) load(I1);
+        compute(I2);
+        if (!m3) break;
+        m2 = m1 && next();
+        if (m2) load(I2);
+        compute(I3);
     }
     if (!px_live) return;
     const size_t opix = ((size_t)n * a.h_out + oy) * a.w_out + ox;
