@@ -56,8 +56,10 @@ struct anh_runtime {
     size_t replicas() const { return 1 + extra.size(); }
     int device_of(size_t r) const { return devices.empty() ? -1 : devices[r]; }
     Engine& replica(size_t r) { return r == 0 ? *eng : *extra[r - 1].eng; }
-    void build(const anh_net_config& cfg) {
+    // `only_device` >= 0: ONE replica on that device whatever anh_set_devices named (a trainer's snapshot, below)
+    void build(const anh_net_config& cfg, int only_device = -1) {
         devices = selected_devices();
+        if (only_device >= 0) devices.assign(1, only_device);
         { DeviceScope scope(device_of(0)); eng = std::make_unique<Engine>(cfg, false); }
         for (size_t r = 1; r < devices.size(); ++r) { DeviceScope scope(devices[r]); extra.push_back(Replica{std::make_unique<Engine>(cfg, false)}); }
         if (devices.size() > 1) coll = std::make_unique<Collective>(devices);
@@ -156,9 +158,12 @@ struct anh_trainer {
             dirty = false;
         }
         if (resume_pending) {   // the reference names the file BEFORE SetClassCount (annonet_train_main.cpp:400-405): resume on first use
-            resume_pending = false;
             std::ifstream probe(sync_path, std::ios::binary);
+            // A file that exists but cannot be loaded (older format, another net, truncated) is an ERROR on every use of the net until the
+            // caller removes it or names another: the flag is cleared only once the resume has succeeded, so no step can run — and the
+            // periodic save can never overwrite a state the user still has — after a failed resume.
             if (probe.good()) { probe.close(); resume(); }
+            resume_pending = false;
         }
         return *eng;
     }
@@ -466,9 +471,7 @@ int anh_argmax_device(anh_runtime* h, const float* d_blended, int height, int wi
         ANH_REQUIRE(h && d_blended && d_result, "null argument");
         ANH_REQUIRE(height >= 1 && width >= 1 && row0 >= 0 && row0 <= row1 && row1 <= height, "argmax: bad row range");
         DeviceScope scope(h->device_of(0));
-        Engine& e = *h->eng;
-        const double* d_gains = e.upload_gains(gains);
-        launch_argmax_range(d_blended, e.spec.cfg.classes, (int64_t)height * width, (int64_t)row0 * width, (int64_t)row1 * width, d_gains, d_result, e.stream);
+        h->eng->argmax_rows(d_blended, height, width, row0, row1, gains, d_result);
     });
 }
 
@@ -754,8 +757,10 @@ int anh_trainer_set_synchronization_file(anh_trainer* h, const char* path, doubl
 }
 double anh_trainer_get_learning_rate(const anh_trainer* h) {
     if (!h) return 0;
-    // a pending resume may change the rate: the host polls this in its loop condition before the first step (annonet_train_main.cpp:583)
-    if (h->resume_pending && h->initialized) { try { (void)const_cast<anh_trainer*>(h)->engine(); } catch (...) {} }
+    // a pending resume may change the rate: the host polls this in its loop condition before the first step (annonet_train_main.cpp:583).
+    // This getter has no status to return: a resume that fails here leaves resume_pending set and the message in anh_last_error(), and
+    // the next call with a status (StartTraining) fails with the same error.
+    if (h->resume_pending && h->initialized) (void)guarded([&] { (void)const_cast<anh_trainer*>(h)->engine(); });
     return h->sched.lr;   // changes only inside apply_update, at the fixed loss lag: no timing-dependent polling
 }
 double anh_trainer_get_last_loss(anh_trainer* h) {
@@ -986,8 +991,12 @@ int anh_trainer_snapshot_runtime(anh_trainer* h, int precision, anh_runtime** ou
         e.get_params(p.data(), r.data());  // synchronises: a step in flight finishes first (annonet_train_main.cpp:558)
         anh_net_config cfg = e.spec.cfg;
         cfg.precision = precision;
+        // A snapshot is ONE replica on the trainer's first device: the host serializes it (annonet_train_main.cpp:557-565, at step 0,
+        // every save interval and at the end) while the trainer's own communicator may have collectives in flight — no second set of
+        // engines, no second ncclCommInitAll.  Handles the caller creates for inference (anh_runtime_create / _deserialize) span the
+        // selected devices.
         auto rt = std::make_unique<anh_runtime>();
-        rt->build(cfg);
+        rt->build(cfg, h->replicas() > 1 ? h->device_of(0) : -1);
         rt->set_params_all(p.data(), r.data());
         *out = rt.release();
     });

@@ -25,7 +25,9 @@ class Profiler {
     // entry names of the most recent pass in host enqueue order, one per begin() (kept whether or not that launch is timed):
     // tools/pmc_traffic.py maps the dispatches of a rocprofv3 trace onto bench.py's per-layer entries with it
     std::vector<std::string> order;
-    void start_pass() { ++pass_index; if (enabled) order.clear(); }
+    bool hold_order = false;   // inside annonet_infer(): `order` spans the whole image (every tile batch is a forward pass of its own)
+    void start_pass() { ++pass_index; if (enabled && !hold_order) order.clear(); }
+    void start_image() { if (enabled) order.clear(); hold_order = true; }
     ~Profiler();
     int begin(hipStream_t s, const char* name, double flops, double bytes);  // returns a token (or -1 when disabled)
     void end(hipStream_t s, int token);
@@ -116,6 +118,7 @@ class Engine {
     void choose_inference_form(const Src& image);
     int tile_batch(int h, int w) const;
     const double* upload_gains(const double* gains_host);   // -> device pointer (or nullptr)
+    void argmax_rows(const float* d_blended, int H, int W, int row0, int row1, const double* gains_host, uint16_t* d_labels);   // find_label over rows [row0, row1)
     void infer_device(const uint8_t* d_image, int H, int W, const double* gains_host, const std::vector<anh_tile>& tiles,
                       uint16_t* d_labels, float* d_blended);
 
@@ -128,6 +131,7 @@ class Engine {
 
   private:
     void plan_dims(int n, int h, int w);
+    void plan_dims_unguarded(int n, int h, int w);
     bool head_is_fused() const;
     Src layer_source(int li, const Src& image) const;
     void run_conv_forward(int li, const Src& image, bool training_pass, float* d_out_nchw);

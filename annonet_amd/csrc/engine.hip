@@ -261,7 +261,24 @@ void Engine::random_init(uint64_t seed) {
 // ---------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------
+// A mini-batch that does not fit (find_max_mini-batch_size.cmd:43-53 probes for exactly that) fails here, before any kernel of the pass
+// is enqueued, as ANH_ERR_OOM; the layer tensors grown so far are handed back, so the handle is as usable as before the call and a
+// smaller batch trains on it afterwards.
 void Engine::plan_dims(int n, int h, int w) {
+    try { plan_dims_unguarded(n, h, w); }
+    catch (const Error& e) {
+        if (e.code == ANH_ERR_OOM) {
+            (void)hipStreamSynchronize(stream);
+            if (aux_stream) (void)hipStreamSynchronize(aux_stream);
+            for (LayerState& s : ls) { s.raw.release(); s.dact.release(); s.bwd_partials.release(); }
+            logits.release(); dlogits.release(); loss_partials.release(); bn_partials.release();
+            have_forward = false;
+        }
+        throw;
+    }
+}
+
+void Engine::plan_dims_unguarded(int n, int h, int w) {
     ANH_REQUIRE(n >= 1, "empty batch");
     ANH_REQUIRE(spec.valid_input_dim(h) && spec.valid_input_dim(w),
                 "input size is not a valid net input dimension (see GetRecommendedInputDimension)");
@@ -350,7 +367,8 @@ void Engine::choose_inference_form(const Src& image) {
 
 void Engine::conv_dispatch(const ConvArgs& a, const char* tag, double flops, double bytes) {
     const bool fast = conv_takes_mfma(a, dtype);
-    std::string name = std::string(fast ? "conv_mfma_bf16:" : (dtype == DT_BF16 ? "conv_generic_bf16:" : "conv_generic_f32:")) + tag;
+    // the entry names the kernel family that runs: bf16 MFMA, fp32 MFMA (the parity mode on v_mfma_f32_32x32x2_f32), or the VALU kernels
+    std::string name = std::string(fast ? "conv_mfma_bf16:" : conv_f32_mfma_ok(a) ? "conv_mfma_f32:" : (dtype == DT_BF16 ? "conv_generic_bf16:" : "conv_generic_f32:")) + tag;
     const int tok = prof.begin(stream, name.c_str(), flops, bytes);
     if (fast) launch_conv_mfma(a, stream);
     else launch_conv_generic(a, stream);
@@ -465,6 +483,7 @@ void Engine::forward_inference(const Src& image, int n, int h, int w, float* d_o
 }
 
 void Engine::forward_training(const Src& image, int n, int h, int w) {
+    prof.hold_order = false;
     prof.start_pass();
     ANH_REQUIRE(training, "not a training net");
     plan_dims(n, h, w);
@@ -807,6 +826,7 @@ void Engine::infer_device(const uint8_t* d_image, int H, int W, const double* ga
     ANH_REQUIRE(H >= 1 && W >= 1, "empty image");
     const int K = spec.cfg.classes;
     const int64_t pixels = (int64_t)H * W;
+    prof.start_image();
     launch_fill_zero(d_blended, (size_t)K * pixels * 4, stream);
     // consecutive tiles with equal input windows (all of them, on a regular tiling) run as batches
     for (size_t i = 0; i < tiles.size();) {
@@ -821,12 +841,15 @@ void Engine::infer_device(const uint8_t* d_image, int H, int W, const double* ga
         infer_tiles(&tiles[i], (int)(j - i), d_image, H, W, d_blended);
         i = j;
     }
+    if (d_labels) argmax_rows(d_blended, H, W, 0, H, gains_host, d_labels);
+}
+
+void Engine::argmax_rows(const float* d_blended, int H, int W, int row0, int row1, const double* gains_host, uint16_t* d_labels) {
+    const int K = spec.cfg.classes;
     const double* d_gains = upload_gains(gains_host);
-    if (d_labels) {
-        const int tok = prof.begin(stream, "argmax_gain", 0, (double)pixels * (K * 4.0 + 2.0));
-        launch_argmax(d_blended, K, pixels, d_gains, d_labels, stream);
-        prof.end(stream, tok);
-    }
+    const int tok = prof.begin(stream, "argmax_gain", 0, (double)(row1 - row0) * W * (K * 4.0 + 2.0));
+    launch_argmax_range(d_blended, K, (int64_t)H * W, (int64_t)row0 * W, (int64_t)row1 * W, d_gains, d_labels, stream);
+    prof.end(stream, tok);
 }
 
 }  // namespace anh

@@ -88,6 +88,7 @@ struct WgradArgs {
 };
 
 void launch_conv_generic(const ConvArgs& a, hipStream_t s);
+bool conv_f32_mfma_ok(const ConvArgs& a);   // launch_conv_generic runs this conv on the fp32 matrix cores (conv_f32_mfma*), not on the VALU kernels
 void launch_wgrad_generic(const WgradArgs& a, hipStream_t s);
 int64_t wgrad_generic_scratch_floats(const WgradArgs& a);
 bool wgrad_accepts_bnbwd(const WgradArgs& a, DType mode);   // decided on the args with dy_y unset

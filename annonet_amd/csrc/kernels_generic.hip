@@ -532,7 +532,7 @@ __global__ __launch_bounds__(256) void conv_f32_mfma_vec_kernel(ConvArgs a, int 
         }
 }
 
-bool conv_f32_mfma_ok(const ConvArgs& a) {
+bool conv_f32_mfma_selected(const ConvArgs& a) {
     static const int on = getenv("ANH_FP32_MFMA") ? atoi(getenv("ANH_FP32_MFMA")) : 1;
     const bool in_f32 = a.src.kind == SRC_IMAGE || a.src.dtype == DT_F32;
     const bool out_f32 = a.out_nchw || a.out_dtype == DT_F32;
@@ -1681,10 +1681,12 @@ void run_detection_filter(const float* d_blended, uint16_t* d_labels, int k, int
 // ===================================================================================================
 // launchers
 // ===================================================================================================
+bool conv_f32_mfma_ok(const ConvArgs& a) { return conv_f32_mfma_selected(a); }
+
 void launch_conv_generic(const ConvArgs& a, hipStream_t s) {
     const int64_t total = (int64_t)a.n * a.h_out * a.w_out;
     if (total == 0) return;
-    if (conv_f32_mfma_ok(a)) {   // fp32 storage: the same k-ordered chains on v_mfma_f32_32x32x2_f32
+    if (conv_f32_mfma_selected(a)) {   // fp32 storage: the same k-ordered chains on v_mfma_f32_32x32x2_f32
         if (a.c_out > 64) launch_conv_f32_mfma_nt<4>(a, s);
         else if (a.c_out > 32) launch_conv_f32_mfma_nt<2>(a, s);
         else launch_conv_f32_mfma_nt<1>(a, s);

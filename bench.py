@@ -8,6 +8,11 @@ SGD update), batch 32 per GPU, bf16, random-init net (levels 2, width 1.0, K=3),
 
 One process per GPU; for N > 1 the only exchange step of the path is the all-reduce (RCCL) of the flat gradient
 bucket (training) / of the cross-rank overlap sums (inference).  Inputs are resident in HBM before the timed region.
+Before the W warm-up steps the workload runs untimed for `prewarm_s` seconds (declared in the line) so that the clocks have
+settled when a short --steps / --warmup run is timed.  The default (training) line also carries an `infer` object: tiled
+inference over a 4096^2 image (BASELINE.json configs[2]; 16384^2 = configs[4] for N > 1), measured by a child process that
+runs `bench.py --mode infer` after the training measurement has finished (a failure there is reported inside `infer`, it
+cannot take the training line with it).
 Prints ONE JSON line on rank 0, with
   roofline     — the §8d conv entry (layer x pass) with the largest time: algorithmic flops and minimum bytes per launch
                   / its mean launch time, measured with HIP events on the compute stream inside the
@@ -44,7 +49,18 @@ PEAK_HBM_GBS = 8000.0
 PEAK_BF16_TFLOPS = 2500.0
 RIDGE = PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
 PROFILE_STEPS = 4          # untimed all-kernel profile pass (feeds `layers`)
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r02_traffic.json")
+PREWARM_S = 3.0            # untimed, time-based pre-warm before the W warm-up steps (declared in the line as prewarm_s)
+
+
+def _latest_profile(suffix):
+    """profiles/rNN_<suffix> of the latest round that committed one (the PMC passes are collected with tools/collect_profiles.sh)"""
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + suffix)))
+    return found[-1] if found else os.path.join(ROOT, "profiles", "r02_" + suffix)
+
+
+TRAFFIC_JSON = _latest_profile("traffic.json")
+INFER_TRAFFIC_JSON = _latest_profile("infer_traffic.json")
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -151,10 +167,10 @@ def split_entries(prof, layers, dims, n, per_steps):
     return convs, other
 
 
-def pmc_traffic(entry):
+def pmc_traffic(entry, path=None):
     """HBM-side bytes per launch of a profiler entry, from the committed rocprofv3 --pmc passes (tools/pmc_traffic.py)."""
     try:
-        with open(TRAFFIC_JSON) as f:
+        with open(path or TRAFFIC_JSON) as f:
             e = json.load(f)["entries"].get(entry)
         return e["traffic_bytes_per_launch"] if e else None
     except (OSError, ValueError, KeyError):
@@ -296,12 +312,38 @@ def dist_facts(torch, dist, dev, local_rank, world, use_dist):
     return int(ones.item()), [int(g.item()) for g in gathered]
 
 
-def bench_infer(args, aa, aad, torch, dist, prec, rank, local_rank, world, use_dist):
-    """BASELINE.json configs[2] / [4]: tiled sliding-window inference over one synthetic image, tiles sharded across ranks.
-    Timed: tile cut + forward + blend, the exchange of the cross-rank overlap sums (one RCCL all-reduce of ~2 % of the
-    planes; nothing at one GPU) and argmax; image and label map resident in HBM.  `value_labels_on_host` times the same
-    passes with the label map copied to (pinned) host memory inside the timed region (SURVEY.md §8d's unit)."""
-    side = args.image_side
+def prewarm(run_once, sync, seconds, agree=None):
+    """untimed: repeats the workload for `seconds` of wall time (clocks and caches settled before the warm-up steps).
+    `agree(more)` (N > 1): every rank must run the same number of passes — they hold collectives — so the ranks continue
+    as long as ANY of them wants to (an all-reduce MAX of the flag)."""
+    if seconds <= 0:
+        return 0
+    t0, n = time.perf_counter(), 0
+    while True:
+        more = time.perf_counter() - t0 < seconds
+        if agree is not None:
+            more = agree(more)
+        if not more:
+            return n
+        for _ in range(4):
+            run_once()
+        n += 4
+        sync()
+
+
+def make_agree(torch, dist, dev, use_dist):
+    if not use_dist:
+        return None
+
+    def agree(more):
+        flag = torch.tensor([1 if more else 0], device=dev, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        return bool(flag.item())
+    return agree
+
+
+def infer_one_size(args, side, with_cpu_baseline, aa, aad, torch, dist, prec, rank, local_rank, world, use_dist):
+    """One image size of the inference bench -> the result object (rank 0) or None."""
     dev = torch.device("cuda", local_rank)
     cfg = aa.net_config(LEVELS, 3, CLASSES, WIDTH, 1, prec)
     tr = aa.TrainingNet(LEVELS, 3, prec, seed=2)
@@ -326,12 +368,12 @@ def bench_infer(args, aa, aad, torch, dist, prec, rank, local_rank, world, use_d
     def run(to_host=False):
         # blend this rank's tiles -> all-reduce the plane sums of the cross-rank overlaps -> label this rank's rows
         row0, row1 = aad.sharded_infer(net, image, labels, blended, tiles, rank, world, exchange, tiling_parameters=tp, stream=net_stream)
-        if gather is not None:   # N > 1: the result of annonet_infer() is one map — reduce the ranks' shares onto rank 0
-            with torch.cuda.stream(net_stream):
+        if gather is not None:   # N > 1: the result of annonet_infer() is one map — the ranks' shares are assembled on rank 0
+            with torch.cuda.stream(net_stream):   # everything that touches `labels` stays on the net's stream
                 whole = gather.run(labels)
-            if whole is not None:
-                labels.copy_(whole)
-                row0, row1 = 0, side
+                if whole is not None:
+                    labels.copy_(whole)
+                    row0, row1 = 0, side
         if to_host and row1 > row0:   # D2H on torch's own stream, ordered after the net's stream and before its next pass
             cur = torch.cuda.current_stream()
             cur.wait_stream(net_stream)
@@ -357,6 +399,7 @@ def bench_infer(args, aa, aad, torch, dist, prec, rank, local_rank, world, use_d
             elapsed = float(el.item())
         return elapsed
 
+    prewarm_passes = prewarm(run, torch.cuda.synchronize, args.prewarm_s, make_agree(torch, dist, dev, use_dist))
     for _ in range(max(args.warmup, 1)):
         run()
     # untimed profile pass: every kernel class of one image
@@ -365,40 +408,104 @@ def bench_infer(args, aa, aad, torch, dist, prec, rank, local_rank, world, use_d
     run()
     net.synchronize()
     prof_all = net.profile()
+    if args.dump_launch_order and rank == 0:
+        with open(args.dump_launch_order, "w") as f:
+            json.dump({"order": net.profile_launch_order()}, f, indent=0)
     net.profile_reset()
-    layers, dims = layer_geometry(aa, cfg, 1024)
+    win = aa.RuntimeNet.GetRecommendedInputDimension(LEVELS, tiles[0][0][2] - tiles[0][0][0] + 1)   # side of a tile's input window
+    layers, dims = layer_geometry(aa, cfg, win)
     convs = [e for e in prof_all if ENTRY_RE.search(e["name"]) and layers[int(ENTRY_RE.search(e["name"]).group(2))].k > 1]
     dominant = max(convs, key=lambda e: e["total_ms"])["name"] if convs else ""
+    # Both timed regions run under the SAME instrumentation (event pairs on the dominant conv entry only) and the same step count:
+    # `value` with image and label map resident, `value_labels_on_host` with the label map copied to pinned host memory per pass.
     net.profile_set_filter(dominant)
     elapsed = timed(args.steps)
     net.synchronize()
     dom = [e for e in net.profile() if e["name"] == dominant]
+    elapsed_host = timed(args.steps, to_host=True)
+    net.synchronize()
     net.profile_enable(False)
-    elapsed_host = timed(max(1, args.steps // 2), to_host=True)
+    out = None
     if rank == 0:
         roof = None
         if dom and dom[0]["launches"]:
             e = dom[0]
+            li = int(ENTRY_RE.search(dominant).group(2))
             avg_s = e["total_ms"] / 1e3 / e["launches"]
-            flops, byts = e["flops"] / e["launches"], e["bytes"] / e["launches"]   # per tile launch: 2 k^2 Cin Cout P and operand + result bytes
-            roof = bound_of(flops, byts, avg_s)
+            # SURVEY.md §8d per launch: the library's launches carry 1..8 tiles, so the mean tile count per launch comes from the
+            # flops the profiler summed (2 k^2 Cin Cout P per launch); bytes = the §8d MINIMUM (one input tensor + the output tensor +
+            # the filters — a skip-add layer's second operand is design traffic, not algorithmic), the convention of the training line
+            flops = e["flops"] / e["launches"]
+            flops_1, bytes_1 = section8d(layers, dims, li, 1)
+            w_bytes = 2.0 * layers[li].k ** 2 * layers[li].cin * layers[li].cout
+            tiles_per_launch = flops / flops_1
+            min_bytes = (bytes_1 - w_bytes) * tiles_per_launch + w_bytes
+            roof = bound_of(flops, min_bytes, avg_s)
             roof.pop("floor_us")
-            roof.update(traffic=None, kernel=dominant, avg_launch_us=avg_s * 1e6, launches=e["launches"], algorithmic_bytes_per_launch=byts, arithmetic_intensity=flops / byts)
+            roof.update(traffic=pmc_traffic(dominant, INFER_TRAFFIC_JSON) if side == 4096 and world == 1 else None, kernel=dominant, layer=li,
+                        avg_launch_us=avg_s * 1e6, launches=e["launches"], tiles_per_launch=tiles_per_launch,
+                        algorithmic_flops_per_launch=flops, algorithmic_bytes_per_launch=min_bytes, design_bytes_per_launch=e["bytes"] / e["launches"],
+                        arithmetic_intensity=flops / min_bytes, bytes_convention="SURVEY 8d minimum: one input + output + filters (skip operand not counted)")
         total_ms = sum(e["total_ms"] for e in prof_all) or 1.0
         share = sorted(((e["name"], round(100 * e["total_ms"] / total_ms, 1)) for e in prof_all), key=lambda x: -x[1])[:10]
         out = {"metric": f"Mpixels/s tiled inference, {side}x{side} image, 1024^2 tiles, overlap {ov}", "value": side * side * args.steps / elapsed / 1e6,
-               "unit": "Mpx/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+               "unit": "Mpx/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "prewarm_s": args.prewarm_s if prewarm_passes else 0.0,
+               "ms_per_step": 1e3 * elapsed / args.steps,
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-               "config": {"workload": f"annonet_infer(): {len(tiles)} tiles ({len(mine)} on rank 0), levels={LEVELS} width={WIDTH} K={CLASSES}", "parallelism": f"tile-shard{world}", "exchanged_pixels": exchange.pixels()},
-               "value_labels_on_host": side * side * max(1, args.steps // 2) / elapsed_host / 1e6,
+               "config": {"workload": f"annonet_infer(): {side}x{side} image, {len(tiles)} tiles ({len(mine)} on rank 0), window {win}, levels={LEVELS} width={WIDTH} K={CLASSES}",
+                          "parallelism": f"tile-shard{world}", "exchanged_pixels": exchange.pixels()},
+               "value_labels_on_host": side * side * args.steps / elapsed_host / 1e6,
+               "value_note": "value: image and label map resident in HBM; value_labels_on_host: the same passes with the label map copied to pinned host memory inside the timed region (SURVEY 8d's unit); same step count and instrumentation",
                "roofline": roof, "kernel_time_share_pct": share, "ranks_seen": ranks_seen, "devices": devices,
-               "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline_infer(aa, cfg, ov)}
-        print(json.dumps(out), flush=True)
+               "cpu_baseline": cpu_baseline_infer(aa, cfg, ov) if with_cpu_baseline else None}
     torch.cuda.synchronize()
-    del host_labels, exchange, gather, net_stream   # torch-side objects that refer to the net's stream go before the net
+    return out
+
+
+def bench_infer(args, aa, aad, torch, dist, prec, rank, local_rank, world, use_dist):
+    """BASELINE.json configs[2] / [4]: tiled sliding-window inference over one synthetic image, tiles sharded across ranks.
+    Timed: tile cut + forward + blend, the exchange of the cross-rank overlap sums (one RCCL all-reduce of ~2 % of the
+    planes; nothing at one GPU) and argmax; image and label map resident in HBM.  `value_labels_on_host` times the same
+    passes with the label map copied to (pinned) host memory inside the timed region (SURVEY.md §8d's unit).
+    --image-side a,b,...: the first size is the line, the others ride in `other_sizes` (no CPU baseline)."""
+    sides = [int(x) for x in str(args.image_side).split(",")]
+    out = None
+    for i, side in enumerate(sides):
+        res = infer_one_size(args, side, i == 0 and not args.no_cpu_baseline and world == 1, aa, aad, torch, dist, prec, rank, local_rank, world, use_dist)
+        if rank == 0:
+            if i == 0:
+                out = res
+            else:
+                out.setdefault("other_sizes", []).append({k: res[k] for k in ("metric", "value", "value_labels_on_host", "ms_per_step", "steps", "config", "roofline")})
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def infer_in_child(args, world):
+    """The inference workload for the training line's `infer` object: `bench.py --mode infer` as a CHILD process (for N > 1 it
+    starts its own ranks), after this process has finished its own measurement.  Whatever happens there — an error, a hang cut at
+    the timeout — stays inside the returned object."""
+    sides = "4096,16384" if world == 1 else "16384"
+    cmd = [sys.executable, os.path.abspath(__file__), "--mode", "infer", "--gpus", str(world), "--image-side", sides, "--steps", str(args.infer_steps),
+           "--warmup", "2", "--precision", args.precision, "--prewarm-s", str(min(args.prewarm_s, 1.0))]
+    if args.no_cpu_baseline:
+        cmd.append("--no-cpu-baseline")
+    drop = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE", "ROLE_RANK", "ROLE_WORLD_SIZE", "ROLE_NAME",
+            "MASTER_ADDR", "MASTER_PORT", "OMP_NUM_THREADS")
+    env = {k: v for k, v in os.environ.items() if k not in drop and not k.startswith("TORCHELASTIC_") and not k.startswith("TORCH_NCCL_")}
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=args.infer_timeout, cwd=ROOT)
+    except subprocess.TimeoutExpired:
+        return {"error": f"inference child exceeded {args.infer_timeout} s", "command": " ".join(cmd[1:])}
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if r.returncode != 0 or len(lines) != 1:
+        return {"error": f"inference child returned {r.returncode}", "stderr_tail": r.stderr[-800:], "command": " ".join(cmd[1:])}
+    d = json.loads(lines[0])
+    d["measured_by"] = "child process: " + " ".join(["bench.py"] + cmd[2:])
+    return d
 
 
 def main():
@@ -409,7 +516,11 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", default="train", choices=["train", "infer"], help="train = BASELINE.json's metric (default); infer = tiled inference over a 4096x4096 image")
-    ap.add_argument("--image-side", type=int, default=4096)
+    ap.add_argument("--image-side", default="4096", help="infer mode: image side, or a comma list (the first is the line, the others ride in other_sizes)")
+    ap.add_argument("--prewarm-s", type=float, default=PREWARM_S, help="untimed time-based pre-warm before the warm-up steps (declared in the line)")
+    ap.add_argument("--no-infer", action="store_true", help="train mode: leave the `infer` object out (profile collection under rocprofv3)")
+    ap.add_argument("--infer-steps", type=int, default=10)
+    ap.add_argument("--infer-timeout", type=float, default=420.0)
     ap.add_argument("--dump-launch-order", default=None, help="write the step's launch order (profiler entry per kernel-class launch) as JSON: input of tools/pmc_traffic.py")
     args = ap.parse_args()
     if args.mode == "infer" and args.steps == 200:
@@ -469,7 +580,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # untimed: warm-up, then an all-kernel profile pass (per-layer table, and which §8d conv entry is the dominant one)
+    # untimed: time-based pre-warm, the W warm-up steps, then an all-kernel profile pass (per-layer table, and which §8d conv entry
+    # is the dominant one)
+    prewarm_steps = prewarm(step, t.synchronize, args.prewarm_s, make_agree(torch, dist, dev, use_dist))
     for _ in range(max(args.warmup, 1)):
         step()
     t.synchronize()
@@ -522,7 +635,7 @@ def main():
         ms = 1e3 * elapsed / args.steps
         out = {
             "metric": "227x227 RGB tiles/sec fwd+bwd @ batch 32", "value": BATCH * world * args.steps / elapsed, "unit": "tiles/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "prewarm_s": args.prewarm_s if prewarm_steps else 0.0, "prewarm_steps": prewarm_steps, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": f"training step (fwd+loss+bwd+SGD), batch {BATCH}x3x{TILE}x{TILE} per GPU, encoder-decoder levels={LEVELS} width={WIDTH} K={CLASSES}, random init",
                        "global_batch": BATCH * world, "parallelism": f"dp{world}"},
@@ -541,10 +654,18 @@ def main():
                 per = e["total_ms"] / PROFILE_STEPS
                 print(f"  {e['name']:52s} {per:8.3f} ms/step  {e['launches'] // PROFILE_STEPS:3d} launches  "
                       f"{e['flops'] / PROFILE_STEPS / per / 1e9 if per else 0:9.1f} TFLOP/s  {e['bytes'] / PROFILE_STEPS / per / 1e6 if per else 0:9.1f} GB/s", file=sys.stderr)
-        print(json.dumps(out), flush=True)
+    # everything of this process's own measurement is done: release the GPU side, then (rank 0) let a child measure tiled inference
+    del early, bucket, t_stream, t
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        under_profiler = "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROFILER_") or k.startswith("ROCP_") for k in os.environ)
+        if not args.no_infer and not under_profiler:
+            out["infer"] = infer_in_child(args, world)
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

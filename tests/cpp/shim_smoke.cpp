@@ -108,13 +108,16 @@ int main() {
         dp_net.SetLearningRate(0.1);
         REQUIRE(anh_handle_replicas(dp_net.handle(), 1) == 2);
         for (int step = 0; step < 3; ++step) dp_net.StartTraining(samples, labels);
-        const NetPimpl::RuntimeNet dp_runtime = dp_net.GetRuntimeNet(ANH_FP32);
+        const NetPimpl::RuntimeNet snapshot = dp_net.GetRuntimeNet(ANH_FP32);   // ONE replica (the host serializes it, annonet_train_main.cpp:557-565)
+        REQUIRE(anh_handle_replicas(snapshot.handle(), 0) == 1);
+        std::ostringstream blob;
+        snapshot.Serialize(blob);
+        NetPimpl::RuntimeNet dp_runtime;                                          // a net the host creates for inference spans the selected devices
+        { std::istringstream iss(blob.str()); dp_runtime.Deserialize(iss, ANH_FP32); }
         REQUIRE(anh_handle_replicas(dp_runtime.handle(), 0) == 2);
         dlib::matrix<uint16_t> dp_result;
-        annonet_infer(const_cast<NetPimpl::RuntimeNet&>(dp_runtime), image, dp_result, temp, {}, {}, small);   // tiles sharded over the replicas
+        annonet_infer(dp_runtime, image, dp_result, temp, {}, {}, small);   // tiles sharded over the replicas
         NetPimpl::SetDevices({});
-        std::ostringstream blob;
-        dp_runtime.Serialize(blob);
         NetPimpl::RuntimeNet one_device;
         { std::istringstream iss(blob.str()); one_device.Deserialize(iss, ANH_FP32); }
         REQUIRE(anh_handle_replicas(one_device.handle(), 0) == 1);

@@ -81,8 +81,10 @@ def test_two_replica_training_runs_several_steps_and_stays_in_lockstep(two_repli
         losses.append(m.get_last_loss())
     assert all(np.isfinite(losses))
     np.testing.assert_array_equal(m.replica_params(0), m.replica_params(1))
-    rt = m.GetRuntimeNet(aa.ANH_FP32)      # the snapshot drives the same devices
-    assert rt.L.anh_handle_replicas(rt.h, 0) == 2
+    rt = m.GetRuntimeNet(aa.ANH_FP32)      # a snapshot is ONE replica on the trainer's first device (the host only serializes it)
+    assert rt.L.anh_handle_replicas(rt.h, 0) == 1
+    p, _ = rt.get_params()
+    np.testing.assert_array_equal(p, m.replica_params(0))
 
 
 @pytest.mark.parametrize("world", [2, 3])

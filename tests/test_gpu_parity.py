@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 
 import annonet_amd as aa
-from conftest import random_params
+from conftest import free_port, random_params
 from oracle.oracle import OracleNet, IGNORE
 
 pytestmark = pytest.mark.gpu
@@ -452,7 +452,7 @@ def test_grad_bucket_is_a_live_view_and_all_reduce_runs_on_it():
     got_bias_grad = bucket[head.b_off:head.b_off + 3].cpu().numpy()               # bias segment is layout-independent
     np.testing.assert_allclose(got_bias_grad, o.grads[head.b_off:head.b_off + 3], rtol=2e-3, atol=1e-7)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29533")
+    os.environ["MASTER_PORT"] = str(free_port())
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     try:
         before = bucket.clone()
@@ -485,7 +485,7 @@ def test_early_reduce_overlaps_the_all_reduce_and_changes_nothing():
     dev = torch.device("cuda:0")
     timg, tlab, tw = (torch.from_numpy(a).to(dev) for a in (img, lab.view(np.int16), w))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29534")
+    os.environ["MASTER_PORT"] = str(free_port())
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     try:
         params = []

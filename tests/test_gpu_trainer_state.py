@@ -101,3 +101,35 @@ def test_learning_rate_history_does_not_depend_on_host_timing():
     assert runs[0][0][-1] < 1e-7, "the schedule never shrank the rate: the test does not exercise the lag"
     for w, g in zip(runs[0][1], runs[1][1]):
         np.testing.assert_array_equal(g, w)
+
+
+@pytest.mark.parametrize("damage", ["other_net", "old_magic", "truncated"])
+def test_a_state_file_that_cannot_be_loaded_is_an_error_not_a_fresh_start(tmp_path, damage):
+    """The reference's host loop asks GetLearningRate() before anything else (annonet_train_main.cpp:583): a synchronization file
+    of another net, of the older format or cut short must still surface as an error on StartTraining — never as a silent restart
+    from step 0 whose periodic save would overwrite the user's state — and the file must be left as it was."""
+    path = tmp_path / "annonet_trainer_state_file.dat"
+    a = make_trainer(classes=4)
+    for i in range(3):
+        a.StartTraining(*batch(i))
+    a.save_state(str(path))
+    blob = path.read_bytes()
+    classes = 4
+    if damage == "other_net":
+        classes = 3
+    elif damage == "old_magic":
+        blob = blob.replace(b"ANHTS002", b"ANHTS001", 1)
+    else:
+        blob = blob[:len(blob) // 2]
+    path.write_bytes(blob)
+    b = make_trainer(classes=classes, sync=str(path))
+    lr = b.GetLearningRate()                  # the getter cannot report the failure ...
+    assert lr == 0.05
+    for _ in range(2):                        # ... every call with a status does, for as long as the file is there
+        with pytest.raises(aa.AnnonetHipError, match="different net|older format|truncated|corrupt"):
+            b.StartTraining(*batch(0, classes=classes))
+    assert b.step_count() == 0
+    assert path.read_bytes() == blob
+    path.unlink()                             # the user removes the file: training starts from scratch
+    b.StartTraining(*batch(0, classes=classes))
+    assert b.step_count() == 1
