@@ -128,8 +128,11 @@ Engine::Engine(const anh_net_config& cfg, bool training_) : spec(Spec::build(cfg
     random_init(0);
 }
 
+// Every stream the engine launched on is drained before anything it owns is destroyed, whatever the host still holds (a torch
+// ExternalStream over `stream`, events recorded there, pinned copies in flight): destruction never races work in flight.
 Engine::~Engine() {
     if (stream) (void)hipStreamSynchronize(stream);
+    if (early_stream) (void)hipStreamSynchronize(early_stream);
     if (aux_stream) { (void)hipStreamSynchronize(aux_stream); (void)hipStreamDestroy(aux_stream); }
     if (ev_dy_ready) (void)hipEventDestroy(ev_dy_ready);
     if (ev_aux_done) (void)hipEventDestroy(ev_aux_done);

@@ -26,7 +26,9 @@ def handle_stream(handle):
     ordered with the handle's own kernels (torch.distributed orders a collective against the CURRENT stream: the
     all-reduce then starts after backward and the update starts after the all-reduce)."""
     import torch
-    return torch.cuda.ExternalStream(handle.stream_ptr(), device=torch.device("cuda", torch.cuda.current_device()))
+    s = torch.cuda.ExternalStream(handle.stream_ptr(), device=torch.device("cuda", torch.cuda.current_device()))
+    s._anh_handle = handle   # the wrapper does not own the stream (torch: "the user keeps it alive"): it keeps the OWNER alive instead
+    return s
 
 
 class EarlyReduce:

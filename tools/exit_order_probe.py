@@ -29,7 +29,7 @@ def flow(variant):
     tr.SetNetWidth(1.0, 1); tr.SetClassCount(3); tr.Initialize()
     net = tr.GetRuntimeNet(prec)
     del tr
-    net_stream = aad.handle_stream(net)
+    net_stream = torch.cuda.ExternalStream(net.stream_ptr(), device=dev)   # the bare wrapper (dist.handle_stream would keep `net` alive): the LIBRARY must cope
     rng = np.random.default_rng(3)
     image = torch.from_numpy(rng.integers(0, 256, (side, side, 3), dtype=np.uint8)).to(dev)
     labels = torch.empty((side, side), dtype=torch.int16, device=dev)
