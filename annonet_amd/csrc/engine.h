@@ -55,6 +55,8 @@ struct LayerState {
     int consumers = 0, da_writes = 0, fused_bwd_blocks = 0;
     DevBuf bwd_partials;
     double running_updates = 0;  // dlib bn_: number of running-stat updates so far (capped by the window)
+    long long* acc = nullptr;    // table mode (bnacc.h): this layer's accumulator table inside Engine::bn_acc
+    double fold_af = 1.0, fold_unbias = 1.0; bool fold_running = false;   // this step's running-statistics update, applied by the fold job
 };
 
 class Engine {
@@ -132,8 +134,19 @@ class Engine {
   private:
     void plan_dims(int n, int h, int w);
     void plan_dims_unguarded(int n, int h, int w);
+    // Table mode (bnacc.h, default in bf16 training when every layer's kernels support it; ANH_BN_TABLES=0 switches it off): the bn
+    // sums of every layer are added to accumulator tables by the kernels that see the values and folded by their consumers, so the
+    // 18 finalize launches of a step disappear from the critical stream.
+    bool tables = false, fold_pending = false;
+    DevBuf bn_acc;
+    size_t bn_acc_bytes = 0;
+    BnFoldJobs fold_jobs;
+    bool choose_table_mode(const Src& image);
+    BnTable table_of(int li) const;
+    BnBwdFinish finish_of(int li);
+    void build_fold_jobs();
     bool head_is_fused() const;
-    Src layer_source(int li, const Src& image) const;
+    Src layer_source(int li, const Src& image, bool fold_tables = false) const;
     void run_conv_forward(int li, const Src& image, bool training_pass, float* d_out_nchw);
     void refresh_compute_weights();
     void fold_running_stats();  // inference: scale/shift from running stats, computed on the host

@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <cstring>
 
+#include "bnacc.h"
 #include "hostlogic.h"
 
 namespace anh {
@@ -319,11 +320,36 @@ void Engine::plan_dims_unguarded(int n, int h, int w) {
     }
 }
 
-Src Engine::layer_source(int li, const Src& image) const {
+BnBwdFinish Engine::finish_of(int li) {
+    const anh_layer_desc& L = spec.layers[li];
+    LayerState& s = ls[li];
+    BnBwdFinish f;
+    f.acc = s.acc; f.gamma = master.as<float>() + L.g_off; f.invstd = s.invstd;
+    f.dgamma = grad.as<float>() + L.g_off; f.dbeta = grad.as<float>() + L.beta_off; f.coef = s.coef;
+    f.pixels = (double)s.n * s.h * s.w; f.c = L.cout;
+    return f;
+}
+
+BnTable Engine::table_of(int li) const {
+    const anh_layer_desc& L = spec.layers[li];
+    const LayerState& s = ls[li];
+    BnTable t;
+    t.acc = s.acc; t.gamma = master.as<float>() + L.g_off; t.beta = master.as<float>() + L.beta_off;
+    t.pixels = (double)s.n * s.h * s.w; t.eps = kBnEps; t.c = L.cout;
+    return t;
+}
+
+// fold_tables (training forward in table mode): the consumer folds the producers' (scale, shift) from their accumulator tables.
+// Backward-time consumers read the arrays, which the fold jobs have written by then.
+Src Engine::layer_source(int li, const Src& image, bool fold_tables) const {
     const anh_layer_desc& L = spec.layers[li];
     if (L.in_a < 0) return image;
     Src s;
     s.dtype = dtype;
+    if (fold_tables && tables) {
+        s.a_tab = table_of(L.in_a);
+        if (L.in_b >= 0) s.b_tab = table_of(L.in_b);
+    }
     if (infer_post) {   // the producers stored relu(bn(y)) (forward_conv_args): plain reads
         s.kind = L.in_b >= 0 ? SRC_SUM2 : SRC_RAW;
         s.a = ls[L.in_a].raw.p;
@@ -342,7 +368,7 @@ ConvArgs Engine::forward_conv_args(int li, const Src& image, bool training_pass,
     const anh_layer_desc& L = spec.layers[li];
     const LayerState& s = ls[li];
     ConvArgs a;
-    a.src = layer_source(li, image);
+    a.src = layer_source(li, image, training_pass);
     a.n = s.n; a.h_in = s.h_in; a.w_in = s.w_in; a.c_red = L.cin;
     a.h_out = s.h; a.w_out = s.w; a.c_out = L.cout;
     a.k = L.k; a.stride = L.stride; a.pad = L.pad; a.gather = L.type;
@@ -365,6 +391,46 @@ void Engine::choose_inference_form(const Src& image) {
     for (size_t li = 0; li + 1 < spec.layers.size(); ++li) {
         const ConvArgs a = forward_conv_args((int)li, image, false, nullptr);
         if (!spec.layers[li].has_bn || !conv_takes_mfma(a, dtype) || !conv_stores_activation(a)) { infer_post = false; return; }
+    }
+}
+
+// Table mode is all or nothing per pass: every bn layer's forward kernel must add its statistics to a table, every consumer's
+// kernel must fold tables, and the bn backward kernels of every width must take them.
+bool Engine::choose_table_mode(const Src& image) {
+    static const bool on = !(getenv("ANH_BN_TABLES") && atoi(getenv("ANH_BN_TABLES")) == 0);
+    tables = false;
+    if (!on || !training || dtype != DT_BF16) return false;
+    const int nl = (int)spec.layers.size();
+    if (nl - 1 > 16) return false;   // BnFoldJobs::job
+    for (int li = 0; li + 1 < nl; ++li) {
+        const anh_layer_desc& L = spec.layers[li];
+        if (!L.has_bn || !bn_table_mode_ok(L.cout)) return false;
+        const ConvArgs a = forward_conv_args(li, image, true, nullptr);   // (tables is false: plain arguments)
+        if (!conv_takes_mfma(a, dtype) || conv_fused_stat_blocks(a) <= 0) return false;
+        if (L.in_a >= 0 && !conv_folds_bn_tables(a)) return false;
+    }
+    // the head reads its input layers through arrays unless it is the fused kernel (which folds tables itself): both are fine
+    size_t words = 0;
+    for (int li = 0; li + 1 < nl; ++li) words += bnacc_words(spec.layers[li].cout);
+    bn_acc.reserve(words * sizeof(long long));
+    bn_acc_bytes = words * sizeof(long long);
+    words = 0;
+    for (int li = 0; li + 1 < nl; ++li) { ls[li].acc = bn_acc.as<long long>() + words; words += bnacc_words(spec.layers[li].cout); }
+    tables = true;
+    return true;
+}
+
+void Engine::build_fold_jobs() {
+    fold_jobs.n = 0;
+    for (size_t li = 0; li + 1 < spec.layers.size(); ++li) {
+        const anh_layer_desc& L = spec.layers[li];
+        LayerState& s = ls[li];
+        BnFoldJob& j = fold_jobs.job[fold_jobs.n++];
+        j.acc = s.acc; j.gamma = master.as<float>() + L.g_off; j.beta = master.as<float>() + L.beta_off;
+        j.mean = s.mean; j.invstd = s.invstd; j.scale = s.scale; j.shift = s.shift; j.var = s.var;
+        j.rmean = s.fold_running ? running.as<float>() + L.rs_off : nullptr;
+        j.rvar = s.fold_running ? running.as<float>() + L.rs_off + L.cout : nullptr;
+        j.pixels = (double)s.n * s.h * s.w; j.af = s.fold_af; j.unbias = s.fold_unbias; j.eps = kBnEps; j.c = L.cout;
     }
 }
 
@@ -417,7 +483,9 @@ void Engine::run_conv_forward(int li, const Src& image, bool training_pass, floa
                          (double)spec.filter_count(li) * es;
     // training forward of a bn layer: the MFMA kernels that can keep per-lane running sums also write the statistic partials
     int fused_stat_blocks = 0;
-    if (L.has_bn && training_pass && conv_takes_mfma(a, dtype)) {
+    const bool table_layer = tables && training_pass && L.has_bn;
+    if (table_layer) a.stat_acc = s.acc;   // the statistics go to the layer's accumulator table; its consumers fold them (bnacc.h)
+    else if (L.has_bn && training_pass && conv_takes_mfma(a, dtype)) {
         fused_stat_blocks = conv_fused_stat_blocks(a);
         if (fused_stat_blocks > 0) {
             bn_partials.reserve((size_t)fused_stat_blocks * 2 * L.cout * sizeof(double));
@@ -425,6 +493,16 @@ void Engine::run_conv_forward(int li, const Src& image, bool training_pass, floa
         }
     }
     conv_dispatch(a, (std::string("fwd_") + layer_tag(li, L)).c_str(), flops, bytes);
+    if (table_layer) {   // no finalize launch: only this step's running-statistics bookkeeping, applied by the fold job
+        s.fold_running = update_running_in_forward;
+        if (update_running_in_forward) {
+            const double P = (double)p_out;
+            s.fold_af = 1.0 / (s.running_updates + 1.0);
+            if (s.running_updates < (double)bn_window) s.running_updates += 1.0;
+            s.fold_unbias = P > 1 ? P / (P - 1.0) : 1.0;
+        }
+        return;
+    }
     if (L.has_bn && training_pass) {
         BnFwdArgs b;
         b.y = s.raw.p; b.dtype = dtype; b.pixels = p_out; b.c = L.cout;
@@ -490,8 +568,24 @@ void Engine::forward_training(const Src& image, int n, int h, int w) {
     prof.start_pass();
     ANH_REQUIRE(training, "not a training net");
     plan_dims(n, h, w);
-    const size_t n_run = head_is_fused() ? spec.layers.size() - 1 : spec.layers.size();  // the fused tail computes the logits itself
-    for (size_t li = 0; li < n_run; ++li) run_conv_forward((int)li, image, true, nullptr);
+    if (choose_table_mode(image)) {
+        const int tok = prof.begin(stream, "bn_tables_zero", 0, (double)bn_acc_bytes);
+        HIP_CHECK(hipMemsetAsync(bn_acc.p, 0, bn_acc_bytes, stream));
+        prof.end(stream, tok);
+    }
+    const bool fused_head = head_is_fused();
+    const size_t n_bn = spec.layers.size() - 1;
+    for (size_t li = 0; li < n_bn; ++li) run_conv_forward((int)li, image, true, nullptr);
+    if (tables) {
+        build_fold_jobs();
+        if (fused_head) fold_pending = true;   // the first workgroups of the fused head kernel run the jobs (Engine::backward)
+        else {                                 // the unfused head reads its input layers' arrays: fold them now
+            const int tok = prof.begin(stream, "bn_fold_all", 0, 0);
+            launch_bn_fold_all(fold_jobs, stream);
+            prof.end(stream, tok);
+        }
+    }
+    if (!fused_head) run_conv_forward((int)n_bn, image, true, nullptr);   // (the fused tail computes the logits itself)
     last_image = image; last_n = n; last_h = h; last_w = w;
     have_forward = true;
 }
@@ -511,7 +605,12 @@ void Engine::backward(const uint16_t* d_labels, const float* d_weights, double l
     bool head_da_virtual = false;
     if (fused_head) {
         HeadTrainArgs t;
-        t.src = layer_source(nl - 1, last_image); t.c_in = head.cin; t.k = head.cout;
+        t.src = layer_source(nl - 1, last_image, true); t.c_in = head.cin; t.k = head.cout;
+        if (tables && fold_pending) {   // the fold jobs ride in the head kernel's first workgroups (a tiny pass without enough of them: own launch)
+            if (head_train_blocks(P) >= fold_jobs.n) t.fold = &fold_jobs;
+            else launch_bn_fold_all(fold_jobs, stream);
+            fold_pending = false;
+        }
         t.w_tm = w_tm_f32.as<float>() + head.w_off; t.w_km = w_km_f32.as<float>() + head.w_off;
         t.bias = master.as<float>() + head.b_off;
         t.labels = d_labels; t.weights = d_weights;
@@ -527,8 +626,12 @@ void Engine::backward(const uint16_t* d_labels, const float* d_weights, double l
         int head_bnred_blocks = 0;
         if (fuse_head_bnred && t.src.kind == SRC_ACT && spec.layers[head.in_a].has_bn) {
             head_bnred_blocks = head_train_blocks(P);
-            hp.bwd_partials.reserve((size_t)head_bnred_blocks * 2 * head.cin * sizeof(double));
-            t.bnred_mean = hp.mean; t.bnred_invstd = hp.invstd; t.bnred_partials = hp.bwd_partials.as<double>();
+            t.bnred_mean = hp.mean; t.bnred_invstd = hp.invstd;
+            if (tables) { t.bnred_acc = hp.acc; t.bnred_finish = finish_of(head.in_a); }
+            else {
+                hp.bwd_partials.reserve((size_t)head_bnred_blocks * 2 * head.cin * sizeof(double));
+                t.bnred_partials = hp.bwd_partials.as<double>();
+            }
             // ... and then nothing needs da in memory: the layer's bn_bwd_apply pass recomputes it from the dlogits (k floats per pixel
             // instead of 32 storage elements written here and read there).
             static const bool virtual_da = !(getenv("ANH_HEAD_DA_VIRTUAL") && atoi(getenv("ANH_HEAD_DA_VIRTUAL")) == 0);
@@ -597,16 +700,19 @@ void Engine::backward(const uint16_t* d_labels, const float* d_weights, double l
             if (head_da_virtual && li == head.in_a) { b.head_g = dlogits.as<float>(); b.head_w_tm = w_tm_f32.as<float>() + head.w_off; b.head_k = head.cout; }
             // one profiler entry per kernel: reduce reads da and y; apply reads both and writes dy
             int tok;
+            if (tables) { b.acc = s.acc; b.finish = finish_of(li); }   // table mode: sums in the layer's accumulator table, folded by the last workgroup that adds to it
             if (s.fused_bwd_blocks > 0) {   // the conv that wrote da last left the partial sums
-                b.partials = s.bwd_partials.as<double>(); b.partial_blocks = s.fused_bwd_blocks;
+                if (!tables) { b.partials = s.bwd_partials.as<double>(); b.partial_blocks = s.fused_bwd_blocks; }
             } else {
                 tok = prof.begin(stream, "bn_bwd_reduce", 0, (double)p_out * L.cout * es * 2);
                 launch_bn_bwd_reduce(b, stream);
                 prof.end(stream, tok);
             }
-            tok = prof.begin(stream, "bn_bwd_finalize", 0, (double)(b.partial_blocks > 0 ? b.partial_blocks : bn_partial_blocks(p_out)) * L.cout * 16.0);
-            launch_bn_bwd_finalize(b, stream);
-            prof.end(stream, tok);
+            if (!tables) {
+                tok = prof.begin(stream, "bn_bwd_finalize", 0, (double)(b.partial_blocks > 0 ? b.partial_blocks : bn_partial_blocks(p_out)) * L.cout * 16.0);
+                launch_bn_bwd_finalize(b, stream);
+                prof.end(stream, tok);
+            }
             // a layer without backward-data conv (the stem): only its filter gradient consumes dy, and the stem wgrad
             // kernel can compute dy from (da, y) while staging -> no apply pass on the critical path
             WgradArgs probe;
@@ -658,9 +764,12 @@ void Engine::backward(const uint16_t* d_labels, const float* d_weights, double l
             if (PL.has_bn && P.da_writes == P.consumers && dtype == DT_BF16 && conv_takes_mfma(dg, dtype)) {
                 const int blocks = conv_fused_bnred_blocks(dg);
                 if (blocks > 0) {
-                    P.bwd_partials.reserve((size_t)blocks * 2 * PL.cout * sizeof(double));
                     dg.bnred_y = P.raw.p; dg.bnred_scale = P.scale; dg.bnred_shift = P.shift; dg.bnred_mean = P.mean; dg.bnred_invstd = P.invstd;
-                    dg.bnred_partials = P.bwd_partials.as<double>();
+                    if (tables) { dg.bnred_acc = P.acc; dg.bnred_finish = finish_of(L.in_a); }
+                    else {
+                        P.bwd_partials.reserve((size_t)blocks * 2 * PL.cout * sizeof(double));
+                        dg.bnred_partials = P.bwd_partials.as<double>();
+                    }
                     P.fused_bwd_blocks = blocks;
                 }
             }

@@ -24,11 +24,22 @@ enum SrcKind {
     // backward-data conv beside it, still applies that expression while staging: WgradArgs::dy_y.)
 };
 
+// Batch-norm accumulator table of the layer a tensor comes from (bnacc.h).  With acc != nullptr a consumer folds that layer's
+// (scale, shift) from the table's totals in its own prologue instead of reading arrays a finalize kernel would have had to write.
+struct BnTable { const long long* acc = nullptr; const float* gamma = nullptr; const float* beta = nullptr; double pixels = 0; float eps = 1e-4f; int c = 0; };
+
+// Table mode, backward sums: the kernel that adds the LAST sums of a layer's (sum dz*xhat, sum dz) also folds them — its last
+// workgroup to finish (a ticket counter in the table) writes dgamma, dbeta and the apply coefficients [k0 | k1 | k2][c], with
+// bn_bwd_finalize_kernel's arithmetic.  The sums are already at the memory side (atomics), so no fence stands in the way.
+struct BnBwdFinish { long long* acc = nullptr; const float* gamma = nullptr; const float* invstd = nullptr;
+                     float* dgamma = nullptr; float* dbeta = nullptr; float* coef = nullptr; double pixels = 0; int c = 0; };
+
 struct Src {
     int kind = SRC_RAW;
     int dtype = DT_F32;
     const void* a = nullptr; const float* a_scale = nullptr; const float* a_shift = nullptr;
     const void* b = nullptr; const float* b_scale = nullptr; const float* b_shift = nullptr;
+    BnTable a_tab, b_tab;   // table mode: replaces a_scale / a_shift (b_scale / b_shift) when .acc is set
     // SRC_IMAGE: sample n lives at img + n*img_sample_stride; the net input window starts at (img_left, img_top)
     const uint8_t* img = nullptr;
     int img_h = 0, img_w = 0, img_left = 0, img_top = 0;
@@ -57,6 +68,10 @@ struct ConvArgs {
     void* out2 = nullptr; int out2_accumulate = 0;  // optional second destination (skip-add gradient)
     int out_nchw = 0;                               // fp32 NCHW destination (boundary layout)
     double* stat_partials = nullptr;                // fused bn statistics (MFMA path), else nullptr
+    // table mode (bnacc.h): the sums are added to accumulator tables instead of leaving one partial per workgroup — stat_acc = this
+    // layer's table (with stat_partials unset), bnred_acc = the table of the layer `out` belongs to (with bnred_partials unset)
+    long long* stat_acc = nullptr; long long* bnred_acc = nullptr;
+    BnBwdFinish bnred_finish;   // with bnred_acc
     // bf16 inference on the MFMA path: the epilogue stores relu(acc * out_scale[c] + out_shift[c]) — this layer's folded bn and its
     // relu on the fp32 accumulator — instead of the raw output, so that its consumers stage plain copies (conv_stores_activation())
     const float* out_scale = nullptr; const float* out_shift = nullptr;
@@ -106,6 +121,7 @@ struct BnFwdArgs {
     float* running_mean = nullptr; float* running_var = nullptr; double averaging_factor = 1.0, unbias = 1.0;
 };
 int bn_partial_blocks(int64_t pixels);
+bool bn_table_mode_ok(int c);   // the bn backward kernels of a c-channel layer take accumulator tables (BnBwdArgs::acc)
 void launch_bn_forward_stats(const BnFwdArgs& a, hipStream_t s);   // = partials, finalize
 int launch_bn_forward_partials(const BnFwdArgs& a, hipStream_t s);
 // statistics already written by the conv kernel (ConvArgs::stat_partials, `blocks` partials per channel): finalize only
@@ -131,6 +147,9 @@ struct BnBwdArgs {
     const float* head_g = nullptr; const float* head_w_tm = nullptr; int head_k = 0;
     void* dy_out = nullptr; // apply: destination (default: in place over da)
     int partial_blocks = 0; // finalize: partials per channel when the reduction came from a conv epilogue (0 = bn_partial_blocks(pixels))
+    // table mode (bnacc.h): reduce ADDS its sums to the table and its last workgroup leaves dgamma / dbeta / coef (no partials, no finalize)
+    long long* acc = nullptr;
+    BnBwdFinish finish;   // with acc
 };
 void launch_bn_backward(const BnBwdArgs& a, hipStream_t s);   // = reduce, finalize, apply
 void launch_bn_bwd_reduce(const BnBwdArgs& a, hipStream_t s);
@@ -233,6 +252,7 @@ void run_detection_filter(const float* d_blended, uint16_t* d_labels, int k, int
                           hipStream_t s);
 void launch_reduce_partials(const float* partials, int splits, int64_t nw, float* out, hipStream_t s);
 
+struct BnFoldJobs;
 // training-time tail fused into one pass: 1x1 head forward + weighted softmax log-loss + head backward-data + head
 // filter / bias gradient (32 input channels, up to 4 classes; other shapes take the separate kernels)
 struct HeadTrainArgs {
@@ -248,7 +268,20 @@ struct HeadTrainArgs {
     // optional (single-input head): also leave the bn + relu backward sums of the layer that produced the input —
     // the head computes that layer's da from its raw output y in the same pass.  Layout [channel][sum dz*xhat | sum dz][workgroup].
     const float* bnred_mean = nullptr; const float* bnred_invstd = nullptr; double* bnred_partials = nullptr;
+    long long* bnred_acc = nullptr;        // table mode: the sums go to the input layer's accumulator table (bnred_partials unset)
+    BnBwdFinish bnred_finish;              // with bnred_acc
+    const BnFoldJobs* fold = nullptr;      // table mode: workgroup j < fold->n also runs fold job j
 };
+// Table mode: the arrays (mean, invstd, scale, shift, var) and the running statistics of every bn layer, formed from the accumulator
+// tables by ONE launch per step — or by the first workgroups of the fused head kernel, which runs before any backward kernel reads them.
+struct BnFoldJob {
+    const long long* acc; const float* gamma; const float* beta;
+    float* mean; float* invstd; float* scale; float* shift; double* var;
+    float* rmean; float* rvar;            // null: no running update
+    double pixels, af, unbias; float eps; int c;
+};
+struct BnFoldJobs { int n = 0; BnFoldJob job[16]; };
+void launch_bn_fold_all(const BnFoldJobs& jobs, hipStream_t s);
 bool head_train_supported(const HeadTrainArgs& a);
 int head_train_blocks(int64_t pixels);   // workgroups of the launch = partials per channel
 int64_t head_train_partial_doubles(const HeadTrainArgs& a);
@@ -261,6 +294,7 @@ void launch_conv_mfma(const ConvArgs& a, hipStream_t s);
 // value is the number of partials per channel to pass to launch_bn_forward_finalize)
 int conv_fused_stat_blocks(const ConvArgs& a);
 int conv_fused_bnred_blocks(const ConvArgs& a);   // same for ConvArgs::bnred_partials (backward-data convs)
+bool conv_folds_bn_tables(const ConvArgs& a);     // the layer's kernel reads Src::a_tab / b_tab (the persistent kernels)
 bool conv_stores_activation(const ConvArgs& a);   // the layer's MFMA kernel honours ConvArgs::out_scale / out_shift (src.kind SRC_RAW, SRC_SUM2 or SRC_IMAGE)
 bool mfma_wgrad_supported(const WgradArgs& a);
 void launch_wgrad_mfma(const WgradArgs& a, hipStream_t s);

@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cstdlib>
 
+#include "bnacc.h"
 #include "common.h"
 #include "kernels.h"
 
@@ -984,7 +985,8 @@ __global__ __launch_bounds__(256) void bn_stats_vec_kernel(const T* y, int64_t p
 
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_vec_kernel(const T* da, const T* y, int64_t pixels, int c, const float* mean, const float* invstd,
-                                                                const float* scale, const float* shift, double* partials, int ppb) {
+                                                                const float* scale, const float* shift, double* partials, int ppb, BnBwdFinish fin) {
+    long long* acc_table = fin.acc;
     __shared__ float sh[256][17];
     const int groups = c >> 3, cg = threadIdx.x % groups, lane_px = threadIdx.x / groups, px_step = 256 / groups;
     const int64_t p0 = (int64_t)blockIdx.x * ppb;
@@ -1015,8 +1017,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_vec_kernel(const T* da, con
         const int g = ch >> 3, j = ch & 7;
         double acc = 0;
         for (int r = 0; r < px_step; ++r) acc += sh[r * groups + g][which * 8 + j];
-        partials[((size_t)ch * 2 + which) * gridDim.x + blockIdx.x] = acc;
+        if (acc_table) bnacc_add(acc_table, BNACC_SUM_DZ_XHAT + which, c, ch, acc);
+        else partials[((size_t)ch * 2 + which) * gridDim.x + blockIdx.x] = acc;
     }
+    if (acc_table) bnacc_finish_backward(fin, (int)gridDim.x);
 }
 
 template <typename T>
@@ -1127,6 +1131,24 @@ __global__ __launch_bounds__(64) void loss_finalize_kernel(const double* partial
 // ---------------------------------------------------------------------------------------------------
 constexpr int kHeadC = 32, kHeadKMax = 4;
 
+// Table mode (bnacc.h): one fold job = one bn layer's arrays (mean, invstd, scale, shift, var) and running statistics from its
+// accumulator table, with bn_finalize_kernel's arithmetic.  Run by a whole workgroup; nothing in the same launch reads the results.
+__device__ __forceinline__ void bn_fold_job(const BnFoldJob& j) {
+    for (int ch = threadIdx.x; ch < j.c; ch += blockDim.x) {
+        const float rm0 = j.rmean ? j.rmean[ch] : 0.f, rv0 = j.rmean ? j.rvar[ch] : 0.f;
+        const BnFolded f = bnacc_fold_forward(j.acc, j.c, ch, j.pixels, j.gamma[ch], j.beta[ch], j.eps);
+        j.mean[ch] = f.mean; j.invstd[ch] = f.invstd; j.scale[ch] = f.scale; j.shift[ch] = f.shift;
+        j.var[ch] = f.var;
+        if (j.rmean) {  // dlib bn_ updates its running statistics in the training forward
+            j.rmean[ch] = (float)((1.0 - j.af) * (double)rm0 + j.af * (double)f.mean);
+            j.rvar[ch] = (float)((1.0 - j.af) * (double)rv0 + j.af * j.unbias * f.var);
+        }
+    }
+}
+__global__ __launch_bounds__(128) void bn_fold_all_kernel(BnFoldJobs jobs) {
+    if ((int)blockIdx.x < jobs.n) bn_fold_job(jobs.job[blockIdx.x]);
+}
+
 // the same pass for the layer under the fused 1x1 head, whose da is not in memory: a thread recomputes its 8 channels of
 // da = round_T(sum_k g[p][k] * w_tm[ch][k]) from the pixel's dlogits (head_train_kernel's expression and order)
 template <typename T, int KM>
@@ -1180,6 +1202,8 @@ struct HeadArgs {
     double* partials;              // [blocks][1 + K + 32*K]
     int* error_flag;
     const float* bn_mean; const float* bn_invstd; double* bn_partials;   // fused bn backward sums of the input layer (SRC_ACT only)
+    long long* bn_acc;             // table mode: those sums are added to the input layer's accumulator table instead (bnacc.h)
+    BnBwdFinish bn_finish;         // ... and the last workgroup folds them
 };
 
 // Four lanes share a pixel: lane `sub` owns channels 8*sub..8*sub+7 (one 16-byte chunk), so a wave reads / writes 1 KiB
@@ -1187,10 +1211,26 @@ struct HeadArgs {
 // KM = register slots per class dimension.  2, 3 and 4 classes get exact instantiations (K = KM known at compile time: no
 // per-class predicates, no dead slots); a one-class net runs the two-slot body with K at run time.
 template <typename T, int KIND, int KM, bool EXACT>
-__global__ __launch_bounds__(256, 2) void head_train_kernel(HeadArgs a) {
+__global__ __launch_bounds__(256, 2) void head_train_kernel(HeadArgs a, BnFoldJobs jobs) {
     constexpr int C = kHeadC;
     const int K = EXACT ? KM : a.k;
     const int sub = threadIdx.x & 3, c0 = sub * 8;
+    // table mode: the first workgroups also form every bn layer's arrays and running statistics (read by the backward kernels, all
+    // of which are launched after this one); this kernel itself folds what it needs of its input layers below
+    if ((int)blockIdx.x < jobs.n) bn_fold_job(jobs.job[blockIdx.x]);
+    __shared__ float sfold[6][C];   // a_scale, a_shift, b_scale, b_shift, a_mean, a_invstd
+    const bool tables = a.src.a_tab.acc != nullptr;
+    if (tables) {
+        const int sides = KIND == SRC_ACT2 ? 2 : 1;
+        if ((int)threadIdx.x < sides * C) {
+            const int side = threadIdx.x >= C, ch = threadIdx.x - side * C;
+            const BnTable& t = side ? a.src.b_tab : a.src.a_tab;
+            const BnFolded f = bnacc_fold_forward(t.acc, t.c, ch, t.pixels, t.gamma[ch], t.beta[ch], t.eps);
+            sfold[2 * side][ch] = f.scale; sfold[2 * side + 1][ch] = f.shift;
+            if (!side) { sfold[4][ch] = f.mean; sfold[5][ch] = f.invstd; }
+        }
+        __syncthreads();
+    }
     // w_tm[ci][k] and w_km[k][ci] are two layouts of the same filter: one register copy serves forward and backward-data
     float w[8][KM], bias[KM], sa[8], ta[8], sb[8], tb[8];
 #pragma unroll
@@ -1201,10 +1241,15 @@ __global__ __launch_bounds__(256, 2) void head_train_kernel(HeadArgs a) {
     }
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-        sa[c] = a.src.a_scale[c0 + c]; ta[c] = a.src.a_shift[c0 + c];
-        sb[c] = KIND == SRC_ACT2 ? a.src.b_scale[c0 + c] : 0.f; tb[c] = KIND == SRC_ACT2 ? a.src.b_shift[c0 + c] : 0.f;
+        if (tables) {
+            sa[c] = sfold[0][c0 + c]; ta[c] = sfold[1][c0 + c];
+            sb[c] = KIND == SRC_ACT2 ? sfold[2][c0 + c] : 0.f; tb[c] = KIND == SRC_ACT2 ? sfold[3][c0 + c] : 0.f;
+        } else {
+            sa[c] = a.src.a_scale[c0 + c]; ta[c] = a.src.a_shift[c0 + c];
+            sb[c] = KIND == SRC_ACT2 ? a.src.b_scale[c0 + c] : 0.f; tb[c] = KIND == SRC_ACT2 ? a.src.b_shift[c0 + c] : 0.f;
+        }
     }
-    const bool bnred = KIND == SRC_ACT && a.bn_partials != nullptr;
+    const bool bnred = KIND == SRC_ACT && (a.bn_partials != nullptr || a.bn_acc != nullptr);
     // bn backward sums of the input layer.  The loop keeps sg = sum dz*y and sb2 = sum dz; the workgroup's partial of
     // sum dz*xhat = invstd * (sum dz*y - mean * sum dz) is formed once, in double, after the folds (8 fewer VALU per
     // pixel and 16 fewer registers than carrying mean / invstd through the loop).
@@ -1354,8 +1399,12 @@ __global__ __launch_bounds__(256, 2) void head_train_kernel(HeadArgs a) {
         const int ch = threadIdx.x >> 1, which = threadIdx.x & 1;
         const double sy = ((redb[0][0][ch] + redb[1][0][ch]) + redb[2][0][ch]) + redb[3][0][ch];
         const double sd = ((redb[0][1][ch] + redb[1][1][ch]) + redb[2][1][ch]) + redb[3][1][ch];
-        a.bn_partials[((size_t)ch * 2 + which) * gridDim.x + blockIdx.x] = which ? sd : (double)a.bn_invstd[ch] * (sy - (double)a.bn_mean[ch] * sd);
+        const double mean_ = tables ? (double)sfold[4][ch] : (double)a.bn_mean[ch], invstd_ = tables ? (double)sfold[5][ch] : (double)a.bn_invstd[ch];
+        const double v = which ? sd : invstd_ * (sy - mean_ * sd);
+        if (a.bn_acc) bnacc_add(a.bn_acc, BNACC_SUM_DZ_XHAT + which, C, ch, v);
+        else a.bn_partials[((size_t)ch * 2 + which) * gridDim.x + blockIdx.x] = v;
     }
+    if (bnred && a.bn_acc) bnacc_finish_backward(a.bn_finish, (int)gridDim.x);
     const int slots = 1 + K + C * K;
     for (int sidx = threadIdx.x; sidx < slots; sidx += blockDim.x) {
         int src;
@@ -1786,9 +1835,15 @@ void launch_head_train(const HeadTrainArgs& t, hipStream_t s) {
     a.src = t.src; a.w_tm = t.w_tm; a.w_km = t.w_km; a.bias = t.bias; a.labels = t.labels; a.weights = t.weights;
     a.logits = t.logits; a.da = t.da; a.dlogits = t.dlogits; a.pixels = t.pixels; a.k = t.k; a.scale = t.scale; a.partials = t.partials; a.error_flag = t.error_flag;
     a.bn_mean = t.bnred_mean; a.bn_invstd = t.bnred_invstd; a.bn_partials = t.src.kind == SRC_ACT ? t.bnred_partials : nullptr;
+    a.bn_acc = t.src.kind == SRC_ACT ? t.bnred_acc : nullptr;
+    a.bn_finish = t.bnred_finish;
+    ANH_REQUIRE(!a.bn_acc || t.src.a_tab.acc, "head_train: table-mode sums need the input layer's accumulator table");
     const int blocks = head_train_blocks(t.pixels);
     const bool bf = t.src.dtype == DT_BF16;
-    auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, s, a); };
+    BnFoldJobs jobs;
+    if (t.fold) jobs = *t.fold;
+    ANH_REQUIRE(jobs.n <= blocks, "head_train: more fold jobs than workgroups");
+    auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, s, a, jobs); };
     auto pick = [&](auto tag_t, auto tag_kind) {
         using T = decltype(tag_t); constexpr int KIND = decltype(tag_kind)::value;
         switch (t.k) {
@@ -1805,6 +1860,8 @@ void launch_head_train(const HeadTrainArgs& t, hipStream_t s) {
     hipLaunchKernelGGL(head_finalize_kernel, dim3(slots), dim3(64), 0, s, t.partials, blocks, slots, t.k, t.loss_out, t.loss_out_f32, t.dbias, t.dw);
     HIP_CHECK(hipGetLastError());
 }
+
+bool bn_table_mode_ok(int c) { return bn_vec_ok(c) && c <= 2048; }
 
 int bn_partial_blocks(int64_t pixels) { const int ppb = bn_pixels_per_block(pixels); return (int)((pixels + ppb - 1) / ppb); }
 
@@ -1841,6 +1898,12 @@ void launch_bn_forward_finalize(const BnFwdArgs& a, int blocks, hipStream_t s) {
     HIP_CHECK(hipGetLastError());
 }
 
+void launch_bn_fold_all(const BnFoldJobs& jobs, hipStream_t s) {
+    if (jobs.n == 0) return;
+    hipLaunchKernelGGL(bn_fold_all_kernel, dim3(jobs.n), dim3(128), 0, s, jobs);
+    HIP_CHECK(hipGetLastError());
+}
+
 void launch_bn_running_update(const float* mean, const double* var, float* running_mean, float* running_var, int c,
                               double averaging_factor, double unbias, hipStream_t s) {
     hipLaunchKernelGGL(bn_running_kernel, dim3((c + 63) / 64), dim3(64), 0, s, mean, var, running_mean, running_var, c, averaging_factor, unbias);
@@ -1851,12 +1914,15 @@ void launch_bn_running_update(const float* mean, const double* var, float* runni
 void launch_bn_bwd_reduce(const BnBwdArgs& a, hipStream_t s) {
     const int blocks = bn_partial_blocks(a.pixels);
     const bool bf = a.dtype == DT_BF16;
+    BnBwdFinish fin = a.finish;
+    fin.acc = a.acc;   // null: partials + finalize kernel
     if (bn_vec_ok(a.c)) {
         if (bf) hipLaunchKernelGGL(bn_bwd_reduce_vec_kernel<bf16>, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const bf16*>(a.da), reinterpret_cast<const bf16*>(a.y),
-                                   a.pixels, a.c, a.mean, a.invstd, a.scale, a.shift, a.partials, bn_pixels_per_block(a.pixels));
+                                   a.pixels, a.c, a.mean, a.invstd, a.scale, a.shift, a.partials, bn_pixels_per_block(a.pixels), fin);
         else hipLaunchKernelGGL(bn_bwd_reduce_vec_kernel<float>, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const float*>(a.da), reinterpret_cast<const float*>(a.y),
-                                a.pixels, a.c, a.mean, a.invstd, a.scale, a.shift, a.partials, bn_pixels_per_block(a.pixels));
+                                a.pixels, a.c, a.mean, a.invstd, a.scale, a.shift, a.partials, bn_pixels_per_block(a.pixels), fin);
     } else {
+        ANH_REQUIRE(!a.acc, "bn_bwd_reduce: table mode needs the vectorised kernel");
         const dim3 block = bn_block(a.c);
         const size_t shmem = (size_t)block.y * a.c * 2 * sizeof(float);
         if (bf) hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16>, dim3(blocks), block, shmem, s, reinterpret_cast<const bf16*>(a.da), reinterpret_cast<const bf16*>(a.y),

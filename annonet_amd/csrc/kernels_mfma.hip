@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <vector>
 
+#include "bnacc.h"
 #include "common.h"
 #include "kernels.h"
 
@@ -1156,19 +1157,31 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
     const int H = a.h_in, W = a.w_in, c_red = a.c_red;
     const int n_slabs = c_red >> 5, n_tiles = tiles_x * tiles_y * a.n;
     constexpr bool CAN_STATS = G::ACC * NT <= 4 || FWD;  // register budget of the consumer waves
-    const bool fuse_stats = !ACT && CAN_STATS && a.stat_partials != nullptr;   // forward: bn statistics of the output
-    const bool fuse_bnred = !FWD && CAN_STATS && a.bnred_partials != nullptr;  // backward-data: dgamma / dbeta sums of the layer `out` belongs to
+    const bool fuse_stats = !ACT && CAN_STATS && (a.stat_partials != nullptr || a.stat_acc != nullptr);   // forward: bn statistics of the output
+    const bool fuse_bnred = !FWD && CAN_STATS && (a.bnred_partials != nullptr || a.bnred_acc != nullptr);  // backward-data: dgamma / dbeta sums of the layer `out` belongs to
     const int stat_mode = fuse_stats ? 1 : fuse_bnred ? 2 : 0;
     float* bnc = tab + c_red * 4;            // [scale | shift | mean | invstd][C_OUT] of this workgroup's channels
 
     int tile = blockIdx.x, slab = 0, it = 0;
     auto init_tables = [&]() __attribute__((always_inline)) {   // every thread of the workgroup, from either branch below
         if (KIND == SRC_ACT || KIND == SRC_ACT2) {
-            for (int i = threadIdx.x; i < c_red; i += 512) {
-                tab[i] = a.src.a_scale[i];
-                tab[c_red + i] = a.src.a_shift[i];
-                tab[2 * c_red + i] = KIND == SRC_ACT2 ? a.src.b_scale[i] : 0.f;
-                tab[3 * c_red + i] = KIND == SRC_ACT2 ? a.src.b_shift[i] : 0.f;
+            if (a.src.a_tab.acc) {   // table mode: the producers' (scale, shift) are folded here from their accumulator tables (bnacc.h)
+                const int sides = KIND == SRC_ACT2 ? 2 : 1;
+                for (int i = threadIdx.x; i < sides * c_red; i += 512) {
+                    const int side = i >= c_red, ch = i - side * c_red;
+                    const BnTable& t = side ? a.src.b_tab : a.src.a_tab;
+                    const BnFolded f = bnacc_fold_forward(t.acc, t.c, ch, t.pixels, t.gamma[ch], t.beta[ch], t.eps);
+                    tab[2 * side * c_red + ch] = f.scale;
+                    tab[(2 * side + 1) * c_red + ch] = f.shift;
+                }
+                if (KIND != SRC_ACT2) for (int i = threadIdx.x; i < c_red; i += 512) { tab[2 * c_red + i] = 0.f; tab[3 * c_red + i] = 0.f; }
+            } else {
+                for (int i = threadIdx.x; i < c_red; i += 512) {
+                    tab[i] = a.src.a_scale[i];
+                    tab[c_red + i] = a.src.a_shift[i];
+                    tab[2 * c_red + i] = KIND == SRC_ACT2 ? a.src.b_scale[i] : 0.f;
+                    tab[3 * c_red + i] = KIND == SRC_ACT2 ? a.src.b_shift[i] : 0.f;
+                }
             }
         }
         if (ACT) {
@@ -1474,10 +1487,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
 #pragma unroll
             for (int off = 1; off < GRP; off <<= 1) sum += __shfl_xor(sum, off, 64);
             if (part == 0) {
+                long long* table = fuse_stats ? a.stat_acc : a.bnred_acc;
                 double* dst = fuse_stats ? a.stat_partials : a.bnred_partials;
-                dst[((size_t)(co_base + ch) * 2 + which) * gridDim.x + blockIdx.x] = sum;
+                if (table) bnacc_add(table, (fuse_stats ? BNACC_SUM_Y : BNACC_SUM_DZ_XHAT) + which, a.c_out, co_base + ch, sum);
+                else dst[((size_t)(co_base + ch) * 2 + which) * gridDim.x + blockIdx.x] = sum;
             }
         }
+        // table mode, backward sums: the last workgroup to finish leaves dgamma / dbeta / the apply coefficients of that layer
+        if (fuse_bnred && a.bnred_acc) bnacc_finish_backward(a.bnred_finish, (int)(gridDim.x * gridDim.y));
     }
 #ifdef ANH_WS_PROFILE
     if (prof && lane == 0) {
@@ -1547,7 +1564,7 @@ void launch_ws(const ConvArgs& a, int tiles_x, int tiles_y, int flip, hipStream_
     // the forward-only form exists where it buys something: four accumulator groups at NT = 2 (cont forward), whose bn
     // statistics sums take the registers the backward forms spend on prefetched epilogue operands
     if (a.out_scale) {   // inference: activation-storing epilogue, plain-copy (or skip-add) staging
-        ANH_REQUIRE(a.out_shift && !a.stat_partials && !a.bnred_partials && !a.out_accumulate && !a.out2, "conv_ws: the activation-storing form takes no training epilogue");
+        ANH_REQUIRE(a.out_shift && !a.stat_partials && !a.bnred_partials && !a.stat_acc && !a.bnred_acc && !a.out_accumulate && !a.out2, "conv_ws: the activation-storing form takes no training epilogue");
         switch (a.src.kind) {
             case SRC_RAW: launch(conv3x3_ws_kernel<G, NT, SRC_RAW, true, true>); break;
             case SRC_SUM2: launch(conv3x3_ws_kernel<G, NT, SRC_SUM2, true, true>); break;
@@ -1557,7 +1574,7 @@ void launch_ws(const ConvArgs& a, int tiles_x, int tiles_y, int flip, hipStream_
         return;
     }
     constexpr bool HAS_FWD_FORM = G::ACC * NT > 4;
-    const bool fwd_form = HAS_FWD_FORM && a.stat_partials && !a.bnred_partials && !a.out_accumulate && !a.out2;
+    const bool fwd_form = HAS_FWD_FORM && (a.stat_partials || a.stat_acc) && !a.bnred_partials && !a.bnred_acc && !a.out_accumulate && !a.out2;
     if constexpr (HAS_FWD_FORM) {
         if (fwd_form) {
             switch (a.src.kind) {
@@ -2015,7 +2032,7 @@ __global__ __launch_bounds__(256, (ACT ? 4 : 2)) void stem_mfma_kernel(ConvArgs 
                 wf[ky][ks][j] = (bf16)w;
             }
 
-    const bool fuse_stats = !ACT && a.stat_partials != nullptr;   // training forward: bn statistics of the stored output, as conv3x3_ws
+    const bool fuse_stats = !ACT && (a.stat_partials != nullptr || a.stat_acc != nullptr);   // training forward: bn statistics of the stored output, as conv3x3_ws
     float stat[1][2][16];
     u32x4 none[1][2];
 #pragma unroll
@@ -2128,7 +2145,10 @@ __global__ __launch_bounds__(256, (ACT ? 4 : 2)) void stem_mfma_kernel(ConvArgs 
         }
         sum += __shfl_xor(sum, 1, 64);
         sum += __shfl_xor(sum, 2, 64);
-        if (part == 0) a.stat_partials[((size_t)ch * 2 + which) * gridDim.x + blockIdx.x] = sum;
+        if (part == 0) {
+            if (a.stat_acc) bnacc_add(a.stat_acc, BNACC_SUM_Y + which, 32, ch, sum);
+            else a.stat_partials[((size_t)ch * 2 + which) * gridDim.x + blockIdx.x] = sum;
+        }
     }
 }
 
@@ -2251,6 +2271,9 @@ int conv_fused_stat_blocks(const ConvArgs& a) {
     return p.grid_x;
 }
 
+// the persistent kernels fold Src::a_tab / b_tab in their table prologue; the classic one-tile kernels read arrays only
+bool conv_folds_bn_tables(const ConvArgs& a) { return mfma_conv_supported(a) && !stem_mfma_ok(a) && ws_form_ok(a); }
+
 int conv_fused_bnred_blocks(const ConvArgs& a) {
     if (!mfma_conv_supported(a) || stem_mfma_ok(a) || (int64_t)a.n * a.h_out * a.w_out == 0) return 0;
     static const int on = getenv("ANH_FUSE_BN_BWD_REDUCE") ? atoi(getenv("ANH_FUSE_BN_BWD_REDUCE")) : 1;
@@ -2265,7 +2288,9 @@ void launch_conv_mfma(const ConvArgs& a, hipStream_t s) {
     if ((int64_t)a.n * a.h_out * a.w_out == 0) return;
     if (stem_mfma_ok(a)) { launch_stem_mfma(a, s); return; }
     const ConvPlan p = conv_plan(a);
-    ANH_REQUIRE(!a.stat_partials || conv_fused_stat_blocks(a) > 0, "conv_mfma: this layer's kernel does not fuse bn statistics");
+    ANH_REQUIRE(!(a.stat_partials || a.stat_acc) || conv_fused_stat_blocks(a) > 0, "conv_mfma: this layer's kernel does not fuse bn statistics");
+    ANH_REQUIRE(!a.bnred_acc || (conv_fused_bnred_blocks(a) > 0 && !a.stat_partials && !a.stat_acc), "conv_mfma: this layer's kernel does not fuse the bn backward reduction");
+    ANH_REQUIRE(!a.src.a_tab.acc || conv_folds_bn_tables(a), "conv_mfma: this layer's kernel does not fold bn accumulator tables");
     ANH_REQUIRE(!a.bnred_partials || (conv_fused_bnred_blocks(a) > 0 && !a.stat_partials), "conv_mfma: this layer's kernel does not fuse the bn backward reduction");
     if (p.geo == 0) {
         if (p.form == 2) { if (p.nt == 1) launch_ws<GeoS1, 1>(a, p.tiles_x, p.tiles_y, p.flip, s); else launch_ws<GeoS1, 2>(a, p.tiles_x, p.tiles_y, p.flip, s); }

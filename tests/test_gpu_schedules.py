@@ -7,8 +7,8 @@ tests/helpers/run_train_steps.py in its own process: 3 bf16 steps on a seeded ba
     the conv filter slabs streamed through LDS with every patch instead of staying resident; the gradient under the fused
     head written to memory instead of recomputed by its bn backward pass; stream priorities; the conv kernels' producer /
     consumer waves mapped to separate SIMDs;
-  * variants that change a summation order (bn statistics / bn backward sums in a conv epilogue vs. the separate
-    kernels; the classic one-tile conv kernels; dy materialised for the stem) agree to bf16-training tolerance.
+  * variants that change a summation order (bn sums in accumulator tables folded by their consumers vs. per-workgroup
+    partials with finalize kernels; bn statistics / bn backward sums in a conv epilogue vs. the separate kernels; the classic one-tile conv kernels; dy materialised for the stem) agree to bf16-training tolerance.
 """
 import os
 import subprocess
@@ -52,6 +52,7 @@ def test_schedule_is_bit_identical(tmp_path, default_run, name, env):
 
 
 @pytest.mark.parametrize("name,env", [
+    ("bn_sums_as_partials_with_finalize_kernels", {"ANH_BN_TABLES": "0"}),
     ("separate_bn_statistics", {"ANH_FUSE_BN_STATS": "0"}),
     ("separate_bn_backward_reduction", {"ANH_FUSE_BN_BWD_REDUCE": "0"}),
     ("stem_dy_materialised", {"ANH_FUSE_STEM_BN_APPLY": "0"}),

@@ -14,7 +14,7 @@ res = {a: [], b: []}
 for r in range(rounds):
     for lib in (a, b):
         env = dict(os.environ, ANH_LIBRARY=lib)
-        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "40", "--warmup", "10", "--no-cpu-baseline"] + extra, env=env, capture_output=True, text=True)
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "40", "--warmup", "10", "--no-cpu-baseline", "--no-infer", "--prewarm-s", "1"] + extra, env=env, capture_output=True, text=True)
         line = [l for l in out.stdout.splitlines() if l.startswith("{")]
         if not line:
             sys.exit(out.stderr[-3000:])
