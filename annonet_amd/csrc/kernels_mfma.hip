@@ -98,6 +98,10 @@ __device__ __forceinline__ uint4 add_bf16x8(const uint4& p, const uint4& q) {
                       pack2(lo_f(p.z) + lo_f(q.z), hi_f(p.z) + hi_f(q.z)), pack2(lo_f(p.w) + lo_f(q.w), hi_f(p.w) + hi_f(q.w)));
 }
 
+// Epilogue buffer (conv3x3_ws, producer-side bn backward sums): pixel slot q holds the stored values of its NT*32 channels as
+// 16-byte chunks k = channel / 8, chunk index XOR-ed so that the eight lanes of a ds_write_b128 group hit distinct banks.
+template <int NT> __device__ __forceinline__ int ebuf_swizzle(int q) { return NT == 1 ? (q >> 2) & 3 : (q >> 1) & 7; }
+
 // NT 32-channel accumulator tiles of one pixel per lane -> NHWC bf16.  Lane = pixel x half; registers 4q..4q+3 of a tile
 // hold channels 8q + 4*half + 0..3, so two v_permlane32_swap per 16 channels leave 8 consecutive channels (16 bytes) in
 // every lane.  With "accumulate" the old values are fetched by one batch of unconditional loads (pix is clamped by the
@@ -110,7 +114,8 @@ template <int NT>
 __device__ __forceinline__ void store_pixel_tiles_rmw(const f32x16 (&acc)[NT], const ConvArgs& a, size_t pix, bool valid, int half, int co_base,
                                                       const u32x4 (&prefetched)[NT][2], bool use_prefetched,
                                                       float (*stat)[2][16] = nullptr, int stat_mode = 0,
-                                                      const u32x4 (*yraw)[2] = nullptr, const float* bnc = nullptr) {
+                                                      const u32x4 (*yraw)[2] = nullptr, const float* bnc = nullptr,
+                                                      char* ebuf = nullptr, int eq = 0) {
     const int C_OUT = a.c_out;  // a workgroup may own only NT*32 of the layer's output channels, starting at co_base
     uint4 q[NT][2];
 #pragma unroll
@@ -149,6 +154,12 @@ __device__ __forceinline__ void store_pixel_tiles_rmw(const f32x16 (&acc)[NT], c
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int s = 0; s < 2; ++s) *reinterpret_cast<uint4*>(out + base + nt * 32 + 16 * s) = fin[nt][s];
+    }
+    if (ebuf) {   // the final values also go to the workgroup's epilogue buffer: the staging waves form the bn backward sums from them
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) *reinterpret_cast<uint4*>(ebuf + eq * (64 * NT) + (((nt * 4 + 2 * s + half) ^ ebuf_swizzle<NT>(eq)) << 4)) = fin[nt][s];
     }
     if (stat_mode == 1 && valid) {
 #pragma unroll
@@ -1120,8 +1131,13 @@ struct GeoUp {
 // FWD: the forward-only form — no prefetched epilogue operands (old values of an accumulating destination, y of the
 // layer behind `out`), whose registers the four-accumulator-group geometry at NT = 2 needs for its bn statistics sums.
 // ACT (inference, with FWD): the epilogue applies this layer's own folded bn + relu (ConvArgs::out_scale) and stores the activation.
-template <class G, int NT, int KIND, bool FWD = false, bool ACT = false>
-__global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tiles_x, int tiles_y, int flip, long long* prof, int wres_) {
+// PS (backward-data forms, with the bn backward sums fused): the sums are formed by the PRODUCER waves.  The consumers' epilogue
+// leaves the stored values of a tile in an LDS epilogue buffer (e_off); two items later a producer thread — which owns a fixed
+// 16-byte channel chunk, hence 16 running sums instead of the consumers' NT x 32 — reads them back beside the y it has fetched
+// meanwhile.  In the backward-data convs the producers (plain-copy staging) wait at the hand-over barrier for a third to half of
+// the kernel while the consumers' epilogue is as long as their MFMA phase: this moves that work to where the slack is.
+template <class G, int NT, int KIND, bool FWD = false, bool ACT = false, bool PS = false>
+__global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tiles_x, int tiles_y, int flip, long long* prof, int wres_, int e_off) {
     // per-phase wall-clock accounting, compiled in with -DANH_WS_PROFILE (ANH_WS_PROF=1 then prints one line per launch)
 #ifdef ANH_WS_PROFILE
     long long t_a = 0, t_b = 0, t_c = 0, t0_;
@@ -1157,9 +1173,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
     const int H = a.h_in, W = a.w_in, c_red = a.c_red;
     const int n_slabs = c_red >> 5, n_tiles = tiles_x * tiles_y * a.n;
     constexpr bool CAN_STATS = G::ACC * NT <= 4 || FWD;  // register budget of the consumer waves
-    const bool fuse_stats = !ACT && CAN_STATS && (a.stat_partials != nullptr || a.stat_acc != nullptr);   // forward: bn statistics of the output
-    const bool fuse_bnred = !FWD && CAN_STATS && (a.bnred_partials != nullptr || a.bnred_acc != nullptr);  // backward-data: dgamma / dbeta sums of the layer `out` belongs to
-    const int stat_mode = fuse_stats ? 1 : fuse_bnred ? 2 : 0;
+    const bool fuse_stats = !PS && !ACT && CAN_STATS && (a.stat_partials != nullptr || a.stat_acc != nullptr);   // forward: bn statistics of the output
+    const bool fuse_bnred = !FWD && (PS || CAN_STATS) && (a.bnred_partials != nullptr || a.bnred_acc != nullptr);  // backward-data: dgamma / dbeta sums of the layer `out` belongs to
+    const int stat_mode = fuse_stats ? 1 : (fuse_bnred && !PS) ? 2 : 0;   // sums kept by the CONSUMER waves
+    const bool ps = PS && fuse_bnred;                                      // sums kept by the producer waves
+    constexpr int E_BYTES = G::ACC * 128 * 64 * NT;                        // epilogue buffer: ACC x 128 pixel slots of NT x 64 bytes
+    constexpr int EK = 4 * NT, EQ_STEP = 256 / EK, ECH = G::ACC * 128 / EQ_STEP;   // chunks per pixel; pixel slots between a thread's chunks; chunks per thread
     float* bnc = tab + c_red * 4;            // [scale | shift | mean | invstd][C_OUT] of this workgroup's channels
 
     int tile = blockIdx.x, slab = 0, it = 0;
@@ -1319,7 +1338,55 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
         }
         init_tables();
         if (DEEP2 && ftile < n_tiles) fetch(R1);
+        // ---- PS: bn backward sums of the tile whose epilogue the consumers finished two items ago ----
+        float esc[8], esh[8], emu[8], eis[8], est[16];
+        const int ek = tid & (EK - 1), eq0 = tid / EK;   // this thread's chunk (channels 8 ek .. 8 ek + 7 of the workgroup's) and first pixel slot
+        int hist1 = -1, hist2 = -1, hist1_it = 0, hist2_it = 0;   // tile (or -1) and item index of the last two items whose epilogue leaves a buffer
+        if (PS) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                esc[j] = bnc[ek * 8 + j]; esh[j] = bnc[C_OUT + ek * 8 + j]; emu[j] = bnc[2 * C_OUT + ek * 8 + j]; eis[j] = bnc[3 * C_OUT + ek * 8 + j];
+                est[j] = 0.f; est[8 + j] = 0.f;
+            }
+        }
+        const bf16* ylayer = reinterpret_cast<const bf16*>(a.bnred_y);
+        auto estat_begin = [&](int et, u32x4 (&yv)[ECH], unsigned& evalid) __attribute__((always_inline)) {   // the y operands are requested ...
+            const int tx = et % tiles_x, ty = (et / tiles_x) % tiles_y, n = et / per_img;
+            evalid = 0;
+#pragma unroll
+            for (int j = 0; j < ECH; ++j) {
+                const int q = eq0 + EQ_STEP * j;
+                size_t pix; bool valid;
+                G::out_pixel(q >> 7, a, n, ty, tx, (q >> 5) & 3, q & 31, pix, valid);
+                yv[j] = *reinterpret_cast<const u32x4*>(ylayer + pix * a.c_out + co_base + ek * 8);
+                evalid |= (valid ? 1u : 0u) << j;
+            }
+        };
+        auto estat_end = [&](int eit, const u32x4 (&yv)[ECH], unsigned evalid) __attribute__((always_inline)) {   // ... and meet the stored values here
+            const char* eb = smem + e_off + (n_slabs == 1 ? (eit & 1) * E_BYTES : 0);
+#pragma unroll
+            for (int j = 0; j < ECH; ++j) {
+                const int q = eq0 + EQ_STEP * j;
+                const u32x4 dv = *reinterpret_cast<const u32x4*>(eb + q * (64 * NT) + ((ek ^ ebuf_swizzle<NT>(q)) << 4));
+                if ((evalid >> j) & 1u) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int h2 = 0; h2 < 2; ++h2) {
+                            const int c = 2 * i + h2;
+                            const float d = h2 ? hi_f(dv[i]) : lo_f(dv[i]), y = h2 ? hi_f(yv[j][i]) : lo_f(yv[j][i]);
+                            const float dz = fmaf(y, esc[c], esh[c]) > 0.f ? d : 0.f;
+                            est[c] = fmaf(dz, (y - emu[c]) * eis[c], est[c]);
+                            est[8 + c] += dz;
+                        }
+                }
+            }
+        };
         auto one_item = [&](Fetched& R) __attribute__((always_inline)) {
+            u32x4 eyv[PS ? ECH : 1];
+            unsigned evalid = 0;
+            const int et = hist2, eit = hist2_it;
+            if constexpr (PS) { if (ps && et >= 0) estat_begin(et, eyv, evalid); }
             TICK();
             commit(R);
 #ifdef ANH_WS_PROFILE
@@ -1329,10 +1396,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
             TICK();
             if (ftile < n_tiles) fetch(R);
             if (!wres && n_slabs > 1 && (slab + 1 < n_slabs || tile + gstep < n_tiles)) fetch_w(slab + 1 < n_slabs ? slab + 1 : 0);
+            if constexpr (PS) { if (ps && et >= 0) estat_end(eit, eyv, evalid); }
             TOCK(t_b);
             TICK();
             __syncthreads();  // buffer it & 1 is full; the consumers are done with buffer (it + 1) & 1
             TOCK(t_c);
+            hist2 = hist1; hist2_it = hist1_it;
+            hist1 = slab == n_slabs - 1 ? tile : -1; hist1_it = it;
             if (++slab == n_slabs) { slab = 0; tile += gstep; }
             ++it;
         };
@@ -1349,6 +1419,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
 #ifdef ANH_WS_PROFILE
         t_loop_end = wall_clock64();
 #endif
+        if constexpr (PS) {
+            if (ps) {   // the last two items: the one before the last is ready, the last one after the consumers' closing barrier
+                u32x4 eyv[ECH];
+                unsigned evalid = 0;
+                if (hist2 >= 0) { estat_begin(hist2, eyv, evalid); estat_end(hist2_it, eyv, evalid); }
+                __syncthreads();
+                if (hist1 >= 0) { estat_begin(hist1, eyv, evalid); estat_end(hist1_it, eyv, evalid); }
+                float* red = reinterpret_cast<float*>(smem) + (size_t)tid * 16;   // the staging buffers are free now
+#pragma unroll
+                for (int e = 0; e < 16; ++e) red[e] = est[e];
+            }
+        }
     } else {
         init_tables();
         typename G::Bases b0;
@@ -1366,7 +1448,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
         constexpr bool DEEP = !FWD && NT == 1 && G::RMW_PREFETCH, DEEP_Y = false;
         u32x4 old_n[DEEP ? G::ACC : 1][NT][2], yraw_n[DEEP_Y ? G::ACC : 1][NT][2];
         const bool rmw_any = !FWD && G::RMW_PREFETCH && a.out_accumulate;
-        const bool pre_any = rmw_any || fuse_bnred;
+        const bool cons_bnred = fuse_bnred && !PS;   // the consumers keep the bn backward sums (and fetch y for them)
+        const bool pre_any = rmw_any || cons_bnred;
         auto prefetch_epilogue = [&](int t, auto& o, auto& y, bool want_old, bool want_y) __attribute__((always_inline)) {
             const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, n = t / (tiles_x * tiles_y);
             const bf16* out = reinterpret_cast<const bf16*>(a.out);
@@ -1387,7 +1470,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
                     }
             }
         };
-        if (DEEP && pre_any && tile < n_tiles) prefetch_epilogue(tile, old, yraw, rmw_any, fuse_bnred && DEEP_Y);
+        if (DEEP && pre_any && tile < n_tiles) prefetch_epilogue(tile, old, yraw, rmw_any, cons_bnred && DEEP_Y);
         float stat[NT][2][16];      // per-lane running sums of this lane's 8 channels per (nt, s): see store_pixel_tiles_rmw
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
@@ -1423,9 +1506,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
             const bool rmw = rmw_any && last_slab;
             if (pre_any && last_slab) {  // epilogue operands travel while the MFMAs run
                 if constexpr (DEEP) {
-                    if (tile + (int)gridDim.x < n_tiles) prefetch_epilogue(tile + (int)gridDim.x, old_n, yraw_n, rmw_any, fuse_bnred && DEEP_Y);
-                    if constexpr (!DEEP_Y) prefetch_epilogue(tile, old, yraw, false, fuse_bnred);
-                } else prefetch_epilogue(tile, old, yraw, rmw_any, fuse_bnred);
+                    if (tile + (int)gridDim.x < n_tiles) prefetch_epilogue(tile + (int)gridDim.x, old_n, yraw_n, rmw_any, cons_bnred && DEEP_Y);
+                    if constexpr (!DEEP_Y) prefetch_epilogue(tile, old, yraw, false, cons_bnred);
+                } else prefetch_epilogue(tile, old, yraw, rmw_any, cons_bnred);
             }
             G::template mfma<NT>(acc, b, wb);
 #ifdef ANH_WS_PROFILE
@@ -1439,7 +1522,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
                     size_t pix; bool valid;
                     G::out_pixel(g, a, n, ty, tx, wave, col, pix, valid);
                     if constexpr (ACT) store_pixel_tiles_act<NT>(acc[g], a, pix, valid, half, co_base, bnc, C_OUT);
-                    else store_pixel_tiles_rmw<NT>(acc[g], a, pix, valid, half, co_base, old[FWD ? 0 : g], rmw, stat, stat_mode, yraw[FWD ? 0 : g], bnc);
+                    else store_pixel_tiles_rmw<NT>(acc[g], a, pix, valid, half, co_base, old[FWD ? 0 : g], rmw, stat, stat_mode, yraw[FWD ? 0 : g], bnc,
+                                                   ps ? smem + e_off + (n_slabs == 1 ? (it & 1) * E_BYTES : 0) : nullptr, (g * 4 + wave) * 32 + col);
                 }
                 if constexpr (DEEP) {
                     if (pre_any) {
@@ -1456,6 +1540,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
             TOCK(t_b);
             tile = ntile; slab = nslab; ++it;
         }
+        if constexpr (PS) { if (ps) __syncthreads(); }   // the consumers' closing barrier: the last tile's epilogue buffer is complete
         if (stat_mode) {
             __syncthreads();  // (matched by the producers) every wave is done with the staging buffers
             float* red = reinterpret_cast<float*>(smem) + (size_t)(wave * 64 + lane) * (32 * NT);
@@ -1493,9 +1578,27 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
                 else dst[((size_t)(co_base + ch) * 2 + which) * gridDim.x + blockIdx.x] = sum;
             }
         }
-        // table mode, backward sums: the last workgroup to finish leaves dgamma / dbeta / the apply coefficients of that layer
-        if (fuse_bnred && a.bnred_acc) bnacc_finish_backward(a.bnred_finish, (int)(gridDim.x * gridDim.y));
     }
+    if constexpr (PS) {
+        if (ps) {   // the producers' 16 sums per thread -> (channel, which) = 64 NT sums, each over the 256 / EK threads that own the chunk, fixed order, in double
+            __syncthreads();
+            constexpr int GRP = 512 / (64 * NT);
+            const int t = threadIdx.x / GRP, part = threadIdx.x % GRP;
+            const int ch = t >> 1, which = t & 1, k = ch >> 3, j = ch & 7;
+            const float* red = reinterpret_cast<const float*>(smem);
+            double sum = 0.0;
+#pragma unroll 4
+            for (int m = part; m < EQ_STEP; m += GRP) sum += (double)red[(size_t)(k + EK * m) * 16 + which * 8 + j];
+#pragma unroll
+            for (int off = 1; off < GRP; off <<= 1) sum += __shfl_xor(sum, off, 64);
+            if (part == 0) {
+                if (a.bnred_acc) bnacc_add(a.bnred_acc, BNACC_SUM_DZ_XHAT + which, a.c_out, co_base + ch, sum);
+                else a.bnred_partials[((size_t)(co_base + ch) * 2 + which) * gridDim.x + blockIdx.x] = sum;
+            }
+        }
+    }
+    // table mode, backward sums: the last workgroup to finish leaves dgamma / dbeta / the apply coefficients of that layer
+    if (fuse_bnred && a.bnred_acc) bnacc_finish_backward(a.bnred_finish, (int)(gridDim.x * gridDim.y));
 #ifdef ANH_WS_PROFILE
     if (prof && lane == 0) {
         long long* o = prof + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (producer ? 4 : 0) + wave) * 8;
@@ -1519,8 +1622,26 @@ void launch_ws(const ConvArgs& a, int tiles_x, int tiles_y, int flip, hipStream_
     static const bool resident_on = !(getenv("ANH_WS_WEIGHT_RESIDENT") && atoi(getenv("ANH_WS_WEIGHT_RESIDENT")) == 0);
     const int n_slabs = a.c_red >> 5;
     const size_t resident_lds = 2 * x_bytes + (size_t)n_slabs * w_bytes + tables;
-    const int wres = resident_on && n_slabs >= 2 && resident_lds <= 160 * 1024 && 2 * x_bytes + (size_t)n_slabs * w_bytes >= (size_t)32 * 1024 * NT;
-    const size_t lds = wres ? resident_lds : 2 * (x_bytes + w_bytes) + tables;
+    int wres = resident_on && n_slabs >= 2 && resident_lds <= 160 * 1024 && 2 * x_bytes + (size_t)n_slabs * w_bytes >= (size_t)32 * 1024 * NT;
+    size_t lds = wres ? resident_lds : 2 * (x_bytes + w_bytes) + tables;
+    // Producer-side bn backward sums (the PS forms): plain-copy staging with the fused reduction, when the epilogue buffer fits —
+    // one buffer of ACC x 128 pixel slots, two (alternating by item) for single-slab layers whose every item ends a tile.  A
+    // single-slab layer may take the resident layout to make room (one filter block instead of a copy per patch buffer; whatever
+    // ANH_WS_WEIGHT_RESIDENT says — which waves keep the sums must not depend on a tuning switch, the summation order follows it).
+    // Measured (same-box A/B): a gain only where the consumers' epilogue is the long pole AND the producers' own work is
+    // small — the four-accumulator-group geometry (stride-2 con backward-data, 32 output channels: 119 -> 108 us); the stride-1 and
+    // down geometries get slower (32->32: 99 -> 117 us: their producers become the long pole).  ANH_WS_PSTAT: 0 off, 1 (default) the
+    // four-group geometry only, 2 every form that fits.
+    static const int ps_env = getenv("ANH_WS_PSTAT") ? atoi(getenv("ANH_WS_PSTAT")) : 1;
+    const bool ps_on = ps_env == 2 || (ps_env == 1 && G::ACC == 4);
+    const size_t e_total = (size_t)G::ACC * 128 * 64 * NT * (n_slabs == 1 ? 2 : 1);
+    bool ps = false;
+    if (ps_on && (a.bnred_partials || a.bnred_acc) && a.src.kind == SRC_RAW && !a.out_scale && !a.stat_partials && !a.stat_acc) {
+        if (lds + e_total <= 160 * 1024) ps = true;
+        else if (n_slabs == 1 && resident_lds + e_total <= 160 * 1024 && resident_lds - tables >= 16 * 1024) { wres = 1; lds = resident_lds; ps = true; }
+    }
+    const int e_off = ps ? (int)((lds + 15) / 16 * 16) : 0;
+    if (ps) lds = (size_t)e_off + e_total;
     // ANH_WS_ROLE_MAP: 0 = one producer + one consumer per SIMD, 1 = consumers on SIMDs 0-1 / producers on SIMDs 2-3, 2 = map 1 for the
     // 32-output-channel kernels only (their MFMA phase is short; the 64-channel kernels need all four matrix cores)
     static const int role_env = getenv("ANH_WS_ROLE_MAP") ? atoi(getenv("ANH_WS_ROLE_MAP")) : 0;
@@ -1528,12 +1649,12 @@ void launch_ws(const ConvArgs& a, int tiles_x, int tiles_y, int flip, hipStream_
     auto launch = [&](auto kernel) {
         ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), lds);
 #ifndef ANH_WS_PROFILE
-        hipLaunchKernelGGL(kernel, grid, block, lds, s, a, tiles_x, tiles_y, flip, (long long*)nullptr, wres | (role_map << 1));
+        hipLaunchKernelGGL(kernel, grid, block, lds, s, a, tiles_x, tiles_y, flip, (long long*)nullptr, wres | (role_map << 1), e_off);
 #else
         static const int prof_on = getenv("ANH_WS_PROF") ? atoi(getenv("ANH_WS_PROF")) : 0;
         static long long* prof = nullptr;
         if (prof_on && !prof) HIP_CHECK(hipMalloc(&prof, 1024 * 8 * 8 * sizeof(long long)));
-        hipLaunchKernelGGL(kernel, grid, block, lds, s, a, tiles_x, tiles_y, flip, prof_on ? prof : nullptr, wres | (role_map << 1));
+        hipLaunchKernelGGL(kernel, grid, block, lds, s, a, tiles_x, tiles_y, flip, prof_on ? prof : nullptr, wres | (role_map << 1), e_off);
         if (prof_on) {
             HIP_CHECK(hipStreamSynchronize(s));
             const int nwg = grid.x * grid.y;
@@ -1587,6 +1708,7 @@ void launch_ws(const ConvArgs& a, int tiles_x, int tiles_y, int flip, hipStream_
             return;
         }
     }
+    if (ps) { launch(conv3x3_ws_kernel<G, NT, SRC_RAW, false, false, true>); HIP_CHECK(hipGetLastError()); return; }
     switch (a.src.kind) {
         case SRC_RAW: launch(conv3x3_ws_kernel<G, NT, SRC_RAW>); break;
         case SRC_ACT: launch(conv3x3_ws_kernel<G, NT, SRC_ACT>); break;

@@ -53,6 +53,8 @@ def test_schedule_is_bit_identical(tmp_path, default_run, name, env):
 
 @pytest.mark.parametrize("name,env", [
     ("bn_sums_as_partials_with_finalize_kernels", {"ANH_BN_TABLES": "0"}),
+    ("bn_backward_sums_kept_by_the_consumer_waves", {"ANH_WS_PSTAT": "0"}),
+    ("bn_backward_sums_kept_by_the_producer_waves_wherever_they_fit", {"ANH_WS_PSTAT": "2"}),
     ("separate_bn_statistics", {"ANH_FUSE_BN_STATS": "0"}),
     ("separate_bn_backward_reduction", {"ANH_FUSE_BN_BWD_REDUCE": "0"}),
     ("stem_dy_materialised", {"ANH_FUSE_STEM_BN_APPLY": "0"}),
