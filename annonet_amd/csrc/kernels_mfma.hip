@@ -1151,7 +1151,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
 #endif
     constexpr int C_OUT = NT * 32, NP = (G::RECS * 4 + 255) / 256, W_ITEMS = 9 * C_OUT * 4, NW = (W_ITEMS + 255) / 256;
     constexpr int X_BYTES_ = G::RECS * 64, W_BYTES = 9 * C_OUT * 64, BUF = X_BYTES_ + W_BYTES;
-    const int wres = wres_ & 1, role_map = wres_ >> 1;   // (see the role map below)
+    const int wres = wres_ & 1, role_map = (wres_ >> 1) & 1, prio = wres_ >> 2;   // (see the role map below; prio: experiment switch ANH_WS_PRIO)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // LDS layout.  Streaming form: [X | W] [X | W] tables — the filter slab of every item travels with its patch.
     // Resident form (wres; the filter slabs of ALL reduction slabs fit beside two patches, i.e. 64 reduction channels):
@@ -1219,6 +1219,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
         }
         __syncthreads();
     };
+    // ANH_WS_PRIO (experiment): 1 = the consumer (matrix) waves at s_setprio 1, 2 = the producer (staging) waves, 3 = consumers at 2 / producers at 1
+    if (prio == 1 && !producer) __builtin_amdgcn_s_setprio(1);
+    if (prio == 2 && producer) __builtin_amdgcn_s_setprio(1);
+    if (prio == 3) { if (producer) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2); }
     if (producer) {
         // The producers request their FIRST patch and the filter blocks before the tables are loaded and the workgroup meets:
         // those round trips overlap instead of adding up.
@@ -1645,7 +1649,8 @@ void launch_ws(const ConvArgs& a, int tiles_x, int tiles_y, int flip, hipStream_
     // ANH_WS_ROLE_MAP: 0 = one producer + one consumer per SIMD, 1 = consumers on SIMDs 0-1 / producers on SIMDs 2-3, 2 = map 1 for the
     // 32-output-channel kernels only (their MFMA phase is short; the 64-channel kernels need all four matrix cores)
     static const int role_env = getenv("ANH_WS_ROLE_MAP") ? atoi(getenv("ANH_WS_ROLE_MAP")) : 0;
-    const int role_map = role_env == 1 || (role_env == 2 && NT == 1) ? 1 : 0;
+    static const int prio_env = getenv("ANH_WS_PRIO") ? atoi(getenv("ANH_WS_PRIO")) : 0;
+    const int role_map = (role_env == 1 || (role_env == 2 && NT == 1) ? 1 : 0) | (prio_env << 1);
     auto launch = [&](auto kernel) {
         ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), lds);
 #ifndef ANH_WS_PROFILE

@@ -7,13 +7,24 @@ set -e
 out=gpurun_out/prof
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
+# the default line (training + the `infer` object measured by its child process), as the driver runs it
 python3 bench.py --dump-launch-order $out/launch_order.json > $out/bench.json 2> $out/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline > $out/bench_under_rocprof.json 2> $out/kt.err
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline > /dev/null 2> $out/fetch.err
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline > /dev/null 2> $out/write.err
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d $out/sq -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2> $out/sq.err
-python3 bench.py --mode infer > $out/bench_infer_4096_bf16.json 2> $out/infer.err
+# profiled runs: the training process alone (--no-infer; --prewarm-s 0 keeps the traces short)
+P="--no-cpu-baseline --no-infer --prewarm-s 0"
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -- python3 bench.py --steps 100 --warmup 10 $P > $out/bench_under_rocprof.json 2> $out/kt.err
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 bench.py --steps 30 --warmup 5 $P > /dev/null 2> $out/fetch.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 bench.py --steps 30 --warmup 5 $P > /dev/null 2> $out/write.err
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d $out/sq -- python3 bench.py --steps 20 --warmup 5 $P > /dev/null 2> $out/sq.err
+# tiled inference (BASELINE.json configs[2]): the line, the kernel stats of the same command, the two HBM counter passes
+I="--mode infer --no-cpu-baseline --prewarm-s 0"
+python3 bench.py --mode infer --dump-launch-order $out/infer_launch_order.json > $out/bench_infer_4096_bf16.json 2> $out/infer.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/ikt -- python3 bench.py $I --steps 20 --warmup 3 > $out/bench_infer_under_rocprof.json 2> $out/ikt.err
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/ifetch -- python3 bench.py $I --steps 6 --warmup 2 > /dev/null 2> $out/ifetch.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/iwrite -- python3 bench.py $I --steps 6 --warmup 2 > /dev/null 2> $out/iwrite.err
 python3 bench.py --mode infer --precision fp32 --steps 5 --warmup 1 --no-cpu-baseline > $out/bench_infer_4096_fp32.json 2>> $out/infer.err
 python3 bench.py --mode infer --image-side 16384 --steps 5 --warmup 1 --no-cpu-baseline > $out/bench_infer_16384_bf16.json 2>> $out/infer.err
-ANH_CONCURRENT_WGRAD=0 rocprofv3 --kernel-trace --output-format csv -d $out/kt1 -- python3 bench.py --steps 40 --warmup 10 --no-cpu-baseline > $out/bench_one_stream.json 2> $out/kt1.err
+ANH_CONCURRENT_WGRAD=0 rocprofv3 --kernel-trace --output-format csv -d $out/kt1 -- python3 bench.py --steps 40 --warmup 10 $P > $out/bench_one_stream_under_rocprof.json 2> $out/kt1.err
+ANH_CONCURRENT_WGRAD=0 python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-infer --prewarm-s 1 > $out/bench_one_stream.json 2> $out/one.err
+# stand-alone times of every layer x pass (one stream, no concurrent filter gradients): the MFMA-bound layers against the peak
+python3 tools/standalone_table.py $out/bench_one_stream.json > $out/standalone_table.txt
 echo collected; du -sh $out

@@ -31,6 +31,7 @@ KERNELS = [
     (r"^conv_mfma_bf16:(fwd|dgrad)_L\d+_", [r"conv3x3_ws_kernel|conv3x3s1_mfma_kernel|conv3x3_down_mfma_kernel|conv3x3_up_mfma_kernel"]),
     (r"^wgrad_mfma_bf16:wgrad_L\d+_stem_", [r"wgrad_stem_mfma_kernel"]),
     (r"^wgrad_mfma_bf16:wgrad_L\d+_", [r"wgrad3x3_(ws|mfma)_kernel"]),
+    (r"^conv_mfma_f32:", [r"conv_f32_mfma"]),
     (r"^conv_generic_(bf16|f32):", [r"conv_generic|stem_forward_kernel|head_forward"]),
     (r"^wgrad_generic_(bf16|f32):", [r"wgrad_generic|wgrad_stem"]),
     (r"^wgrad_reduce_partials$", [r"reduce_partials_kernel"]),
@@ -42,6 +43,11 @@ KERNELS = [
     (r"^head_fused_fwd_loss_bwd$", [r"head_train_kernel", r"head_finalize_kernel"]),
     (r"^softmax_logloss$", [r"loss_kernel", r"loss_finalize"]),
     (r"^sgd_momentum_wd$", [r"sgd_kernel"]),
+    (r"^bn_tables_zero$", []),                       # a runtime fill, not a kernel of this library
+    (r"^bn_fold_all$", [r"bn_fold_all_kernel"]),
+    (r"^head_blend_fused$", [r"head_blend_kernel"]),
+    (r"^blend_accumulate$", [r"(?<!head_)blend_kernel"]),
+    (r"^argmax_gain$", [r"argmax_kernel"]),
 ]
 OURS = re.compile(r"anh::|_ZN3anh")          # kernels of this library (everything else in the trace: runtime copies / fills)
 
@@ -87,7 +93,7 @@ def per_entry(dispatches, order, what):
         else:
             unmatched.append(ours[i][1])
             i += 1
-    if steps < 3:
+    if steps < 2:
         raise SystemExit(f"pmc_traffic: only {steps} complete steps of the launch order found in the {what} trace — the order does not fit the trace")
     # kernels outside complete steps: the first / last partial step of the run and set-up launches (layout refresh) are expected; anything
     # that is a large share of the trace is not

@@ -25,9 +25,14 @@ def run(*cmd, out):
         subprocess.check_call([sys.executable, *cmd], stdout=f)
 
 
-for name in ("bench.json", "bench_under_rocprof.json", "bench_infer_4096_bf16.json", "bench_infer_4096_fp32.json", "bench_infer_16384_bf16.json", "bench_one_stream.json", "launch_order.json"):
+for name in ("bench.json", "bench_under_rocprof.json", "bench_infer_4096_bf16.json", "bench_infer_under_rocprof.json", "bench_infer_4096_fp32.json", "bench_infer_16384_bf16.json",
+             "bench_one_stream.json", "launch_order.json", "infer_launch_order.json"):
     shutil.copy(os.path.join(SRC, name), os.path.join(DST, f"{tag}_{name}"))
 shutil.copy(one("kt/*/*_kernel_stats.csv"), os.path.join(DST, f"{tag}_kernel_stats.csv"))
+shutil.copy(os.path.join(SRC, "standalone_table.txt"), os.path.join(DST, f"{tag}_standalone_table.txt"))
+shutil.copy(one("ikt/*/*_kernel_stats.csv"), os.path.join(DST, f"{tag}_infer_kernel_stats.csv"))
+run(os.path.join(ROOT, "tools", "pmc_traffic.py"), os.path.join(SRC, "infer_launch_order.json"), one("ifetch/*/*_counter_collection.csv"), one("iwrite/*/*_counter_collection.csv"),
+    os.path.join(DST, f"{tag}_infer_traffic.json"), out=os.path.join(DST, f"{tag}_infer_traffic.txt"))
 order = os.path.join(SRC, "launch_order.json")
 fetch, write, sq = one("fetch/*/*_counter_collection.csv"), one("write/*/*_counter_collection.csv"), one("sq/*/*_counter_collection.csv")
 run(os.path.join(ROOT, "tools", "pmc_traffic.py"), order, fetch, write, os.path.join(DST, f"{tag}_traffic.json"), out=os.path.join(DST, f"{tag}_traffic.txt"))
