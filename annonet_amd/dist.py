@@ -205,9 +205,12 @@ class LabelGather:
         import torch
         import torch.distributed as dist
         mine = self.code(labels)
+        # gloo moves host memory only in its point-to-point calls: a rehearsal job with GPU tensors (bench.py --backend gloo) stages the
+        # bands through the host; over RCCL the bands travel GPU to GPU
+        via_host = mine.is_cuda and dist.get_backend(group) == "gloo"
         if self.rank != dst:
             if mine.numel():
-                for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, mine, dst, group)]):
+                for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, mine.cpu() if via_host else mine, dst, group)]):
                     w.wait()
             return None
         bands, ops = [], []
@@ -215,7 +218,7 @@ class LabelGather:
             if r == dst:
                 bands.append(mine if mine.numel() else None)
             elif row1 > row0:
-                buf = torch.empty((row1 - row0, self.width), dtype=torch.uint8, device=mine.device)
+                buf = torch.empty((row1 - row0, self.width), dtype=torch.uint8, device="cpu" if via_host else mine.device)
                 bands.append(buf)
                 ops.append(dist.P2POp(dist.irecv, buf, r, group))
             else:
@@ -223,6 +226,8 @@ class LabelGather:
         if ops:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
+        if via_host:
+            bands = [b.to(mine.device) if b is not None and not b.is_cuda else b for b in bands]
         return self.decode(self.merge(bands))
 
 

@@ -72,6 +72,8 @@ def self_launch(args):
     This process never initialises HIP (counting devices does not)."""
     import torch
     have = torch.cuda.device_count()
+    if args.one_gpu:
+        have = args.gpus if have >= 1 else 0   # rehearsal: every rank drives device 0
     if have < args.gpus:
         print(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) visible", file=sys.stderr)
         sys.exit(2)
@@ -301,7 +303,8 @@ def cpu_baseline_infer(aa, cfg, ov):
 
 # ----------------------------------------------------------------------------------------------------------------------
 def dist_facts(torch, dist, dev, local_rank, world, use_dist):
-    """ranks_seen = all-reduce of ones; devices = every rank's device index (proves N distinct ranks drove N devices)."""
+    """ranks_seen = all-reduce of ones; devices = every rank's device index (proves N distinct ranks drove N devices).
+    A job whose ranks do not add up leaves with an error instead of reporting a number for fewer GPUs than it claims."""
     if not use_dist:
         return 1, [local_rank]
     ones = torch.ones(1, device=dev)
@@ -309,7 +312,11 @@ def dist_facts(torch, dist, dev, local_rank, world, use_dist):
     mine = torch.tensor([local_rank], device=dev, dtype=torch.int64)
     gathered = [torch.zeros_like(mine) for _ in range(world)]
     dist.all_gather(gathered, mine)
-    return int(ones.item()), [int(g.item()) for g in gathered]
+    seen = int(ones.item())
+    if seen != world:
+        print(f"bench.py: {seen} rank(s) answered the all-reduce of ones, WORLD_SIZE is {world}", file=sys.stderr)
+        sys.exit(3)
+    return seen, [int(g.item()) for g in gathered]
 
 
 def prewarm(run_once, sync, seconds, agree=None):
@@ -488,11 +495,15 @@ def infer_in_child(args, world):
     """The inference workload for the training line's `infer` object: `bench.py --mode infer` as a CHILD process (for N > 1 it
     starts its own ranks), after this process has finished its own measurement.  Whatever happens there — an error, a hang cut at
     the timeout — stays inside the returned object."""
-    sides = "4096,16384" if world == 1 else "16384"
+    sides = args.infer_sides or ("4096,16384" if world == 1 else "16384")
     cmd = [sys.executable, os.path.abspath(__file__), "--mode", "infer", "--gpus", str(world), "--image-side", sides, "--steps", str(args.infer_steps),
            "--warmup", "2", "--precision", args.precision, "--prewarm-s", str(min(args.prewarm_s, 1.0))]
     if args.no_cpu_baseline:
         cmd.append("--no-cpu-baseline")
+    if args.backend != "nccl":
+        cmd += ["--backend", args.backend]
+    if args.one_gpu:
+        cmd.append("--one-gpu")
     drop = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE", "ROLE_RANK", "ROLE_WORLD_SIZE", "ROLE_NAME",
             "MASTER_ADDR", "MASTER_PORT", "OMP_NUM_THREADS")
     env = {k: v for k, v in os.environ.items() if k not in drop and not k.startswith("TORCHELASTIC_") and not k.startswith("TORCH_NCCL_")}
@@ -520,7 +531,11 @@ def main():
     ap.add_argument("--prewarm-s", type=float, default=PREWARM_S, help="untimed time-based pre-warm before the warm-up steps (declared in the line)")
     ap.add_argument("--no-infer", action="store_true", help="train mode: leave the `infer` object out (profile collection under rocprofv3)")
     ap.add_argument("--infer-steps", type=int, default=10)
-    ap.add_argument("--infer-timeout", type=float, default=420.0)
+    ap.add_argument("--infer-sides", default=None, help="image sides of the `infer` object (default: 4096,16384 at one GPU = BASELINE.json configs[2], 16384 = configs[4] otherwise)")
+    ap.add_argument("--infer-timeout", type=float, default=300.0)
+    ap.add_argument("--collective-timeout", type=float, default=180.0, help="seconds after which a collective that a rank never joined fails the job")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend: nccl = RCCL over xGMI (the job); gloo = rehearsal transport")
+    ap.add_argument("--one-gpu", action="store_true", help="rehearsal of the N > 1 paths on a one-GPU box: every rank drives device 0 (needs --backend gloo: RCCL wants one GPU per rank)")
     ap.add_argument("--dump-launch-order", default=None, help="write the step's launch order (profiler entry per kernel-class launch) as JSON: input of tools/pmc_traffic.py")
     args = ap.parse_args()
     if args.mode == "infer" and args.steps == 200:
@@ -538,14 +553,23 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.one_gpu:
+        if args.backend != "gloo":
+            raise SystemExit("--one-gpu is a rehearsal on one device: it needs --backend gloo (RCCL refuses two ranks on one GPU)")
+        local_rank = 0
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local_rank)
     aa._lib.check(aa.lib().anh_set_device(local_rank))
     import torch.distributed as dist
     use_dist = world > 1 or "RANK" in os.environ  # launched by torch.distributed.run: take the RCCL path even at world 1
     if use_dist:
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        # a rank that never arrives, or dies, must end the job with an error — not leave the others waiting: every collective has a deadline
+        kw = {"device_id": torch.device("cuda", local_rank)} if args.backend == "nccl" else {}
+        dist.init_process_group(args.backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=args.collective_timeout), **kw)
 
     prec = aa.ANH_BF16 if args.precision == "bf16" else aa.ANH_FP32
     if args.mode == "infer":

@@ -86,3 +86,18 @@ def test_inference_bench_line():
 def test_fp32_inference_entries_name_the_matrix_kernels():
     d = run_bench("--mode", "infer", "--image-side", "1024", "--steps", "1", "--warmup", "1", "--prewarm-s", "0", "--precision", "fp32", "--no-cpu-baseline")
     assert d["roofline"]["kernel"].startswith("conv_mfma_f32:fwd_L")     # the fp32 parity mode runs on v_mfma_f32_32x32x2_f32, and says so
+
+
+def test_two_rank_job_rehearsed_on_one_gpu():
+    """The N > 1 paths of bench.py as a REAL two-process job — self-launch, rank bookkeeping, the two-part gradient exchange
+    (dist.EarlyReduce), the agreed pre-warm, and in the inference child the overlap exchange and the label gather — with both ranks on
+    device 0 and gloo as the transport (RCCL wants one GPU per rank; the one-GPU test box cannot run it at world size 2)."""
+    d = run_bench("--gpus", "2", "--backend", "gloo", "--one-gpu", "--steps", "3", "--warmup", "1", "--prewarm-s", "0.3", "--no-cpu-baseline",
+                  "--infer-steps", "2", "--infer-sides", "2048")
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["devices"] == [0, 0] and d["config"]["global_batch"] == 64
+    assert d["value"] > 0 and abs(d["value"] - 64 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]      # whole-job tiles per second
+    assert d["cpu_baseline"] is None and d["scaling"] == "weak" and d["prewarm_steps"] >= 4
+    i = d["infer"]
+    assert "error" not in i, i
+    assert i["n_gpus"] == 2 and i["ranks_seen"] == 2 and i["config"]["parallelism"] == "tile-shard2" and i["config"]["exchanged_pixels"] > 0
+    assert i["value"] > 0 and i["value_labels_on_host"] > 0
