@@ -172,6 +172,8 @@ _SIGNATURES = {  # ConvDesc / OpInput are defined above
     "anh_dataset_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "anh_dataset_destroy": (None, [C.c_void_p]),
     "anh_dataset_add": (C.c_int, [C.c_void_p, _P, _P, C.c_int, C.c_int, C.POINTER(C.c_int)]),
+    "anh_dataset_remove": (C.c_int, [C.c_void_p, C.c_int]),
+    "anh_dataset_resident_bytes": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "anh_dataset_crop_batch": (C.c_int, [C.c_void_p, C.POINTER(CropSpec), C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, _P, _P]),
     "anh_trainer_step_crops": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CropSpec), C.c_int, C.c_int, C.c_double, C.c_double]),
     "anh_dnn_envelope_pack": (C.c_int, [C.c_char_p, C.c_size_t, C.c_double, _P, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),

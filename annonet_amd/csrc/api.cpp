@@ -219,7 +219,9 @@ struct anh_trainer {
 struct anh_dataset {
     int channels = 3;
     struct Item { DevBuf image, labels; int height = 0, width = 0; };
-    std::vector<Item> items;
+    std::vector<Item> items;          // a removed image leaves an empty slot (height 0) that a later add reuses
+    std::vector<int> free_slots;
+    uint64_t resident_bytes = 0;
     hipStream_t stream = nullptr;
     DevBuf d_specs, d_hist, d_first, d_table, d_bad;
     void* pinned = nullptr; size_t pinned_bytes = 0;
@@ -251,7 +253,7 @@ struct anh_dataset {
         int* h_bad = reinterpret_cast<int*>(pin + spec_bytes + 3 * tab);
         for (int i = 0; i < n; ++i) {
             const anh_crop_spec& c = specs[i];
-            ANH_REQUIRE(c.image >= 0 && (size_t)c.image < items.size(), "crop batch: image index out of range");
+            ANH_REQUIRE(c.image >= 0 && (size_t)c.image < items.size() && items[(size_t)c.image].height > 0, "crop batch: image index out of range (or removed)");
             ANH_REQUIRE(c.left > -(1L << 30) && c.left < (1L << 30) && c.top > -(1L << 30) && c.top < (1L << 30), "crop batch: rectangle out of range");
             ANH_REQUIRE(c.brightness_change >= 0, "crop batch: negative brightness change");
             const Item& it = items[(size_t)c.image];
@@ -1214,9 +1216,26 @@ int anh_dataset_add(anh_dataset* d, const uint8_t* image_hwc, const uint16_t* la
         it.height = height; it.width = width;
         HIP_CHECK(hipMemcpy(it.image.p, image_hwc, px * d->channels, hipMemcpyHostToDevice));
         HIP_CHECK(hipMemcpy(it.labels.p, labels, px * 2, hipMemcpyHostToDevice));
-        d->items.push_back(std::move(it));
-        if (index) *index = (int)d->items.size() - 1;
+        d->resident_bytes += px * d->channels + px * 2;
+        int slot;
+        if (!d->free_slots.empty()) { slot = d->free_slots.back(); d->free_slots.pop_back(); d->items[(size_t)slot] = std::move(it); }
+        else { d->items.push_back(std::move(it)); slot = (int)d->items.size() - 1; }
+        if (index) *index = slot;
     });
+}
+int anh_dataset_remove(anh_dataset* d, int index) {
+    return guarded([&] {
+        ANH_REQUIRE(d, "null dataset");
+        ANH_REQUIRE(index >= 0 && (size_t)index < d->items.size() && d->items[(size_t)index].height > 0, "dataset remove: no such image");
+        HIP_CHECK(hipStreamSynchronize(d->stream));   // the crop kernels that read the image have finished
+        anh_dataset::Item& it = d->items[(size_t)index];
+        d->resident_bytes -= (uint64_t)it.height * it.width * (d->channels + 2);
+        it.image.release(); it.labels.release(); it.height = it.width = 0;
+        d->free_slots.push_back(index);
+    });
+}
+int anh_dataset_resident_bytes(const anh_dataset* d, uint64_t* bytes) {
+    return guarded([&] { ANH_REQUIRE(d && bytes, "null argument"); *bytes = d->resident_bytes; });
 }
 int anh_dataset_crop_batch(anh_dataset* d, const anh_crop_spec* specs, int n, int dim, int classes, double class_weight, double image_weight,
                            uint8_t* images, anh_wlabel* labels) {

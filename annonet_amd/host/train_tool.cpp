@@ -13,12 +13,15 @@
 #define ANNONET_HIP_NO_DLIB
 #include "annonet_train_host.h"
 
+#include <list>
 #include <map>
+#include <unordered_set>
 
 namespace {
 
 struct TrainSettings {
     std::string directory, precision = "bf16";
+    double hbm_budget_gib = 64.0;   // full images kept resident in HBM on the device-crop path (LRU beyond it)
     double initial_downscaling = 1.0, further_downscaling = 1.0;
     bool flip_ud = false, flip_lr = false, color_offset = false, quiet_empty_labels = false, host_crops = false;
     double brightness_probability = 0.0, brightness_sigma = 0.1, noise_stddev = 0.0, class_weight = 0.5, image_weight = 0.5;
@@ -43,7 +46,7 @@ const char* usage_text() {
            "      --initial-learning-rate arg   --learning-rate-shrink-factor arg   --min-learning-rate arg   --save-interval arg\n"
            "  -t, --relative-training-length arg   --max-total-steps arg   -c, --cached-image-count arg   --data-loader-thread-count arg\n"
            "      --no-empty-label-image-warning   --primary-cuda-device arg\n"
-           "  extensions: --host-crops   --devices 0,1,...   --precision bf16|fp32   --seed arg\n";
+           "  extensions: --host-crops   --devices 0,1,...   --precision bf16|fp32   --seed arg   --hbm-image-budget-gib arg\n";
 }
 
 TrainSettings read_command_line(int argc, char** argv) {
@@ -71,6 +74,7 @@ TrainSettings read_command_line(int argc, char** argv) {
         {"--data-loader-thread-count", [&](const std::string& v) { s.loader_threads = (unsigned)std::stoul(v); }},
         {"--primary-cuda-device", [&](const std::string& v) { s.primary_device = std::stoi(v); s.has_primary_device = true; }},
         {"--precision", [&](const std::string& v) { s.precision = v; }},
+        {"--hbm-image-budget-gib", num(s.hbm_budget_gib)},
         {"--seed", [&](const std::string& v) { s.seed = std::stoull(v); s.has_seed = true; }},
         {"--devices", [&](const std::string& v) { std::stringstream list(v); std::string item; while (std::getline(list, item, ',')) s.devices.push_back(std::stoi(item)); }},
     };
@@ -240,8 +244,16 @@ int run(const TrainSettings& s) {
     std::cout << std::endl << "Now training..." << std::endl;
 
     CropFeeder feeder(s, files, classes, crop_side, device_crops);
-    NetPimpl::Dataset hbm_images;                                    // device path: full images, uploaded once each
-    std::unordered_map<std::string, int> hbm_index;
+    // device path: full images uploaded on first sight and kept in HBM — within a byte budget (--hbm-image-budget-gib): the least
+    // recently drawn image leaves when a new one would not fit, as the decoded images leave the reference's LRU cache
+    // (--cached-image-count, annonet_train_main.cpp:301,504-518); an image of the mini-batch being assembled is never the one to go
+    NetPimpl::Dataset hbm_images;
+    struct Resident { int index; uint64_t bytes; std::list<std::string>::iterator at; };
+    std::unordered_map<std::string, Resident> hbm_index;
+    std::list<std::string> hbm_lru;                                  // front = most recently drawn
+    std::unordered_set<std::string> batch_keys;
+    const uint64_t hbm_budget = (uint64_t)(std::max(0.0, s.hbm_budget_gib) * 1024.0 * 1024.0 * 1024.0);
+    size_t hbm_evictions = 0;
     std::set<std::string> warned;
     std::vector<NetPimpl::input_type> images;
     std::vector<NetPimpl::training_label_type> labels;
@@ -250,7 +262,7 @@ int run(const TrainSettings& s) {
     const double total_downscaling = s.initial_downscaling * s.further_downscaling;
     try {
         while (trainer.GetLearningRate() >= s.min_learning_rate && !(s.has_max_steps && step >= s.max_steps)) {   // :569-577,583
-            images.clear(); labels.clear(); specs.clear();
+            images.clear(); labels.clear(); specs.clear(); batch_keys.clear();
             while ((device_crops ? specs.size() : images.size()) < s.minibatch) {
                 FeedItem item = feeder.next();
                 if (!item.made.error.empty()) throw std::runtime_error(item.made.error);
@@ -261,8 +273,22 @@ int run(const TrainSettings& s) {
                 if (item.made.is_spec) {
                     const std::string& key = item.full->image_filenames.image_filename;
                     auto at = hbm_index.find(key);
-                    if (at == hbm_index.end()) at = hbm_index.emplace(key, hbm_images.Add(item.full->input_image, item.full->label_image)).first;
-                    item.made.spec.image = at->second;
+                    if (at == hbm_index.end()) {
+                        const uint64_t bytes = (uint64_t)item.full->input_image.nr() * item.full->input_image.nc() * (sizeof(*item.full->input_image.begin()) + 2);
+                        while (hbm_images.ResidentBytes() + bytes > hbm_budget) {   // make room: least recently drawn first, never one of this mini-batch
+                            auto victim = hbm_lru.end();
+                            while (victim != hbm_lru.begin()) { --victim; if (!batch_keys.count(*victim)) break; }
+                            if (victim == hbm_lru.end() || batch_keys.count(*victim)) break;   // everything resident belongs to this mini-batch
+                            hbm_images.Remove(hbm_index.at(*victim).index);
+                            hbm_index.erase(*victim);
+                            hbm_lru.erase(victim);
+                            ++hbm_evictions;
+                        }
+                        hbm_lru.push_front(key);
+                        at = hbm_index.emplace(key, Resident{hbm_images.Add(item.full->input_image, item.full->label_image), bytes, hbm_lru.begin()}).first;
+                    } else hbm_lru.splice(hbm_lru.begin(), hbm_lru, at->second.at);
+                    batch_keys.insert(key);
+                    item.made.spec.image = at->second.index;
                     specs.push_back(item.made.spec);
                 } else {
                     images.push_back(std::move(item.made.input_image));
@@ -280,7 +306,7 @@ int run(const TrainSettings& s) {
     }
     feeder.stop();
     save_inference_net(trainer, classes_json, total_downscaling);
-    std::cout << "steps: " << step << ", " << feeder.statistics(hbm_index.size()) << std::endl;
+    std::cout << "steps: " << step << ", " << feeder.statistics(hbm_index.size()) << ", HBM evictions: " << hbm_evictions << std::endl;
     return 0;
 }
 

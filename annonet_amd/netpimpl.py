@@ -145,6 +145,15 @@ class Dataset:
         check(self.L.anh_dataset_add(self.h, _ptr(img), _ptr(lab), lab.shape[0], lab.shape[1], C.byref(idx)))
         return idx.value
 
+    def remove(self, index):
+        """frees that image's HBM; its index is handed out again by a later add()"""
+        check(self.L.anh_dataset_remove(self.h, int(index)))
+
+    def resident_bytes(self):
+        n = C.c_uint64()
+        check(self.L.anh_dataset_resident_bytes(self.h, C.byref(n)))
+        return int(n.value)
+
     @staticmethod
     def _specs(specs):
         arr = (_lib.CropSpec * len(specs))()

@@ -171,6 +171,8 @@ class Dataset {
                               (int)image.nr(), (int)image.nc(), &index));
         return index;
     }
+    void Remove(int index) { check(anh_dataset_remove(h_, index)); }   // frees that image's HBM; the index is reused by a later Add
+    uint64_t ResidentBytes() const { uint64_t n = 0; check(anh_dataset_resident_bytes(h_, &n)); return n; }
     anh_dataset* handle() const { return h_; }
 
   private:

@@ -278,6 +278,11 @@ int anh_dataset_create(int channels, anh_dataset** out);
 void anh_dataset_destroy(anh_dataset* d);
 /* uploads one full image (u8, HWC, `channels` interleaved) and its label image (u16) and keeps them resident; *index = its number */
 int anh_dataset_add(anh_dataset* d, const uint8_t* image_hwc, const uint16_t* labels, int height, int width, int* index);
+/* frees the image with that index (after the crops in flight that read it): the index becomes invalid (a crop spec naming it is
+   ANH_ERR_INVALID) and is handed out again by a later anh_dataset_add.  With anh_dataset_resident_bytes a host bounds the HBM the
+   resident set may take (the reference bounds its decoded images by --cached-image-count, annonet_train_main.cpp:301,504-518). */
+int anh_dataset_remove(anh_dataset* d, int index);
+int anh_dataset_resident_bytes(const anh_dataset* d, uint64_t* bytes);
 /* n crops of dim x dim into host arrays: images n*dim*dim*channels u8, weighted labels n*dim*dim (tests, non-resident hosts) */
 int anh_dataset_crop_batch(anh_dataset* d, const anh_crop_spec* specs, int n, int dim, int classes, double class_weight, double image_weight,
                            uint8_t* images, anh_wlabel* labels);

@@ -95,6 +95,22 @@ int main() {
     annonet_infer(net, image, result, temp, {}, {}, small);
     REQUIRE(result.nr() == 150 && result.nc() == 170);
     for (auto v : result) REQUIRE(v < 3);
+    {   // blended_output (annonet_infer.h:31): stays in HBM unless asked for (or defaulted on: ANNONET_HIP_KEEP_BLENDED_OUTPUT / ANH_KEEP_BLENDED_OUTPUT);
+        // when it comes back, the label map is its argmax with the reference's tie rule (annonet_infer.cpp:170-185)
+        REQUIRE(temp.keep_blended_output == annonet_hip_keep_blended_default());
+        annonet_infer_temp keeping;
+        keeping.keep_blended_output = true;
+        dlib::matrix<uint16_t> again;
+        annonet_infer(net, image, again, keeping, {}, {}, small);
+        REQUIRE(keeping.blended_output.size() == 3 && keeping.blended_output[0].nr() == 150 && keeping.blended_output[0].nc() == 170);
+        for (long r = 0; r < 150; ++r)
+            for (long c = 0; c < 170; ++c) {
+                REQUIRE(again(r, c) == result(r, c));
+                uint16_t best = 0;
+                for (uint16_t k = 1; k < 3; ++k) if (keeping.blended_output[k](r, c) > keeping.blended_output[best](r, c)) best = k;
+                REQUIRE(best == result(r, c));
+            }
+    }
     bool threw = false;
     try { NetPimpl::input_type bad; bad.set_size(24, 24); net.Forward(bad); } catch (const std::exception&) { threw = true; }
     REQUIRE(threw);

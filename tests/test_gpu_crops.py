@@ -126,3 +126,22 @@ def test_training_on_device_crops_equals_training_on_host_crops():
     pb, rb = b.get_params()
     np.testing.assert_array_equal(pa, pb)
     np.testing.assert_array_equal(ra, rb)
+
+
+def test_dataset_remove_frees_the_image_and_reuses_its_index():
+    rng = np.random.default_rng(4)
+    ds = aa.Dataset(3)
+    imgs = [rng.integers(0, 256, (40 + 10 * i, 50, 3), dtype=np.uint8) for i in range(3)]
+    labs = [rng.integers(0, 3, im.shape[:2]).astype(np.uint16) for im in imgs]
+    idx = [ds.add(im, lb) for im, lb in zip(imgs, labs)]
+    assert idx == [0, 1, 2] and ds.resident_bytes() == sum(im.shape[0] * im.shape[1] * 5 for im in imgs)
+    ds.remove(1)
+    assert ds.resident_bytes() == sum(imgs[i].shape[0] * imgs[i].shape[1] * 5 for i in (0, 2))
+    with pytest.raises(aa.AnnonetHipError, match="removed"):
+        ds.crop_batch([(1, 0, 0, 0, 0, 1.0)], 35, 3, 0.5, 0.5)
+    with pytest.raises(aa.AnnonetHipError, match="no such image"):
+        ds.remove(1)
+    again = ds.add(imgs[1], labs[1])
+    assert again == 1                                     # the freed slot is handed out again
+    got_img, _, _ = ds.crop_batch([(1, 3, 2, 0, 0, 1.0)], 35, 3, 0.5, 0.5)
+    np.testing.assert_array_equal(got_img[0], imgs[1][2:37, 3:38])

@@ -53,7 +53,7 @@ def test_train_main_device_crops_then_infer(tmp_path, dataset):
                  "images in dataset: 3", "Mini-batches are cut on the device from HBM-resident full images", "Now training...", "saving network"):
         assert line in out, line
     assert "Warning: no anno_classes.json file found" in out and "Using the default anno classes" in out
-    m = re.search(r"steps: 6, full images decoded: (\d+), cache hits: (\d+), evictions: (\d+), images resident in HBM: 3", out)
+    m = re.search(r"steps: 6, full images decoded: (\d+), cache hits: (\d+), evictions: (\d+), images resident in HBM: 3, HBM evictions: 0", out)
     assert m and int(m.group(1)) >= 3 and int(m.group(3)) >= 1          # 3 images through a 2-entry cache: evictions happened
     assert out.count("saving network") == 3                              # steps 0 and 4 (save interval) + the final save (:611-613,634-636)
     classes_json, factor, blob = aa.dnn_envelope_unpack((tmp_path / "annonet.dnn").read_bytes())
@@ -62,6 +62,15 @@ def test_train_main_device_crops_then_infer(tmp_path, dataset):
     assert net.cfg.classes == 3 and net.cfg.levels == 2
     r = subprocess.run([INFER, str(dataset), "--dnn", str(tmp_path / "annonet.dnn"), "-w", "128", "-h", "128"], capture_output=True, text=True, timeout=600, cwd=tmp_path)
     assert r.returncode == 0 and "downscaling factor = 1.5" in r.stdout and "Confusion matrix per pixel:" in r.stdout
+
+
+def test_train_main_bounds_the_hbm_resident_images(tmp_path, dataset):
+    """--hbm-image-budget-gib: the full images kept in HBM for the device-crop path are an LRU set within a byte budget (the
+    reference bounds its decoded images by --cached-image-count): 3 images of ~100-170 KB under a 0.0002 GiB (~215 KB) budget."""
+    r = train(tmp_path, dataset, "--hbm-image-budget-gib", "0.0002", steps=8)
+    assert r.returncode == 0, r.stdout + r.stderr
+    m = re.search(r"images resident in HBM: (\d+), HBM evictions: (\d+)", r.stdout)
+    assert m and int(m.group(2)) >= 1, r.stdout[-400:]     # (the images of ONE mini-batch may all have to be resident together: no bound on group 1 here)
 
 
 def test_train_main_host_crops_learn_and_resume(tmp_path, dataset):
