@@ -995,11 +995,14 @@ struct GeoS1 {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) b.x[kx][ks] = swz_addr(lds_x, wave * 2 * PW + col + kx, (col + kx) >> 2, ks, half);
     }
+    // The two output rows of a wave and the three filter rows touch patch rows 0..3: for each (kx, k-step) those four pixel
+    // fragments are read ONCE and reused by the three ky (10 LDS reads per 12 MFMAs at NT = 2, instead of 12).
+    // (Round 3: a hand-pinned two-register-set form of this nest — all ten fragments of step i + 1 requested behind the second MFMA of
+    // step i — shortens the instrumented MFMA phase by 17 % (27 -> 22.7 us on the 64->64 forward) and leaves the step where it was:
+    // 1.741 vs 1.738 ms for this plain nest, same box.  What did pay is registers: see HAS_FWD_FORM in launch_ws.)
     template <int NT>
     __device__ static void mfma(f32x16 (&acc)[ACC][NT], const Bases& b, const char* (&wb)[2]) {
         constexpr int C_OUT = NT * 32;
-        // The two output rows of a wave and the three filter rows touch patch rows 0..3: for each (kx, k-step) those four
-        // pixel fragments are read ONCE and reused by the three ky (10 LDS reads per 12 MFMAs at NT = 2, instead of 12).
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
 #pragma unroll
@@ -1699,7 +1702,11 @@ void launch_ws(const ConvArgs& a, int tiles_x, int tiles_y, int flip, hipStream_
         HIP_CHECK(hipGetLastError());
         return;
     }
-    constexpr bool HAS_FWD_FORM = G::ACC * NT > 4;
+    // (Round 3: EVERY geometry has one.  A training forward that runs the general form carries the registers of the backward epilogues
+    // (old values, y operands: 64 VGPRs at two accumulator groups x two channel tiles) through its MFMA phase, where hipcc then keeps
+    // three operand register sets and waits behind every LDS read; in the forward-only form the same nest is scheduled with seven.
+    // Same-box A/B: 1.757 -> 1.738 ms per step; the skip-add 64->64 forward 72.7 -> 63.1 us.)
+    constexpr bool HAS_FWD_FORM = true;
     const bool fwd_form = HAS_FWD_FORM && (a.stat_partials || a.stat_acc) && !a.bnred_partials && !a.bnred_acc && !a.out_accumulate && !a.out2;
     if constexpr (HAS_FWD_FORM) {
         if (fwd_form) {
