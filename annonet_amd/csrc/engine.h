@@ -138,6 +138,7 @@ class Engine {
     // sums of every layer are added to accumulator tables by the kernels that see the values and folded by their consumers, so the
     // 18 finalize launches of a step disappear from the critical stream.
     bool tables = false, fold_pending = false;
+    bool tables_clean = false;   // the update kernel of the previous step cleared the tables (Engine::apply_update)
     DevBuf bn_acc;
     size_t bn_acc_bytes = 0;
     BnFoldJobs fold_jobs;

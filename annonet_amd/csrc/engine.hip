@@ -412,7 +412,9 @@ bool Engine::choose_table_mode(const Src& image) {
     // the head reads its input layers through arrays unless it is the fused kernel (which folds tables itself): both are fine
     size_t words = 0;
     for (int li = 0; li + 1 < nl; ++li) words += bnacc_words(spec.layers[li].cout);
+    const void* had = bn_acc.p;
     bn_acc.reserve(words * sizeof(long long));
+    if (bn_acc.p != had) tables_clean = false;
     bn_acc_bytes = words * sizeof(long long);
     words = 0;
     for (int li = 0; li + 1 < nl; ++li) { ls[li].acc = bn_acc.as<long long>() + words; words += bnacc_words(spec.layers[li].cout); }
@@ -569,9 +571,12 @@ void Engine::forward_training(const Src& image, int n, int h, int w) {
     ANH_REQUIRE(training, "not a training net");
     plan_dims(n, h, w);
     if (choose_table_mode(image)) {
-        const int tok = prof.begin(stream, "bn_tables_zero", 0, (double)bn_acc_bytes);
-        HIP_CHECK(hipMemsetAsync(bn_acc.p, 0, bn_acc_bytes, stream));
-        prof.end(stream, tok);
+        if (!tables_clean) {   // first step, or a pass that no update followed: clear the tables here
+            const int tok = prof.begin(stream, "bn_tables_zero", 0, (double)bn_acc_bytes);
+            HIP_CHECK(hipMemsetAsync(bn_acc.p, 0, bn_acc_bytes, stream));
+            prof.end(stream, tok);
+        }
+        tables_clean = false;
     }
     const bool fused_head = head_is_fused();
     const size_t n_bn = spec.layers.size() - 1;
@@ -798,6 +803,7 @@ void Engine::apply_update(double lr, double weight_decay, double momentum_coef, 
     a.w_tm_f32 = w_tm_f32.as<float>(); a.w_km_f32 = w_km_f32.as<float>();
     a.w_tm_bf16 = w_tm_bf16.p; a.w_km_bf16 = w_km_bf16.p;
     a.lr = lr; a.weight_decay = weight_decay; a.momentum_coef = momentum_coef; a.grad_scale = grad_scale; a.apply = 1;
+    if (tables && bn_acc.p && bn_acc_bytes % 16 == 0) { a.zero = bn_acc.p; a.zero_words16 = (int64_t)(bn_acc_bytes / 16); tables_clean = true; }
     const int tok = prof.begin(stream, "sgd_momentum_wd", 0, (double)spec.n_params * 28);
     launch_sgd(a, stream);
     prof.end(stream, tok);

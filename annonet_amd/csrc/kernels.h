@@ -187,6 +187,9 @@ struct SgdArgs {
     void* w_tm_bf16 = nullptr; void* w_km_bf16 = nullptr;
     double lr = 0, weight_decay = 0, momentum_coef = 0, grad_scale = 1;
     int apply = 1;  // 0: only refresh the compute-layout copies from master (after set_params)
+    // table mode: the update is the last kernel of a step, and the bn accumulator tables are dead by then — it also clears them for
+    // the next step (16-byte words), so the next forward starts without a fill on its critical path
+    void* zero = nullptr; int64_t zero_words16 = 0;
 };
 void launch_sgd(const SgdArgs& a, hipStream_t s);
 // canonical <-> tap-major conversion of a whole blob (get_grads, tests)
