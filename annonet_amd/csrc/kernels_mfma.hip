@@ -1145,7 +1145,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
 #ifdef ANH_WS_PROFILE
     long long t_a = 0, t_b = 0, t_c = 0, t0_;
     const long long t_entry = wall_clock64();   // absolute (the counter is chip-wide): launch skew, prologue and tail of the kernel
-    long long t_loop = 0, t_loop_end = 0;
+    long long t_loop = 0, t_loop_end = 0, c_loop = 0;   // c_loop: shader cycles (s_memtime) over the producers' loop -> the clock the kernel holds
 #define TICK() (t0_ = wall_clock64())
 #define TOCK(acc_) (acc_ += wall_clock64() - t0_)
 #else
@@ -1415,6 +1415,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
         };
 #ifdef ANH_WS_PROFILE
         t_loop = wall_clock64();
+        c_loop = clock64();
 #endif
         while (tile < n_tiles) {
             one_item(R0);
@@ -1425,6 +1426,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
         }
 #ifdef ANH_WS_PROFILE
         t_loop_end = wall_clock64();
+        c_loop = clock64() - c_loop;
 #endif
         if constexpr (PS) {
             if (ps) {   // the last two items: the one before the last is ready, the last one after the consumers' closing barrier
@@ -1609,7 +1611,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
 #ifdef ANH_WS_PROFILE
     if (prof && lane == 0) {
         long long* o = prof + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (producer ? 4 : 0) + wave) * 8;
-        o[0] = t_a; o[1] = t_b; o[2] = t_c; o[3] = it; o[4] = t_entry; o[5] = t_loop; o[6] = t_loop_end; o[7] = wall_clock64();
+        o[0] = t_a; o[1] = t_b; o[2] = t_c; o[3] = producer ? c_loop : it; o[4] = t_entry; o[5] = t_loop; o[6] = t_loop_end; o[7] = wall_clock64();
     }
 #endif
 #undef TICK
@@ -1670,7 +1672,7 @@ void launch_ws(const ConvArgs& a, int tiles_x, int tiles_y, int flip, hipStream_
             HIP_CHECK(hipMemcpy(h.data(), prof, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
             double pa = 0, pb = 0, pc = 0, ca = 0, cb = 0, cc = 0, items = 0;
             long long first_entry = h[4], last_exit = h[7];
-            double entry = 0, pro = 0, loop = 0, tail = 0;   // over the consumer waves: entry skew, entry -> loop, loop, loop end -> exit
+            double entry = 0, pro = 0, loop = 0, tail = 0, cycles = 0;   // over the producer waves: entry skew, entry -> loop, loop, loop end -> exit; shader cycles of the loop
             for (int w = 0; w < nwg; ++w) {
                 for (int v = 0; v < 8; ++v) { first_entry = std::min(first_entry, h[(w * 8 + v) * 8 + 4]); last_exit = std::max(last_exit, h[(w * 8 + v) * 8 + 7]); }
                 for (int v = 0; v < 4; ++v) { ca += h[(w * 8 + v) * 8]; cb += h[(w * 8 + v) * 8 + 1]; cc += h[(w * 8 + v) * 8 + 2]; }
@@ -1681,12 +1683,13 @@ void launch_ws(const ConvArgs& a, int tiles_x, int tiles_y, int flip, hipStream_
                 for (int v = 4; v < 8; ++v) {   // producer waves carry the loop stamps
                     const long long* o = &h[(w * 8 + v) * 8];
                     entry += (double)(o[4] - first_entry); pro += (double)(o[5] - o[4]); loop += (double)(o[6] - o[5]); tail += (double)(o[7] - o[6]);
+                    cycles += (double)o[3];
                 }
             const double k = 1.0 / (4.0 * nwg) / 100.0;  // wall clock = 100 MHz -> us per wave
             fprintf(stderr, "[ws prof] geo_recs=%d NT=%d kind=%d c_red=%d wgs=%d items/wg=%.1f | producer us: commit %.1f fetch %.1f barrier %.1f | consumer us: mfma %.1f store %.1f barrier %.1f"
-                            " | kernel %.1f us = launch skew %.1f + prologue %.1f + loop %.1f + tail %.1f (+ drain to the last wave)\n",
+                            " | kernel %.1f us = launch skew %.1f + prologue %.1f + loop %.1f + tail %.1f (+ drain to the last wave) | clock in the loop %.0f MHz\n",
                     G::RECS, NT, a.src.kind, a.c_red, nwg, items / nwg, pa * k, pb * k, pc * k, ca * k, cb * k, cc * k,
-                    (double)(last_exit - first_entry) / 100.0, entry * k, pro * k, loop * k, tail * k);
+                    (double)(last_exit - first_entry) / 100.0, entry * k, pro * k, loop * k, tail * k, loop > 0 ? cycles / loop * 100.0 : 0.0);
         }
 #endif
     };
