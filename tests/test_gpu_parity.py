@@ -506,3 +506,33 @@ def test_early_reduce_overlaps_the_all_reduce_and_changes_nothing():
         dist.destroy_process_group()
     np.testing.assert_array_equal(params[0][0], params[1][0])
     np.testing.assert_array_equal(params[0][1], params[1][1])
+
+
+def test_single_tile_whose_layer_planes_exceed_2_31_elements():
+    """One 8195 x 8195 tile through the benchmark net: the 32-channel tensors at full resolution hold 8195^2 x 32 = 2.15e9 elements,
+    past the 32-bit element offsets of the persistent conv kernels, so those layers take the one-tile-per-workgroup kernels with
+    64-bit indexing (and the net the raw-output storage form).  Checked where it can be: against the bf16-restating oracle on crops
+    deep inside the image — at the far corner too, where the element offsets are largest — and through finiteness / label range."""
+    o, net = pair(2, 3, 3, 1.0, 1, aa.ANH_BF16, seed=17)
+    side = 8195
+    assert o.recommended_input_dim(side) == side and side * side * 32 >= 2 ** 31
+    rng = np.random.default_rng(21)
+    img = rng.integers(0, 256, (side, side, 3), dtype=np.uint8)
+    labels, blended = aa.annonet_infer(net, img, want_blended=True)        # no tiling parameters: ONE tile
+    assert not net.stores_activations()                                    # the persistent kernels do not cover every layer here
+    assert labels.max() < 3 and np.isfinite(blended[:, ::97, ::89]).all()
+    o.set_bf16_emulation(2)
+    ov = o.required_input_dim()
+    d = o.recommended_input_dim(2 * ov + 41)
+    worst_mismatch = 0.0
+    for top, left in ((4096, 4000), (side - d - 4 - (side - d - 4) % 4, side - d - 8 - (side - d - 8) % 4), (8, 7000)):
+        top -= top % 4; left -= left % 4                                  # the stride-2 grid phase of the whole-image window (origin 0)
+        want = o.forward(img[top:top + d, left:left + d][None])[0]
+        m = ov
+        got = blended[:, top + m:top + d - m, left + m:left + d - m]
+        ref = want[:, m:d - m, m:d - m]
+        span = want.max() - want.min()
+        assert np.abs(got - ref).max() <= 6e-3 * span, (top, left, float(np.abs(got - ref).max()), float(span))
+        assert np.abs(got - ref).mean() <= 3e-4 * span
+        worst_mismatch = max(worst_mismatch, float((labels[top + m:top + d - m, left + m:left + d - m] != ref.argmax(0)).mean()))
+    assert worst_mismatch <= 0.01
