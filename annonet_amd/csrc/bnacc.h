@@ -11,8 +11,9 @@
 // Same-address atomics serialise at the memory side (measured: 256 workgroups adding 256 words each into ONE table cost a conv
 // kernel 3-6 us of tail, 1024 workgroups 30 us), so a table is kept as kBnAccReplicas copies; an adder picks the copy by its
 // workgroup index and a fold adds the copies up (integers: any order gives the same total).
-// A partial that is not finite, or too large for hi, raises the table's poison word: every fold of that table then yields NaN
-// (what the floating-point path would have produced), never a silently wrong finite value.
+// A partial that is not finite, or too large for hi, raises the table's poison word: every fold of that table then yields NaN — a
+// diverged net shows as NaN parameters, never as finite numbers formed from a wrapped or truncated sum.  (The floating-point
+// finalize kernels turn an infinite sum of squares into invstd = 0 and carry on with finite values; NaN partials give NaN there too.)
 #pragma once
 #include <hip/hip_runtime.h>
 

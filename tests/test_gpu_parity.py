@@ -536,3 +536,25 @@ def test_single_tile_whose_layer_planes_exceed_2_31_elements():
         assert np.abs(got - ref).mean() <= 3e-4 * span
         worst_mismatch = max(worst_mismatch, float((labels[top + m:top + d - m, left + m:left + d - m] != ref.argmax(0)).mean()))
     assert worst_mismatch <= 0.01
+
+
+def test_non_finite_bn_sums_poison_the_table_instead_of_passing_as_numbers():
+    """The bn accumulator tables hold integers (bnacc.h): a workgroup partial that is not finite, or too large for the fixed-point
+    range, cannot be added — it raises the table's poison word and every fold of that table yields NaN: a diverged net shows as NaN
+    parameters after the step (the loss itself clamps its probabilities and stays finite), never as finite numbers formed from a
+    wrapped or truncated sum.  A stem filter blown up to 1e30 overflows the stem's sum of squares."""
+    o, t = trainer_pair(2, 3, 3, 1.0, 1, aa.ANH_BF16, lr=0.05)
+    p, r = t.get_params()
+    L0 = o.layers[0]
+    p = p.copy()
+    p[L0.w_off:L0.w_off + 16] = 1e30
+    t.set_params(p, r)
+    rng = np.random.default_rng(3)
+    d = 43
+    img = rng.integers(1, 256, (2, d, d, 3), dtype=np.uint8)
+    lab = rng.integers(0, 3, (2, d, d)).astype(np.uint16)
+    t.StartTraining(list(img), [aa.set_weights(l, 0.5, 0.5) for l in lab])
+    t.synchronize()
+    after, _ = t.get_params()
+    L1 = o.layers[1]
+    assert np.isnan(after[L1.w_off:L1.w_off + 64]).all()      # the next layer's filters saw a NaN input through the poisoned fold
