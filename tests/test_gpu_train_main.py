@@ -67,10 +67,14 @@ def test_train_main_device_crops_then_infer(tmp_path, dataset):
 def test_train_main_bounds_the_hbm_resident_images(tmp_path, dataset):
     """--hbm-image-budget-gib: the full images kept in HBM for the device-crop path are an LRU set within a byte budget (the
     reference bounds its decoded images by --cached-image-count): 3 images of ~100-170 KB under a 0.0002 GiB (~215 KB) budget."""
-    r = train(tmp_path, dataset, "--hbm-image-budget-gib", "0.0002", steps=8)
+    # mini-batches of ONE crop: an image of the mini-batch being assembled is never evicted, so with larger batches all three images
+    # may have to be resident together; 14 single-crop steps draw at least two different images
+    r = subprocess.run([TRAIN, str(dataset), "-b", "1", "--net-width-scaler", "0.25", "--net-width-min-filter-count", "4", "--input-dimension-multiplier", "1.2",
+                        "--max-total-steps", "14", "--save-interval", "100", "--data-loader-thread-count", "2", "--cached-image-count", "2", "--seed", "5",
+                        "--hbm-image-budget-gib", "0.0002"], capture_output=True, text=True, timeout=900, cwd=tmp_path)
     assert r.returncode == 0, r.stdout + r.stderr
     m = re.search(r"images resident in HBM: (\d+), HBM evictions: (\d+)", r.stdout)
-    assert m and int(m.group(2)) >= 1, r.stdout[-400:]     # (the images of ONE mini-batch may all have to be resident together: no bound on group 1 here)
+    assert m and int(m.group(1)) <= 2 and int(m.group(2)) >= 1, r.stdout[-400:]
 
 
 def test_train_main_host_crops_learn_and_resume(tmp_path, dataset):
