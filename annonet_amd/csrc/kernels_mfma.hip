@@ -892,18 +892,37 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_ws_kernel(WgParams a, int til
                 *reinterpret_cast<uint4*>(lbuf + tdst0 + ((jj / JPN) * TILE_PIX + 2 * (jj % JPN) * 32) * 64) = v;
             }
         };
+        // Skip-add patches (two inputs per chunk) and the 128-tile-channel forms keep ONE set.  With two, those forms hold 195-232
+        // VGPRs, and what this kernel's waves leave of a SIMD's register file decides how many waves of the bn backward apply pass —
+        // which runs beside this kernel on the other stream and IS on the step's critical path — fit next to them: none beside 232,
+        // one 82-VGPR wave beside 195, two beside <= 168.  Same-box A/B: 1.7405 -> 1.7217 ms per step; this
+        // kernel's own time does not change (it is not what the step waits for).  ANH_WGRAD_LEAN (build flag): 0 two sets everywhere,
+        // 1 skip-add forms lean, 2 every form lean, 3 (default) skip-add and 128-channel forms.
+#ifndef ANH_WGRAD_LEAN
+#define ANH_WGRAD_LEAN 3
+#endif
+        constexpr bool ONE_SET = ANH_WGRAD_LEAN == 2 || (ANH_WGRAD_LEAN == 1 && KP == SRC_ACT2) || (ANH_WGRAD_LEAN == 3 && (KP == SRC_ACT2 || NTC == 4));
         if (tile < total_tiles) fetch(ra, tile);
-        if (tile + splits < total_tiles) fetch(rb, tile + splits);
-        while (tile < total_tiles) {   // unrolled by two so that the register sets are addressed statically
-            commit(ra, smem);
-            if (tile + 2 * splits < total_tiles) fetch(ra, tile + 2 * splits);
-            __syncthreads();  // buffer 0 is full; the consumers are done with buffer 1
-            tile += splits;
-            if (tile >= total_tiles) break;
-            commit(rb, smem + BUF_BYTES);
-            if (tile + 2 * splits < total_tiles) fetch(rb, tile + 2 * splits);
-            __syncthreads();
-            tile += splits;
+        if constexpr (ONE_SET) {
+            while (tile < total_tiles) {
+                commit(ra, smem + (it & 1) * BUF_BYTES);
+                if (tile + splits < total_tiles) fetch(ra, tile + splits);
+                __syncthreads();  // buffer it & 1 is full; the consumers are done with the other one
+                tile += splits; ++it;
+            }
+        } else {
+            if (tile + splits < total_tiles) fetch(rb, tile + splits);
+            while (tile < total_tiles) {   // unrolled by two so that the register sets are addressed statically
+                commit(ra, smem);
+                if (tile + 2 * splits < total_tiles) fetch(ra, tile + 2 * splits);
+                __syncthreads();  // buffer 0 is full; the consumers are done with buffer 1
+                tile += splits;
+                if (tile >= total_tiles) break;
+                commit(rb, smem + BUF_BYTES);
+                if (tile + 2 * splits < total_tiles) fetch(rb, tile + 2 * splits);
+                __syncthreads();
+                tile += splits;
+            }
         }
     } else {
         const int nt_mine = wave % NTC;
@@ -1919,11 +1938,14 @@ WgPlan wgrad_plan_mfma(const WgradArgs& a) {
     p.cont = a.gather == 1;
     static const int ws_on = getenv("ANH_WGRAD_WS") ? atoi(getenv("ANH_WGRAD_WS")) : 1;
     p.ws = ws_on != 0;
-    const int ntc_ = std::min((p.cont ? a.c_in : a.c_out) / 32, 4);
+    // tile channels per workgroup: 128 (ntc 4) leaves a consumer wave nine accumulator tiles (216-232 VGPRs: no wave of another kernel
+    // fits beside the workgroup); 64 (ntc 2) runs 128 channels as two workgroup groups — ANH_WGRAD_NTC_MAX
+    static const int ntc_max = getenv("ANH_WGRAD_NTC_MAX") ? std::max(1, std::min(4, atoi(getenv("ANH_WGRAD_NTC_MAX")))) : 4;
+    const int ntc_ = std::min((p.cont ? a.c_in : a.c_out) / 32, ntc_max == 3 ? 2 : ntc_max);
     const int th = a.stride == 1 ? ((p.ws && ntc_ == 4) ? 4 : 8) : 4;
     const int lr_h = p.cont ? a.h_in : a.h_out, lr_w = p.cont ? a.w_in : a.w_out;   // the low-res (tile) tensor
     const int c_tile = p.cont ? a.c_in : a.c_out, c_patch = p.cont ? a.c_out : a.c_in;
-    p.ntc = std::min(c_tile / 32, 4);
+    p.ntc = ntc_;
     p.zgroups = c_tile / (p.ntc * 32);   // 256 tile channels: two groups of 128 (warp-specialised kernel only)
     p.slabs = c_patch / 32;
     p.tiles_x = (lr_w + 31) / 32;
