@@ -1188,6 +1188,19 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_head_kernel(const float* g, 
 }
 
 
+// value of another lane of the same quad (DPP quad_perm: a VALU modifier, no LDS crossbar)
+template <int CTRL> __device__ __forceinline__ float quad_perm(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float quad_bcast(float v, int k) {   // k: a constant after unrolling
+    switch (k) {
+        case 0: return quad_perm<0x00>(v);
+        case 1: return quad_perm<0x55>(v);
+        case 2: return quad_perm<0xAA>(v);
+        default: return quad_perm<0xFF>(v);
+    }
+}
+
 struct HeadArgs {
     Src src;                       // SRC_ACT or SRC_ACT2, 32 channels
     const float* w_tm;             // [ci][k]   (tap-major with one tap), bf16-rounded values in bf16 mode
@@ -1256,10 +1269,9 @@ __global__ __launch_bounds__(256, 2) void head_train_kernel(HeadArgs a, BnFoldJo
     float sg[8], sb2[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) { sg[c] = 0.f; sb2[c] = 0.f; }
-    float dw[8][KM], db[KM];
+    float dw[8][KM], db_mine = 0.f;   // db of class `sub`
 #pragma unroll
     for (int k = 0; k < KM; ++k) {
-        db[k] = 0.f;
 #pragma unroll
         for (int c = 0; c < 8; ++c) dw[c][k] = 0.f;
     }
@@ -1301,33 +1313,39 @@ __global__ __launch_bounds__(256, 2) void head_train_kernel(HeadArgs a, BnFoldJo
             float acc = 0.f;
 #pragma unroll
             for (int c = 0; c < 8; ++c) acc = fmaf(x[c], w[c][k], acc);
-            acc += __shfl_xor(acc, 1, 64);
-            acc += __shfl_xor(acc, 2, 64);
+            acc += quad_perm<0xB1>(acc);   // lane ^ 1
+            acc += quad_perm<0x4E>(acc);   // lane ^ 2
             z[k] = acc + bias[k];
         }
-        if (sub == 0) {
+        // From here lane `sub` of the pixel's four owns class `sub`: one exp, one division and one 4-byte store per lane instead of
+        // all K on every lane; what every lane needs comes back with quad broadcasts.  Same expressions in the same order as the
+        // plain form (sum over k ascending, e / sum), and no branch: a pixel without a label takes the selects' zero side.
+        float z_mine = z[0];
 #pragma unroll
-            for (int k = 0; k < KM; ++k) if (k < K) a.logits[(size_t)p * K + k] = z[k];
-        }
+        for (int k = 1; k < KM; ++k) z_mine = sub == k ? z[k] : z_mine;
+        const bool mine = sub < K;
+        if (mine) a.logits[(size_t)p * K + sub] = z_mine;
         const uint16_t y = r.y;
+        const bool valid = y != ANH_LABEL_IGNORE && y < K;
+        if (!valid && y != ANH_LABEL_IGNORE && a.error_flag) *a.error_flag = 1;
+        float m = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < KM; ++k) if (k < K) m = fmaxf(m, z[k]);
+        const float e_mine = mine ? expf(z_mine - m) : 0.f;
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < KM; ++k) sum += quad_bcast(e_mine, k);
+        const float pk_mine = e_mine / sum;
+        const float sw = (float)a.scale * r.wgt;
+        const bool is_y = sub == (int)y;
+        const float g_mine = (valid && mine) ? (is_y ? sw * (pk_mine - 1.f) : sw * pk_mine) : 0.f;
+        float py = (valid && is_y) ? pk_mine : 0.f;   // one lane of the four holds p[y]; x + 0 is exact
+        py += quad_perm<0xB1>(py);
+        py += quad_perm<0x4E>(py);
+        if (valid && sub == 0) loss += sw * (-logf(fmaxf(py, 1e-10f)));
         float g[KM];
 #pragma unroll
-        for (int k = 0; k < KM; ++k) g[k] = 0.f;
-        if (y != ANH_LABEL_IGNORE && y < K) {
-            float m = -INFINITY;
-#pragma unroll
-            for (int k = 0; k < KM; ++k) if (k < K) m = fmaxf(m, z[k]);
-            float e[KM], sum = 0.f;
-#pragma unroll
-            for (int k = 0; k < KM; ++k) { e[k] = k < K ? expf(z[k] - m) : 0.f; sum += e[k]; }
-            const float sw = (float)a.scale * r.wgt;
-#pragma unroll
-            for (int k = 0; k < KM; ++k) if (k < K) {
-                const float pk = e[k] / sum;
-                if (k == y) { if (sub == 0) loss += sw * (-logf(fmaxf(pk, 1e-10f))); g[k] = sw * (pk - 1.f); }
-                else g[k] = sw * pk;
-            }
-        } else if (y != ANH_LABEL_IGNORE && a.error_flag) *a.error_flag = 1;
+        for (int k = 0; k < KM; ++k) g[k] = quad_bcast(g_mine, k);
         float dx[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
@@ -1338,15 +1356,9 @@ __global__ __launch_bounds__(256, 2) void head_train_kernel(HeadArgs a, BnFoldJo
 #pragma unroll
             for (int k = 0; k < KM; ++k) dw[c][k] = fmaf(x[c], g[k], dw[c][k]);
         }
-        if (sub == 0) {
-#pragma unroll
-            for (int k = 0; k < KM; ++k) db[k] += g[k];
-        }
+        db_mine += g_mine;
         if (da) store8<T>(da + (size_t)p * C + c0, dx);
-        if (a.dlogits && sub == 0) {
-#pragma unroll
-            for (int k = 0; k < KM; ++k) if (k < K) a.dlogits[(size_t)p * K + k] = g[k];
-        }
+        if (a.dlogits && mine) a.dlogits[(size_t)p * K + sub] = g_mine;
         if (bnred) {
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
@@ -1379,8 +1391,7 @@ __global__ __launch_bounds__(256, 2) void head_train_kernel(HeadArgs a, BnFoldJo
     {
         const double l = fold(loss);
         if (lane == 0) red[wave][0] = l;
-#pragma unroll
-        for (int k = 0; k < KM; ++k) { const double v = fold(db[k]); if (lane == 0) red[wave][1 + k] = v; }
+        { const double v = fold(db_mine); if (lane < KM) red[wave][1 + lane] = v; }   // lanes 0..3 = sub 0..3 = class
 #pragma unroll
         for (int c = 0; c < 8; ++c)
 #pragma unroll
@@ -1827,7 +1838,13 @@ bool head_train_supported(const HeadTrainArgs& a) {
 }
 // 768 = 3 workgroups per CU (the two-class kernel fits 3 waves per SIMD): one resident round, so the per-workgroup
 // reduction tail (about 50 double wave-folds per thread) is paid once per CU slot and not once per 12 pixels.
-int head_train_blocks(int64_t pixels) { return (int)std::max<int64_t>(1, std::min<int64_t>((pixels * 4 + 255) / 256, 768)); }
+int head_train_blocks(int64_t pixels) {
+    // two workgroups per CU are resident (194-226 VGPRs): 512 is ONE round of them on 256 CUs; every further workgroup pays the closing
+    // fold again (43 double-precision wave reductions + its row of partials).  Measured 256 / 384 / 512 / 640 / 768 / 1024 workgroups:
+    // 89 / 82 / 68 / 85 / 80 / 78 us
+    static const int cap = getenv("ANH_HEAD_BLOCKS") ? std::max(1, atoi(getenv("ANH_HEAD_BLOCKS"))) : 512;
+    return (int)std::max<int64_t>(1, std::min<int64_t>((pixels * 4 + 255) / 256, cap));
+}
 int64_t head_train_partial_doubles(const HeadTrainArgs& a) { return (int64_t)head_train_blocks(a.pixels) * (1 + a.k + kHeadC * a.k); }
 
 void launch_head_train(const HeadTrainArgs& t, hipStream_t s) {
@@ -1940,6 +1957,11 @@ void launch_bn_bwd_finalize(const BnBwdArgs& a, hipStream_t s) {
     HIP_CHECK(hipGetLastError());
 }
 
+static int apply_block_cap() {   // 10 workgroups per CU; 1024 / 1280 / 2048 / 2304 / 2560 / 3072 / 4096 / 8192: +0.5 / +0.2 / 0 / -0.2 / -0.4 / 0 / +0.5 / +3 % of the step
+    static const int cap = getenv("ANH_APPLY_BLOCKS") ? std::max(1, atoi(getenv("ANH_APPLY_BLOCKS"))) : 256 * 10;
+    return cap;
+}
+
 void launch_bn_bwd_apply(const BnBwdArgs& a, hipStream_t s) {
     const int64_t total = a.pixels * a.c;
     const bool bf = a.dtype == DT_BF16;
@@ -1947,7 +1969,7 @@ void launch_bn_bwd_apply(const BnBwdArgs& a, hipStream_t s) {
     if (a.head_g) {   // da of the layer under the fused head is recomputed from the head's dlogits
         ANH_REQUIRE(a.c == kHeadC && a.head_k >= 1 && a.head_k <= kHeadKMax && out != nullptr, "bn_bwd_apply: head form needs 32 channels and at most 4 classes");
         const int64_t chunks = total / 8;
-        const int blocks = (int)std::min<int64_t>((chunks + 255) / 256, 256 * 8);
+        const int blocks = (int)std::min<int64_t>((chunks + 255) / 256, apply_block_cap());
         auto go = [&](auto kernel, auto tag) {
             using T = decltype(tag);
             hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, s, a.head_g, a.head_w_tm, a.head_k, reinterpret_cast<T*>(out), reinterpret_cast<const T*>(a.y), chunks,
@@ -1960,7 +1982,7 @@ void launch_bn_bwd_apply(const BnBwdArgs& a, hipStream_t s) {
     }
     if (bn_vec_ok(a.c)) {
         const int64_t chunks = total / 8;
-        const int apply_blocks = (int)std::min<int64_t>((chunks + 255) / 256, 256 * 8);  // 256 threads: a multiple of every group count
+        const int apply_blocks = (int)std::min<int64_t>((chunks + 255) / 256, apply_block_cap());  // 256 threads: a multiple of every group count
         if (bf) hipLaunchKernelGGL(bn_bwd_apply_vec_kernel<bf16>, dim3(apply_blocks), dim3(256), 0, s, reinterpret_cast<const bf16*>(a.da), reinterpret_cast<bf16*>(out),
                                    reinterpret_cast<const bf16*>(a.y), chunks, a.c, a.mean, a.invstd, a.scale, a.shift, a.coef);
         else hipLaunchKernelGGL(bn_bwd_apply_vec_kernel<float>, dim3(apply_blocks), dim3(256), 0, s, reinterpret_cast<const float*>(a.da), reinterpret_cast<float*>(out),
