@@ -106,10 +106,12 @@ struct anh_trainer {
     // which lr decision therefore does not depend on GPU / host timing: runs are reproducible and the ranks of a data-parallel
     // job (who all see the same all-reduced loss) shrink their rate at the same step.
     static constexpr unsigned long kLossLag = 4;
-    float* loss_ring = nullptr;
-    struct PendingLoss { hipEvent_t ev; int slot; unsigned long step; bool arrived; double value; };
+    // pinned ring of posted losses: the update kernel of step k stores (tag(k) << 32 | float bits) into slot k mod 256 (SgdArgs::loss_post)
+    unsigned long long* loss_ring = nullptr;      // host address
+    unsigned long long* loss_ring_dev = nullptr;  // the same words as the device sees them
+    static unsigned int loss_tag(unsigned long step) { return (unsigned int)(step & 0x7fffffffu) | 0x80000000u; }   // never the 0 of a fresh slot
+    struct PendingLoss { int slot; unsigned long step; bool arrived; double value; };
     std::deque<PendingLoss> pending;   // step order; not yet recorded into the schedule
-    std::vector<hipEvent_t> free_events;
     int next_slot = 0;
     bool resume_pending = false;       // SetSynchronizationFile named a file: resume from it once the net structure is final
     // Host-buffer steps (StartTraining): two staging sets, each a pinned host block + a device block holding
@@ -171,11 +173,20 @@ struct anh_trainer {
     void structural_change() { if (steps > 0) fail(ANH_ERR_INVALID, "the net structure cannot change once training has started"); dirty = true; }
     void arrive(PendingLoss& p) {   // blocks until the loss of that step is on the host
         if (p.arrived) return;
-        HIP_CHECK(hipEventSynchronize(p.ev));
-        p.value = (double)loss_ring[p.slot];
+        const volatile unsigned long long* word = loss_ring + p.slot;
+        const unsigned int want = loss_tag(p.step);
+        unsigned long long w = *word;
+        if ((unsigned int)(w >> 32) != want) {
+            // not there yet: the stream is at most kLossLag steps behind.  Drain it (this also surfaces a device fault) and look again.
+            { DeviceScope scope(device_of(0)); eng->synchronize(); }
+            w = *word;
+            if ((unsigned int)(w >> 32) != want) fail(ANH_ERR_INTERNAL, "the loss of a finished step was not posted");
+        }
+        const unsigned int bits = (unsigned int)(w & 0xffffffffu);
+        float v;
+        std::memcpy(&v, &bits, sizeof v);
+        p.value = (double)v;
         p.arrived = true;
-        free_events.push_back(p.ev);
-        p.ev = nullptr;
     }
     // records the losses of steps <= upto into the schedule, oldest first
     void record_until(unsigned long upto) {
@@ -191,8 +202,6 @@ struct anh_trainer {
         if (!pending.empty()) last_loss = pending.back().value;
     }
     ~anh_trainer() {
-        for (auto& p : pending) if (p.ev) (void)hipEventDestroy(p.ev);
-        for (auto e : free_events) (void)hipEventDestroy(e);
         if (loss_ring) (void)hipHostFree(loss_ring);
         for (auto& st : stage) {
             if (st.pinned) (void)hipHostFree(st.pinned);
@@ -737,7 +746,11 @@ int anh_trainer_initialize(anh_trainer* h) {
         (void)Spec::build(h->cfg);  // validates the configuration
         h->initialized = true;
         h->dirty = true;
-        if (!h->loss_ring) HIP_CHECK(hipHostMalloc((void**)&h->loss_ring, 256 * sizeof(float), hipHostMallocDefault));
+        if (!h->loss_ring) {
+            HIP_CHECK(hipHostMalloc((void**)&h->loss_ring, 256 * sizeof(unsigned long long), hipHostMallocDefault));
+            std::memset(h->loss_ring, 0, 256 * sizeof(unsigned long long));
+            HIP_CHECK(hipHostGetDevicePointer((void**)&h->loss_ring_dev, h->loss_ring, 0));
+        }
     });
 }
 int anh_trainer_set_learning_rate(anh_trainer* h, double lr) { TRAINER_SETTER(lr, { ANH_REQUIRE(lr > 0, "learning rate must be positive"); h->sched.lr = lr; }); }
@@ -798,17 +811,12 @@ int anh_trainer_apply_update(anh_trainer* h, double grad_scale) {
         if (h->steps + 1 > anh_trainer::kLossLag) h->record_until(h->steps + 1 - anh_trainer::kLossLag);
         for (size_t r = 1; r < h->replicas(); ++r) { DeviceScope scope(h->device_of(r)); h->replica(r).apply_update(h->sched.lr, h->weight_decay, h->momentum, grad_scale, h->bn_window); }
         DeviceScope scope0(h->device_of(0));
-        e.apply_update(h->sched.lr, h->weight_decay, h->momentum, grad_scale, h->bn_window);
-        // ship this step's loss (gradient bucket's trailing slot: already all-reduced under data parallelism)
-        hipEvent_t ev;
-        if (!h->free_events.empty()) { ev = h->free_events.back(); h->free_events.pop_back(); }
-        else HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        // the update kernel also ships this step's loss (gradient bucket's trailing slot: already all-reduced under data parallelism)
         const int slot = h->next_slot;
         h->next_slot = (h->next_slot + 1) % 256;
-        HIP_CHECK(hipMemcpyAsync(h->loss_ring + slot, e.grad_bucket() + e.spec.n_params, sizeof(float), hipMemcpyDeviceToHost, e.stream));
-        HIP_CHECK(hipEventRecord(ev, e.stream));
+        e.apply_update(h->sched.lr, h->weight_decay, h->momentum, grad_scale, h->bn_window, h->loss_ring_dev + slot, anh_trainer::loss_tag(h->steps + 1));
         ++h->steps;
-        h->pending.push_back({ev, slot, h->steps, false, 0.0});
+        h->pending.push_back({slot, h->steps, false, 0.0});
         if (h->verbose && h->steps % 100 == 0) {
             if (!h->pending.empty()) { h->arrive(h->pending.front()); h->last_loss = h->pending.front().value; }   // the oldest loss in flight
             std::printf("step#: %lu  learning rate: %g  loss: %g  steps without apparent progress: %lu\n", h->steps, h->sched.lr, h->last_loss,
@@ -1060,7 +1068,7 @@ void load_state_into(anh_trainer* h, Engine& e, const char* path) {
     f.read((char*)&n_unrec, 8);
     if (!f || n_unrec > 4096) fail(ANH_ERR_IO, "trainer state file is corrupt");
     std::deque<anh_trainer::PendingLoss> unrec;
-    for (uint64_t i = 0; i < n_unrec; ++i) { uint64_t st; double v; f.read((char*)&st, 8); f.read((char*)&v, 8); unrec.push_back({nullptr, 0, (unsigned long)st, true, v}); }
+    for (uint64_t i = 0; i < n_unrec; ++i) { uint64_t st; double v; f.read((char*)&st, 8); f.read((char*)&v, 8); unrec.push_back({0, (unsigned long)st, true, v}); }
     f.read((char*)&n_bn, 8);
     if (!f || n_bn > 4096) fail(ANH_ERR_IO, "trainer state file is corrupt");
     std::vector<double> updates((size_t)n_bn);
@@ -1076,7 +1084,6 @@ void load_state_into(anh_trainer* h, Engine& e, const char* path) {
         er.set_momentum(m.data());
         er.set_running_updates(updates);
     }
-    for (auto& pl : h->pending) if (pl.ev) h->free_events.push_back(pl.ev);
     h->pending = unrec;
     h->steps = (unsigned long)steps; h->last_loss = last_loss;
     h->sched.lr = lr; h->sched.check_budget = (unsigned long)budget; h->sched.steps_without_progress = (unsigned long)swp; h->sched.history = hist;

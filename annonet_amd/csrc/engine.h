@@ -106,7 +106,8 @@ class Engine {
     void forward_training(const Src& image, int n, int h, int w);
     // ---- training ----
     void backward(const uint16_t* d_labels, const float* d_weights, double loss_scale_n);
-    void apply_update(double lr, double weight_decay, double momentum, double grad_scale, unsigned long bn_window);
+    // loss_post / loss_tag: SgdArgs::loss_post (the update kernel posts the step's loss to that pinned host word), or null
+    void apply_update(double lr, double weight_decay, double momentum, double grad_scale, unsigned long bn_window, unsigned long long* loss_post = nullptr, unsigned int loss_tag = 0);
     double read_loss();  // synchronises
     int read_error_flag_and_clear();
     void layer_tensor(int layer, int which, float* out_host, int64_t capacity, int dims[4]);

@@ -793,7 +793,7 @@ void Engine::backward(const uint16_t* d_labels, const float* d_weights, double l
     }
 }
 
-void Engine::apply_update(double lr, double weight_decay, double momentum_coef, double grad_scale, unsigned long bn_window_arg) {
+void Engine::apply_update(double lr, double weight_decay, double momentum_coef, double grad_scale, unsigned long bn_window_arg, unsigned long long* loss_post, unsigned int loss_tag) {
     ANH_REQUIRE(training && have_forward, "apply_update without a step");
     (void)bn_window_arg;  // running statistics are updated by the training forward (bn_finalize), as dlib's bn_ does
     SgdArgs a;
@@ -803,6 +803,7 @@ void Engine::apply_update(double lr, double weight_decay, double momentum_coef, 
     a.w_tm_f32 = w_tm_f32.as<float>(); a.w_km_f32 = w_km_f32.as<float>();
     a.w_tm_bf16 = w_tm_bf16.p; a.w_km_bf16 = w_km_bf16.p;
     a.lr = lr; a.weight_decay = weight_decay; a.momentum_coef = momentum_coef; a.grad_scale = grad_scale; a.apply = 1;
+    if (loss_post) { a.loss_src = grad.as<float>() + spec.n_params; a.loss_post = loss_post; a.loss_tag = loss_tag; }
     if (tables && bn_acc.p && bn_acc_bytes % 16 == 0) { a.zero = bn_acc.p; a.zero_words16 = (int64_t)(bn_acc_bytes / 16); tables_clean = true; }
     const int tok = prof.begin(stream, "sgd_momentum_wd", 0, (double)spec.n_params * 28);
     launch_sgd(a, stream);

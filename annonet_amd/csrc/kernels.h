@@ -190,6 +190,9 @@ struct SgdArgs {
     // table mode: the update is the last kernel of a step, and the bn accumulator tables are dead by then — it also clears them for
     // the next step (16-byte words), so the next forward starts without a fill on its critical path
     void* zero = nullptr; int64_t zero_words16 = 0;
+    // the step's loss (fp32 at loss_src, final by the time this kernel runs) posted to pinned host memory as ONE 64-bit word
+    // (tag << 32 | float bits): the host polls the tag — no copy, no event packet on the stream between two steps
+    const float* loss_src = nullptr; unsigned long long* loss_post = nullptr; unsigned int loss_tag = 0;
 };
 void launch_sgd(const SgdArgs& a, hipStream_t s);
 // canonical <-> tap-major conversion of a whole blob (get_grads, tests)

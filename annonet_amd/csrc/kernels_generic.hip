@@ -1467,6 +1467,8 @@ __device__ __forceinline__ void filter_indices(const ParamSegment& sg, int64_t l
 __global__ __launch_bounds__(256) void sgd_kernel(SgdArgs a) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     for (int64_t z = i; z < a.zero_words16; z += (int64_t)gridDim.x * blockDim.x) reinterpret_cast<uint4*>(a.zero)[z] = make_uint4(0u, 0u, 0u, 0u);
+    if (i == 0 && a.loss_post)
+        __hip_atomic_store(a.loss_post, ((unsigned long long)a.loss_tag << 32) | (unsigned long long)__float_as_uint(*a.loss_src), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (i >= a.n_params) return;
     const ParamSegment sg = a.segments[find_segment(a.segments, a.n_segments, i)];
     const int64_t local = i - sg.start;

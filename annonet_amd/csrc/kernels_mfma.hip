@@ -1639,19 +1639,20 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
 
 int ws_target_wgs();
 
-template <class G, int NT>
-void launch_ws(const ConvArgs& a, int tiles_x, int tiles_y, int flip, hipStream_t s) {
-    const int n_tiles = tiles_x * tiles_y * a.n, groups = a.c_out / (NT * 32);
-    const dim3 grid((unsigned)std::max(1, std::min(n_tiles, ws_target_wgs() / groups)), (unsigned)groups), block(512);
-    const size_t tables = (size_t)a.c_red * 16 + (size_t)NT * 32 * 16;
-    const size_t x_bytes = (size_t)G::RECS * 64, w_bytes = (size_t)9 * NT * 32 * 64;
+// LDS layout of a persistent conv launch and whether it takes the producer-side form of the fused bn backward sums (PS).
+// with_bnred: the sums are wanted (conv_fused_bnred_blocks asks before ConvArgs::bnred_* are set).
+struct WsLayout { int wres; size_t lds; bool ps; int e_off; };
+WsLayout ws_layout(const ConvArgs& a, int recs, int acc, int nt, bool with_bnred) {
+    const size_t tables = (size_t)a.c_red * 16 + (size_t)nt * 32 * 16;
+    const size_t x_bytes = (size_t)recs * 64, w_bytes = (size_t)9 * nt * 32 * 64;
     // filter-resident form: two reduction slabs (64 channels) whose filter blocks fit beside two patches; the end-of-kernel
     // statistics reduction borrows 32 NT KiB from the start of the buffer
     static const bool resident_on = !(getenv("ANH_WS_WEIGHT_RESIDENT") && atoi(getenv("ANH_WS_WEIGHT_RESIDENT")) == 0);
     const int n_slabs = a.c_red >> 5;
     const size_t resident_lds = 2 * x_bytes + (size_t)n_slabs * w_bytes + tables;
-    int wres = resident_on && n_slabs >= 2 && resident_lds <= 160 * 1024 && 2 * x_bytes + (size_t)n_slabs * w_bytes >= (size_t)32 * 1024 * NT;
-    size_t lds = wres ? resident_lds : 2 * (x_bytes + w_bytes) + tables;
+    WsLayout L{};
+    L.wres = resident_on && n_slabs >= 2 && resident_lds <= 160 * 1024 && 2 * x_bytes + (size_t)n_slabs * w_bytes >= (size_t)32 * 1024 * nt;
+    L.lds = L.wres ? resident_lds : 2 * (x_bytes + w_bytes) + tables;
     // Producer-side bn backward sums (the PS forms): plain-copy staging with the fused reduction, when the epilogue buffer fits —
     // one buffer of ACC x 128 pixel slots, two (alternating by item) for single-slab layers whose every item ends a tile.  A
     // single-slab layer may take the resident layout to make room (one filter block instead of a copy per patch buffer; whatever
@@ -1661,15 +1662,25 @@ void launch_ws(const ConvArgs& a, int tiles_x, int tiles_y, int flip, hipStream_
     // down geometries get slower (32->32: 99 -> 117 us: their producers become the long pole).  ANH_WS_PSTAT: 0 off, 1 (default) the
     // four-group geometry only, 2 every form that fits.
     static const int ps_env = getenv("ANH_WS_PSTAT") ? atoi(getenv("ANH_WS_PSTAT")) : 1;
-    const bool ps_on = ps_env == 2 || (ps_env == 1 && G::ACC == 4);
-    const size_t e_total = (size_t)G::ACC * 128 * 64 * NT * (n_slabs == 1 ? 2 : 1);
-    bool ps = false;
-    if (ps_on && (a.bnred_partials || a.bnred_acc) && a.src.kind == SRC_RAW && !a.out_scale && !a.stat_partials && !a.stat_acc) {
-        if (lds + e_total <= 160 * 1024) ps = true;
-        else if (n_slabs == 1 && resident_lds + e_total <= 160 * 1024 && resident_lds - tables >= 16 * 1024) { wres = 1; lds = resident_lds; ps = true; }
+    const bool ps_on = ps_env == 2 || (ps_env == 1 && acc == 4);
+    const size_t e_total = (size_t)acc * 128 * 64 * nt * (n_slabs == 1 ? 2 : 1);
+    if (ps_on && with_bnred && a.src.kind == SRC_RAW && !a.out_scale && !a.stat_partials && !a.stat_acc) {
+        if (L.lds + e_total <= 160 * 1024) L.ps = true;
+        else if (n_slabs == 1 && resident_lds + e_total <= 160 * 1024 && resident_lds - tables >= 16 * 1024) { L.wres = 1; L.lds = resident_lds; L.ps = true; }
     }
-    const int e_off = ps ? (int)((lds + 15) / 16 * 16) : 0;
-    if (ps) lds = (size_t)e_off + e_total;
+    L.e_off = L.ps ? (int)((L.lds + 15) / 16 * 16) : 0;
+    if (L.ps) L.lds = (size_t)L.e_off + e_total;
+    return L;
+}
+
+template <class G, int NT>
+void launch_ws(const ConvArgs& a, int tiles_x, int tiles_y, int flip, hipStream_t s) {
+    const int n_tiles = tiles_x * tiles_y * a.n, groups = a.c_out / (NT * 32);
+    const dim3 grid((unsigned)std::max(1, std::min(n_tiles, ws_target_wgs() / groups)), (unsigned)groups), block(512);
+    const WsLayout lay = ws_layout(a, G::RECS, G::ACC, NT, a.bnred_partials != nullptr || a.bnred_acc != nullptr);
+    const int wres = lay.wres, e_off = lay.e_off;
+    const size_t lds = lay.lds;
+    const bool ps = lay.ps;
     // ANH_WS_ROLE_MAP: 0 = one producer + one consumer per SIMD, 1 = consumers on SIMDs 0-1 / producers on SIMDs 2-3, 2 = map 1 for the
     // 32-output-channel kernels only (their MFMA phase is short; the 64-channel kernels need all four matrix cores)
     static const int role_env = getenv("ANH_WS_ROLE_MAP") ? atoi(getenv("ANH_WS_ROLE_MAP")) : 0;
@@ -2438,7 +2449,12 @@ int conv_fused_bnred_blocks(const ConvArgs& a) {
     static const int on = getenv("ANH_FUSE_BN_BWD_REDUCE") ? atoi(getenv("ANH_FUSE_BN_BWD_REDUCE")) : 1;
     const ConvPlan p = conv_plan(a);
     const int acc = p.geo == 0 ? 2 : p.geo == 1 ? 1 : 4;
-    if (!on || p.form != 2 || acc * p.nt > 4) return 0;
+    if (!on || p.form != 2) return 0;
+    // more than four accumulator tiles per consumer wave leave no registers for the sums there: only the producer-side form keeps them
+    // (64 output channels of the up geometry: 128->64 backward-data 48 -> 77 us, and the layer's own reduce pass over (da, y), 42 us,
+    // disappears; two workgroup groups of 32 channels each in that form cost the same 77 us)
+    static const int wide_ps = getenv("ANH_WS_WIDE_PS") ? atoi(getenv("ANH_WS_WIDE_PS")) : 1;
+    if (acc * p.nt > 4 && !(wide_ps && ws_layout(a, p.geo == 0 ? GeoS1::RECS : p.geo == 1 ? GeoDown::RECS : GeoUp::RECS, acc, p.nt, true).ps)) return 0;
     return p.grid_x;
 }
 

@@ -55,6 +55,8 @@ def test_schedule_is_bit_identical(tmp_path, default_run, name, env):
     ("bn_sums_as_partials_with_finalize_kernels", {"ANH_BN_TABLES": "0"}),
     ("bn_backward_sums_kept_by_the_consumer_waves", {"ANH_WS_PSTAT": "0"}),
     ("bn_backward_sums_kept_by_the_producer_waves_wherever_they_fit", {"ANH_WS_PSTAT": "2"}),
+    ("separate_reduce_pass_for_the_layer_behind_the_64_channel_up_conv", {"ANH_WS_WIDE_PS": "0"}),
+    ("fused_head_on_768_workgroups", {"ANH_HEAD_BLOCKS": "768"}),
     ("separate_bn_statistics", {"ANH_FUSE_BN_STATS": "0"}),
     ("separate_bn_backward_reduction", {"ANH_FUSE_BN_BWD_REDUCE": "0"}),
     ("stem_dy_materialised", {"ANH_FUSE_STEM_BN_APPLY": "0"}),
