@@ -1563,6 +1563,8 @@ __global__ __launch_bounds__(256) void head_blend_kernel(HeadBlendArgs a) {
     const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 2;
     const int f0 = (int)b.full[0], f1 = (int)b.full[1], f2 = (int)b.full[2], f3 = (int)b.full[3];
     const int u0 = (int)b.unique[0], u1 = (int)b.unique[1], u2 = (int)b.unique[2], u3 = (int)b.unique[3];
+    const float inv_w = 1.0f / (float)b.tile_w;
+    const bool small_tile = (int64_t)b.tile_h * b.tile_w <= ((int64_t)1 << 24);
     auto process = [&](int64_t p, const Raw8<bf16>& ra, const Raw8<bf16>& rb) __attribute__((always_inline)) {
         float x[8];
         raw_to_float(ra, x);
@@ -1584,15 +1586,22 @@ __global__ __launch_bounds__(256) void head_blend_kernel(HeadBlendArgs a) {
             float acc = 0.f;
 #pragma unroll
             for (int c = 0; c < 8; ++c) acc = fmaf(x[c], w[c][k], acc);
-            acc += __shfl_xor(acc, 1, 64);
-            acc += __shfl_xor(acc, 2, 64);
+            acc += quad_perm<0xB1>(acc);   // lane ^ 1
+            acc += quad_perm<0x4E>(acc);   // lane ^ 2
             z[k] = acc + bias[k];
         }
         // blend (annonet_infer.cpp:116-164): lane `sub` owns class `sub`
         // (a tile has < 2^31 pixels and its rectangles lie within int range: 32-bit arithmetic — the 64-bit division and compares
         // of the first version were a third of this kernel's instructions)
         const unsigned up = (unsigned)p, uw = (unsigned)b.tile_w;
-        const int y = (int)(up / uw), xx = (int)(up - (unsigned)y * uw);
+        // p / tile_w without the 32-bit division sequence on tiles of up to 2^24 pixels: p is exact in fp32 and the float quotient lies
+        // within one of the answer (error <= y * 2^-23 < 1 for tile_w >= 3; tile_w = 1, 2 are exact)
+        int y, xx;
+        if (small_tile) {
+            y = (int)((float)up * inv_w);
+            xx = (int)up - y * (int)uw;
+            if (xx < 0) { --y; xx += (int)uw; } else if (xx >= (int)uw) { ++y; xx -= (int)uw; }
+        } else { y = (int)(up / uw); xx = (int)(up - (unsigned)y * uw); }
         const int bx = b.tile_left + xx, by = b.tile_top + y;
         if (sub >= K || by < f1 || by > f3 || by < 0 || by >= b.img_h || bx < f0 || bx > f2 || bx < 0 || bx >= b.img_w) return;
         float in = z[0];
@@ -2037,7 +2046,10 @@ void launch_head_blend(const HeadBlendArgs& a, hipStream_t s) {
     ANH_REQUIRE(head_blend_supported(a), "head_blend: unsupported shape");
     const int64_t pixels = (int64_t)a.blend.tile_h * a.blend.tile_w;
     if (pixels <= 0) return;
-    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((pixels * 4 + 255) / 256, 2048));   // 8 workgroups per CU, >= 5 rounds of four pixels per thread on a 1024^2 tile
+    // ONE round of resident workgroups (94-115 VGPRs: five per CU on 256 CUs).  4096^2 tiled inference, 1024 / 1280 / 2048 / 2560 / 3840
+    // workgroups: 3,799 / 3,838 / 3,759 / 3,801 / 3,763 Mpx/s
+    static const int cap = getenv("ANH_HEAD_BLEND_BLOCKS") ? std::max(1, atoi(getenv("ANH_HEAD_BLEND_BLOCKS"))) : 1280;
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((pixels * 4 + 255) / 256, cap));
     switch (a.src.kind) {
         case SRC_ACT: hipLaunchKernelGGL(head_blend_kernel<SRC_ACT>, dim3(blocks), dim3(256), 0, s, a); break;
         case SRC_ACT2: hipLaunchKernelGGL(head_blend_kernel<SRC_ACT2>, dim3(blocks), dim3(256), 0, s, a); break;

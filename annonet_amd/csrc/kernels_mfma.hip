@@ -2328,7 +2328,9 @@ bool stem_mfma_ok(const ConvArgs& a) {
 }
 int stem_mfma_blocks(const ConvArgs& a) {
     const int total = ((a.w_out + 31) / 32) * ((a.h_out + 7) / 8) * a.n;
-    return std::min(total, 1024);   // four workgroups per CU (the training form's registers admit three at a time)
+    static const int env = getenv("ANH_STEM_BLOCKS") ? atoi(getenv("ANH_STEM_BLOCKS")) : 0;
+    // ONE round of resident workgroups: four per CU for the inference form, three for the training form (152 VGPRs)
+    return std::min(total, env > 0 ? env : a.out_scale ? 1024 : 768);
 }
 void launch_stem_mfma(const ConvArgs& a, hipStream_t s) {
     const int tiles_x = (a.w_out + 31) / 32, tiles_y = (a.h_out + 7) / 8;
