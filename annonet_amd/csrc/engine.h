@@ -50,6 +50,7 @@ struct LayerState {
     float* coef = nullptr;  // bn backward coefficients [3][C] of this layer (its own slot: two streams read them)
     int n = 0, h_in = 0, w_in = 0, h = 0, w = 0;
     bool dact_written = false;
+    const void* da_alias = nullptr;   // backward: da of this layer lives in ANOTHER layer's buffer (skip gradient written once); its apply pass reads it from there
     // backward bookkeeping: a layer's da is final once all its consumers' backward-data convs have written it; the conv
     // that writes it last may also leave the dgamma / dbeta partial sums (fused bn backward reduction)
     int consumers = 0, da_writes = 0, fused_bwd_blocks = 0;

@@ -605,7 +605,7 @@ void Engine::backward(const uint16_t* d_labels, const float* d_weights, double l
     const int64_t P = (int64_t)last_n * last_h * last_w;
     const double es = (double)elem_size(dtype);
     const bool fused_head = head_is_fused();
-    for (auto& s : ls) s.dact_written = false;
+    for (auto& s : ls) { s.dact_written = false; s.da_alias = nullptr; }
     int head_bnred_blocks_ = 0;
     bool head_da_virtual = false;
     if (fused_head) {
@@ -689,6 +689,15 @@ void Engine::backward(const uint16_t* d_labels, const float* d_weights, double l
             dg.w_bf16 = dtype == DT_BF16 ? (const void*)(w_tm_bf16.as<uint16_t>() + L.w_off) : nullptr;
             dg.out = ls[L.in_a].dact.p; dg.out_dtype = dtype; dg.out_accumulate = ls[L.in_a].dact_written ? 1 : 0;
             if (L.in_b >= 0) { dg.out2 = ls[L.in_b].dact.p; dg.out2_accumulate = ls[L.in_b].dact_written ? 1 : 0; }
+            // experiment switch: the gradient w.r.t. a skip sum is ONE tensor for both addends.  When this conv is the first writer of both,
+            // it is stored once, in the skip source's buffer; the main source's apply pass reads it there and writes its dy out of place.
+            static const bool skip_once = getenv("ANH_SKIP_GRAD_ONCE") && atoi(getenv("ANH_SKIP_GRAD_ONCE")) != 0;
+            if (skip_once && L.in_b >= 0 && !ls[L.in_a].dact_written && !ls[L.in_b].dact_written && spec.layers[L.in_a].has_bn && spec.layers[L.in_a].in_a >= 0 &&
+                !(head_da_virtual && L.in_a == head.in_a) && ls[L.in_a].dact.bytes == ls[L.in_b].dact.bytes) {
+                dg.out = ls[L.in_b].dact.p; dg.out_accumulate = 0;
+                dg.out2 = nullptr; dg.out2_accumulate = 0;
+                ls[L.in_a].da_alias = ls[L.in_b].dact.p;
+            }
         }
         // bn + relu backward of this layer: sums (left by the conv that wrote da, else a reduce pass) -> finalize -> one elementwise
         // apply pass that turns da into dy in place, read by the backward-data conv (this stream) and the filter gradient (second
@@ -698,7 +707,8 @@ void Engine::backward(const uint16_t* d_labels, const float* d_weights, double l
         if (L.has_bn) {
             ANH_REQUIRE(s.dact_written, "internal: layer output has no consumer");
             BnBwdArgs b;
-            b.da = s.dact.p; b.y = s.raw.p; b.dtype = dtype; b.pixels = p_out; b.c = L.cout;
+            b.da = s.da_alias ? const_cast<void*>(s.da_alias) : s.dact.p; b.y = s.raw.p; b.dtype = dtype; b.pixels = p_out; b.c = L.cout;
+            if (s.da_alias) b.dy_out = s.dact.p;
             b.gamma = master.as<float>() + L.g_off; b.mean = s.mean; b.invstd = s.invstd; b.scale = s.scale; b.shift = s.shift;
             b.dgamma = grad.as<float>() + L.g_off; b.dbeta = grad.as<float>() + L.beta_off;
             b.partials = bn_partials.as<double>(); b.coef = s.coef;
