@@ -958,17 +958,20 @@ void Engine::infer_device(const uint8_t* d_image, int H, int W, const double* ga
     prof.start_image();
     launch_fill_zero(d_blended, (size_t)K * pixels * 4, stream);
     // consecutive tiles with equal input windows (all of them, on a regular tiling) run as batches
+    // — as FEW batches as the cap allows, of equal size (25 tiles at a cap of 8 used to run as 8 + 8 + 8 + 1: every launch has a fixed
+    // prologue and tail, and the last batch paid them for one tile)
     for (size_t i = 0; i < tiles.size();) {
         const TileWindow w0 = tile_window(tiles[i], spec.cfg.levels);
-        const int batch = tile_batch(w0.height, w0.width);
-        size_t j = i + 1;
-        while (j < tiles.size() && j - i < (size_t)batch) {
-            const TileWindow wj = tile_window(tiles[j], spec.cfg.levels);
+        const size_t batch = (size_t)tile_batch(w0.height, w0.width);
+        size_t run = 1;
+        while (i + run < tiles.size()) {
+            const TileWindow wj = tile_window(tiles[i + run], spec.cfg.levels);
             if (wj.height != w0.height || wj.width != w0.width) break;
-            ++j;
+            ++run;
         }
-        infer_tiles(&tiles[i], (int)(j - i), d_image, H, W, d_blended);
-        i = j;
+        const size_t n_batches = (run + batch - 1) / batch, per = (run + n_batches - 1) / n_batches;
+        for (size_t done = 0; done < run; done += per) infer_tiles(&tiles[i + done], (int)std::min(per, run - done), d_image, H, W, d_blended);
+        i += run;
     }
     if (d_labels) argmax_rows(d_blended, H, W, 0, H, gains_host, d_labels);
 }

@@ -47,7 +47,7 @@ struct Src {
     // several windows of ONE image as the samples of a batch (annonet_infer() runs tiles of equal size together): sample n
     // starts at (img_win[2n], img_win[2n+1]); img_nwin = 0 means the single window above
     int img_nwin = 0;
-    int img_win[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int img_win[32] = {};
     __host__ __device__ int win_left(int n) const { return img_nwin ? img_win[2 * n] : img_left; }
     __host__ __device__ int win_top(int n) const { return img_nwin ? img_win[2 * n + 1] : img_top; }
 };
