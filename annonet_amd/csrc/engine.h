@@ -114,6 +114,7 @@ class Engine {
     void layer_tensor(int layer, int which, float* out_host, int64_t capacity, int dims[4]);
 
     // ---- tiled inference: annonet_infer.cpp:42-214 with image, blended planes and labels resident in HBM ----
+    int head_epi_layer = -1; float* head_epi_out = nullptr;   // set around the conv launches of one inference batch (infer_tiles)
     static constexpr int kMaxTileBatch = 16;   // Src::img_win holds 16 windows (4096^2 image, 25 tiles of 1024^2: batches of 8+8+8+1 / 7+6+6+6 / 9+8+8 / 13+12 / 25: 3,838 / 3,865 / 3,917 / 3,960 / 3,938 Mpx/s)
     void infer_tile(const anh_tile& t, const uint8_t* d_image, int H, int W, float* d_blended);
     void infer_tiles(const anh_tile* ts, int count, const uint8_t* d_image, int H, int W, float* d_blended);

@@ -478,6 +478,10 @@ void Engine::run_conv_forward(int li, const Src& image, bool training_pass, floa
     const anh_layer_desc& L = spec.layers[li];
     LayerState& s = ls[li];
     ConvArgs a = forward_conv_args(li, image, training_pass, d_out_nchw);
+    if (!training_pass && li == head_epi_layer) {   // inference: this conv's epilogue also runs the 1x1 head (Engine::infer_tiles)
+        const anh_layer_desc& head = spec.layers.back();
+        a.head_w = w_tm_f32.as<float>() + head.w_off; a.head_bias = master.as<float>() + head.b_off; a.head_k = head.cout; a.head_out = head_epi_out;
+    }
     const int64_t p_out = (int64_t)s.n * s.h * s.w, p_in = (int64_t)s.n * s.h_in * s.w_in;
     const double flops = 2.0 * L.k * L.k * L.cin * L.cout * (double)(L.type == 0 ? p_out : p_in);
     const double es = (double)elem_size(dtype);
@@ -887,11 +891,25 @@ void Engine::infer_tiles(const anh_tile* ts, int count, const uint8_t* d_image, 
     HeadBlendArgs hb;
     hb.src = layer_source((int)spec.layers.size() - 1, image); hb.c_in = head.cin; hb.k = head.cout;
     const bool fuse_head = !training && head.k == 1 && head.has_bias && head.in_a >= 0 && head_blend_supported(hb);
+    bool head_epi = false;   // the head rides in the epilogue of the last hidden layer's conv: its logits, not its activation, go to memory
     if (fuse_head) {
         prof.start_pass();
         plan_dims(count, win.height, win.width);
         choose_inference_form(image);
+        const int hl = head.in_a;
+        if (head.in_b < 0 && hl == (int)spec.layers.size() - 2) {
+            int readers = 0;
+            for (const anh_layer_desc& X : spec.layers) readers += (X.in_a == hl) + (X.in_b == hl);
+            ConvArgs probe = forward_conv_args(hl, image, false, nullptr);
+            probe.head_k = head.cout;
+            head_epi = readers == 1 && conv_head_in_epilogue_ok(probe);
+        }
+        if (head_epi) {
+            tile_out.reserve((size_t)count * K * win.height * win.width * 4);
+            head_epi_layer = hl; head_epi_out = tile_out.as<float>();
+        }
         for (size_t li = 0; li + 1 < spec.layers.size(); ++li) run_conv_forward((int)li, image, false, nullptr);
+        head_epi_layer = -1; head_epi_out = nullptr;
     } else {
         tile_out.reserve((size_t)count * K * win.height * win.width * 4);
         forward_inference(image, count, win.height, win.width, tile_out.as<float>());
@@ -901,12 +919,12 @@ void Engine::infer_tiles(const anh_tile* ts, int count, const uint8_t* d_image, 
         const anh_tile& t = ts[i];
         const TileWindow wi = tile_window(t, spec.cfg.levels);
         BlendArgs b;
-        b.logits_nchw = fuse_head ? nullptr : tile_out.as<float>() + (size_t)i * K * win.height * win.width; b.blended = d_blended;
+        b.logits_nchw = (fuse_head && !head_epi) ? nullptr : tile_out.as<float>() + (size_t)i * K * win.height * win.width; b.blended = d_blended;
         b.k = K; b.tile_h = wi.height; b.tile_w = wi.width; b.tile_left = wi.left; b.tile_top = wi.top;
         b.img_h = H; b.img_w = W;
         b.full[0] = t.full_rect.left; b.full[1] = t.full_rect.top; b.full[2] = t.full_rect.right; b.full[3] = t.full_rect.bottom;
         b.unique[0] = t.unique_rect.left; b.unique[1] = t.unique_rect.top; b.unique[2] = t.unique_rect.right; b.unique[3] = t.unique_rect.bottom;
-        if (fuse_head) {
+        if (fuse_head && !head_epi) {
             hb.src = layer_source((int)spec.layers.size() - 1, image);   // (scale/shift pointers are stable; the tensors were just written)
             const size_t plane = (size_t)win.height * win.width * head.cin * es;   // sample i of the last hidden tensor
             hb.src.a = static_cast<const char*>(hb.src.a) + (size_t)i * plane;

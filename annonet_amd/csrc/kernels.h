@@ -75,6 +75,11 @@ struct ConvArgs {
     // bf16 inference on the MFMA path: the epilogue stores relu(acc * out_scale[c] + out_shift[c]) — this layer's folded bn and its
     // relu on the fp32 accumulator — instead of the raw output, so that its consumers stage plain copies (conv_stores_activation())
     const float* out_scale = nullptr; const float* out_shift = nullptr;
+    // ... and, for the layer under a 1x1 head (32 channels -> head_k <= 4 classes, bias): head_out set = that activation is NOT stored;
+    // the epilogue forms the pixel's logits from it (the fused head/blend kernel's expression and order) and stores them as fp32
+    // planes [n][head_k][h_out][w_out] — 4 head_k instead of 64 bytes per pixel written here and read back by the blend
+    // (conv_head_in_epilogue_ok() decides; head_w = [ci][k] fp32 holding bf16-rounded values)
+    const float* head_w = nullptr; const float* head_bias = nullptr; int head_k = 0; float* head_out = nullptr;
     // Fused bn + relu backward REDUCTION (MFMA path, backward-data convs): `out` receives its final value da of a layer with
     // raw output bnred_y and folded constants; the kernel also writes that layer's dgamma / dbeta partial sums
     // ([channel][sum dz*xhat | sum dz][workgroup], dz = (y*scale+shift > 0) ? da : 0, xhat = (y-mean)*invstd).
@@ -215,6 +220,7 @@ struct HeadBlendArgs {
     BlendArgs blend;
 };
 bool head_blend_supported(const HeadBlendArgs& a);
+bool conv_head_in_epilogue_ok(const ConvArgs& a);   // a = the conv of the last hidden layer, with out_scale / head_k set
 void launch_head_blend(const HeadBlendArgs& a, hipStream_t s);
 void launch_argmax(const float* blended, int k, int64_t pixels, const double* gains_or_null, uint16_t* labels, hipStream_t s);
 void launch_argmax_range(const float* blended, int k, int64_t pixels, int64_t p0, int64_t p1, const double* gains_or_null, uint16_t* labels, hipStream_t s);

@@ -13,6 +13,7 @@
 //     v_permlane32_swap and stores 16 B per lane straight to NHWC — no LDS transpose.
 //   * fp32 accumulate; 2 workgroups per CU (<= 59 KB LDS, <= 256 VGPR) overlap one tile's staging with the other's MFMAs.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #include <algorithm>
 #include <mutex>
@@ -248,6 +249,53 @@ __device__ __forceinline__ void store_pixel_tiles_act(const f32x16 (&acc)[NT], c
             auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
             if (valid) *reinterpret_cast<uint4*>(out + base + nt * 32 + 16 * s) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
         }
+    }
+}
+
+// Inference epilogue of the layer under the 1x1 head: the activation of store_pixel_tiles_act (same rounding), not stored — after the
+// permlane swap this lane holds two of the pixel's four 8-channel chunks (channels 16 s + 8 half ...), which are exactly the chunks of
+// head_blend_kernel's four lanes: chunk sums chained over ascending channels from 0, (chunk 0 + chunk 1) + (chunk 2 + chunk 3), + bias.
+// hw[s][j][k] = head weight of channel 16 s + 8 half + j, class k (zero beyond head_k).  Half 0 stores classes 0 and 2, half 1 classes 1 and 3.
+__device__ __forceinline__ void store_pixel_tiles_head(const f32x16& acc, const ConvArgs& a, size_t pix, int n, bool valid, int half, const float* act, int cw,
+                                                       const float (&hw)[2][8][4], const float (&hbias)[4]) {
+    float v[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 sc = *reinterpret_cast<const float4*>(act + 8 * q + 4 * half);
+        const float4 sh = *reinterpret_cast<const float4*>(act + cw + 8 * q + 4 * half);
+        v[4 * q + 0] = fmaf(acc[4 * q + 0], sc.x, sh.x);
+        v[4 * q + 1] = fmaf(acc[4 * q + 1], sc.y, sh.y);
+        v[4 * q + 2] = fmaf(acc[4 * q + 2], sc.z, sh.z);
+        v[4 * q + 3] = fmaf(acc[4 * q + 3], sc.w, sh.w);
+    }
+    float part[2][4];   // chunk sums of this lane's two chunks
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const unsigned a0 = relu_bf16x2(pack2(v[8 * s + 0], v[8 * s + 1])), a1 = relu_bf16x2(pack2(v[8 * s + 2], v[8 * s + 3]));
+        const unsigned b0 = relu_bf16x2(pack2(v[8 * s + 4], v[8 * s + 5])), b1 = relu_bf16x2(pack2(v[8 * s + 6], v[8 * s + 7]));
+        auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+        auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+        const unsigned w4[4] = {r0[0], r1[0], r0[1], r1[1]};   // channels 16 s + 8 half + 0 .. 7, two per word
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                sum = fmaf(lo_f(w4[i]), hw[s][2 * i][k], sum);
+                sum = fmaf(hi_f(w4[i]), hw[s][2 * i + 1][k], sum);
+            }
+            part[s][k] = sum;
+        }
+    }
+    const size_t plane = (size_t)a.h_out * a.w_out;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        // the other half's chunk sums: chunk 2 s + (1 - half)
+        auto x0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(part[0][k]), __float_as_uint(part[0][k]), false, false);
+        auto x1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(part[1][k]), __float_as_uint(part[1][k]), false, false);
+        const float o0 = __uint_as_float(half ? x0[0] : x0[1]), o1 = __uint_as_float(half ? x1[0] : x1[1]);
+        const float z = ((part[0][k] + o0) + (part[1][k] + o1)) + hbias[k];
+        if (valid && k < a.head_k && (k & 1) == half) a.head_out[pix + ((size_t)n * (a.head_k - 1) + k) * plane] = z;
     }
 }
 
@@ -1158,7 +1206,7 @@ struct GeoUp {
 // 16-byte channel chunk, hence 16 running sums instead of the consumers' NT x 32 — reads them back beside the y it has fetched
 // meanwhile.  In the backward-data convs the producers (plain-copy staging) wait at the hand-over barrier for a third to half of
 // the kernel while the consumers' epilogue is as long as their MFMA phase: this moves that work to where the slack is.
-template <class G, int NT, int KIND, bool FWD = false, bool ACT = false, bool PS = false>
+template <class G, int NT, int KIND, bool FWD = false, bool ACT = false, bool PS = false, bool HEAD = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tiles_x, int tiles_y, int flip, long long* prof, int wres_, int e_off) {
     // per-phase wall-clock accounting, compiled in with -DANH_WS_PROFILE (ANH_WS_PROF=1 then prints one line per launch)
 #ifdef ANH_WS_PROFILE
@@ -1467,6 +1515,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) wb0[ks] = swz_addr(smem, col, col >> 2, ks, half);   // + the slab's block offset per item
         f32x16 acc[G::ACC][NT];
+        float hw[HEAD ? 2 : 1][HEAD ? 8 : 1][4], hbias[4] = {0.f, 0.f, 0.f, 0.f};   // HEAD: this lane's share of the 1x1 head (store_pixel_tiles_head)
+        if constexpr (HEAD) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                hbias[k] = k < a.head_k ? a.head_bias[k] : 0.f;
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) hw[s2][j][k] = k < a.head_k ? a.head_w[(16 * s2 + 8 * half + j) * a.head_k + k] : 0.f;
+            }
+        }
         u32x4 old[FWD ? 1 : G::ACC][NT][2];   // prefetched old values of a read-modify-write destination (GeoUp)
         u32x4 yraw[FWD ? 1 : G::ACC][NT][2];  // prefetched raw outputs y of the layer whose da is written (fused bn backward reduction)
         // The 32-channel read-modify-write kernel (GeoUp, NT = 1: HBM-bound, short MFMA phase) keeps the old values a whole
@@ -1549,7 +1608,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
                 for (int g = 0; g < G::ACC; ++g) {
                     size_t pix; bool valid;
                     G::out_pixel(g, a, n, ty, tx, wave, col, pix, valid);
-                    if constexpr (ACT) store_pixel_tiles_act<NT>(acc[g], a, pix, valid, half, co_base, bnc, C_OUT);
+                    if constexpr (HEAD) store_pixel_tiles_head(acc[g][0], a, pix, n, valid, half, bnc, C_OUT, hw, hbias);
+                    else if constexpr (ACT) store_pixel_tiles_act<NT>(acc[g], a, pix, valid, half, co_base, bnc, C_OUT);
                     else store_pixel_tiles_rmw<NT>(acc[g], a, pix, valid, half, co_base, old[FWD ? 0 : g], rmw, stat, stat_mode, yraw[FWD ? 0 : g], bnc,
                                                    ps ? smem + e_off + (n_slabs == 1 ? (it & 1) * E_BYTES : 0) : nullptr, (g * 4 + wave) * 32 + col);
                 }
@@ -1727,6 +1787,18 @@ void launch_ws(const ConvArgs& a, int tiles_x, int tiles_y, int flip, hipStream_
     // statistics sums take the registers the backward forms spend on prefetched epilogue operands
     if (a.out_scale) {   // inference: activation-storing epilogue, plain-copy (or skip-add) staging
         ANH_REQUIRE(a.out_shift && !a.stat_partials && !a.bnred_partials && !a.stat_acc && !a.bnred_acc && !a.out_accumulate && !a.out2, "conv_ws: the activation-storing form takes no training epilogue");
+        if (a.head_out) {   // the layer under the 1x1 head: logits instead of the activation
+            if constexpr (std::is_same<G, GeoS1>::value && NT == 1) {
+                ANH_REQUIRE(conv_head_in_epilogue_ok(a) && a.head_w && a.head_bias, "conv_ws: this layer cannot take the head in its epilogue");
+                switch (a.src.kind) {
+                    case SRC_RAW: launch(conv3x3_ws_kernel<G, NT, SRC_RAW, true, true, false, true>); break;
+                    case SRC_SUM2: launch(conv3x3_ws_kernel<G, NT, SRC_SUM2, true, true, false, true>); break;
+                    default: fail(ANH_ERR_INTERNAL, "conv_ws: the activation-storing form reads post-activation tensors");
+                }
+            } else fail(ANH_ERR_INTERNAL, "conv_ws: the head-in-epilogue form exists for the stride-1 32-channel kernel only");
+            HIP_CHECK(hipGetLastError());
+            return;
+        }
         switch (a.src.kind) {
             case SRC_RAW: launch(conv3x3_ws_kernel<G, NT, SRC_RAW, true, true>); break;
             case SRC_SUM2: launch(conv3x3_ws_kernel<G, NT, SRC_SUM2, true, true>); break;
@@ -2445,6 +2517,13 @@ int conv_fused_stat_blocks(const ConvArgs& a) {
 
 // the persistent kernels fold Src::a_tab / b_tab in their table prologue; the classic one-tile kernels read arrays only
 bool conv_folds_bn_tables(const ConvArgs& a) { return mfma_conv_supported(a) && !stem_mfma_ok(a) && ws_form_ok(a); }
+
+bool conv_head_in_epilogue_ok(const ConvArgs& a) {
+    static const bool on = !(getenv("ANH_HEAD_IN_EPILOGUE") && atoi(getenv("ANH_HEAD_IN_EPILOGUE")) == 0);
+    if (!on || !mfma_conv_supported(a) || stem_mfma_ok(a) || !ws_form_ok(a)) return false;
+    return a.k == 3 && a.stride == 1 && a.c_out == 32 && a.out_scale && a.out_dtype == DT_BF16 && a.head_k >= 1 && a.head_k <= 4 &&
+           (a.src.kind == SRC_RAW || a.src.kind == SRC_SUM2);
+}
 
 int conv_fused_bnred_blocks(const ConvArgs& a) {
     if (!mfma_conv_supported(a) || stem_mfma_ok(a) || (int64_t)a.n * a.h_out * a.w_out == 0) return 0;

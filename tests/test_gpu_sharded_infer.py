@@ -119,7 +119,7 @@ def test_the_default_stream_cannot_be_named_by_set_stream():
 
 
 def test_tile_batch_size_does_not_change_the_result(tmp_path):
-    """annonet_infer() runs tiles of equal size through the net as batches (ANH_INFER_TILE_BATCH, default 4) and blends them one after the
+    """annonet_infer() runs tiles of equal size through the net as batches (ANH_INFER_TILE_BATCH; default: equal batches of at most 16) and blends them one after the
     other in list order: label map and blended planes are BIT-identical to the tile-by-tile loop of annonet_infer.cpp:116-164, in both
     precisions, and the streamed host form (strips up, label rows down, batches within a tile row) gives the same label map."""
     import os
@@ -139,6 +139,15 @@ def test_tile_batch_size_does_not_change_the_result(tmp_path):
             np.testing.assert_array_equal(runs[batch][key], runs["1"][key], err_msg=f"batch {batch}: {key}")
     for prec in ("bf16", "fp32"):
         np.testing.assert_array_equal(runs["4"][prec + "_labels_streamed"], runs["4"][prec + "_labels"])
+    # the 1x1 head in the epilogue of the last hidden layer's conv (default) against the separate fused head/blend kernel
+    # (ANH_HEAD_IN_EPILOGUE=0): the same expression in the same order — bit-identical planes and labels
+    out = str(tmp_path / "head_kernel.npz")
+    r = subprocess.run([sys.executable, os.path.join(here, "helpers", "run_tiled_infer.py"), out], env=dict(os.environ, ANH_HEAD_IN_EPILOGUE="0"),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    sep = np.load(out)
+    for key in ("bf16_labels", "bf16_blended", "bf16_labels_streamed", "fp32_labels", "fp32_blended"):
+        np.testing.assert_array_equal(sep[key], runs["4"][key], err_msg=f"head kernel: {key}")
     # the other bf16 inference form (raw conv outputs stored, consumers re-apply bn + relu: ANH_INFER_POST_ACT=0) differs by bf16
     # rounding points only; the fp32 mode does not have two forms
     out = str(tmp_path / "raw.npz")
