@@ -485,8 +485,8 @@ void Engine::run_conv_forward(int li, const Src& image, bool training_pass, floa
     const int64_t p_out = (int64_t)s.n * s.h * s.w, p_in = (int64_t)s.n * s.h_in * s.w_in;
     const double flops = 2.0 * L.k * L.k * L.cin * L.cout * (double)(L.type == 0 ? p_out : p_in);
     const double es = (double)elem_size(dtype);
-    const double bytes = (double)p_in * L.cin * (L.in_a < 0 ? 1.0 : es) * (L.in_b >= 0 ? 2 : 1) + (double)p_out * L.cout * (L.has_bn ? es : 4.0) +
-                         (double)spec.filter_count(li) * es;
+    const double bytes = (double)p_in * L.cin * (L.in_a < 0 ? 1.0 : es) * (L.in_b >= 0 ? 2 : 1) +
+                         (a.head_out ? (double)p_out * a.head_k * 4.0 : (double)p_out * L.cout * (L.has_bn ? es : 4.0)) + (double)spec.filter_count(li) * es;
     // training forward of a bn layer: the MFMA kernels that can keep per-lane running sums also write the statistic partials
     int fused_stat_blocks = 0;
     const bool table_layer = tables && training_pass && L.has_bn;

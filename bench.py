@@ -439,7 +439,7 @@ def infer_one_size(args, side, with_cpu_baseline, aa, aad, torch, dist, prec, ra
             e = dom[0]
             li = int(ENTRY_RE.search(dominant).group(2))
             avg_s = e["total_ms"] / 1e3 / e["launches"]
-            # SURVEY.md §8d per launch: the library's launches carry 1..8 tiles, so the mean tile count per launch comes from the
+            # SURVEY.md §8d per launch: the library's launches carry 1..16 tiles, so the mean tile count per launch comes from the
             # flops the profiler summed (2 k^2 Cin Cout P per launch); bytes = the §8d MINIMUM (one input tensor + the output tensor +
             # the filters — a skip-add layer's second operand is design traffic, not algorithmic), the convention of the training line
             flops = e["flops"] / e["launches"]
