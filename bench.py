@@ -59,8 +59,9 @@ def _latest_profile(suffix):
     return found[-1] if found else os.path.join(ROOT, "profiles", "r02_" + suffix)
 
 
-TRAFFIC_JSON = _latest_profile("traffic.json")
-INFER_TRAFFIC_JSON = _latest_profile("infer_traffic.json")
+# (tools/collect_profiles.sh points these at the counter passes it has just made on the same box)
+TRAFFIC_JSON = os.environ.get("ANH_TRAFFIC_JSON") or _latest_profile("traffic.json")
+INFER_TRAFFIC_JSON = os.environ.get("ANH_INFER_TRAFFIC_JSON") or _latest_profile("infer_traffic.json")
 
 
 # ----------------------------------------------------------------------------------------------------------------------
