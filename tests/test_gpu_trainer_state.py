@@ -133,3 +133,27 @@ def test_a_state_file_that_cannot_be_loaded_is_an_error_not_a_fresh_start(tmp_pa
     path.unlink()                             # the user removes the file: training starts from scratch
     b.StartTraining(*batch(0, classes=classes))
     assert b.step_count() == 1
+
+
+def test_posted_losses_survive_the_ring_wrapping_around():
+    """The update kernel posts each step's loss into a pinned ring of 256 tagged slots (api.cpp: loss_ring); the host reads a slot
+    kLossLag steps later, or at once when asked.  300 steps: a trainer that asks after every step and one that never asks until the
+    end see the same last loss, the same learning-rate history and the same parameters — the slots are reused without mixing steps."""
+    data = [batch(100 + i % 7) for i in range(300)]
+    a, b = make_trainer(lr=0.02), make_trainer(lr=0.02)
+    losses, rates = [], []
+    for d in data:
+        a.StartTraining(*d)
+        losses.append(a.get_last_loss())     # forces the newest slot to be read right away
+        rates.append(a.GetLearningRate())
+    for d in data:
+        b.StartTraining(*d)                  # losses reach the schedule through the lagged reads only
+    assert b.step_count() == a.step_count() == 300
+    assert b.get_last_loss() == losses[-1]
+    assert b.GetLearningRate() == rates[-1]
+    assert len(set(rates)) > 1, "the schedule never moved: the test would not see a mixed-up loss"
+    assert all(np.isfinite(losses)) and len(set(losses)) > 100   # (the rate shrinks to nothing on this random data: late losses repeat)
+    pa, ra = a.get_params()
+    pb, rb = b.get_params()
+    np.testing.assert_array_equal(pb, pa)
+    np.testing.assert_array_equal(rb, ra)
