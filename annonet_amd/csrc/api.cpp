@@ -747,7 +747,8 @@ int anh_trainer_initialize(anh_trainer* h) {
         h->initialized = true;
         h->dirty = true;
         if (!h->loss_ring) {
-            HIP_CHECK(hipHostMalloc((void**)&h->loss_ring, 256 * sizeof(unsigned long long), hipHostMallocDefault));
+            // portable + mapped: the update kernel of replica 0 writes it, whichever device that replica lives on (anh_set_devices may come later)
+            HIP_CHECK(hipHostMalloc((void**)&h->loss_ring, 256 * sizeof(unsigned long long), hipHostMallocPortable | hipHostMallocMapped));
             std::memset(h->loss_ring, 0, 256 * sizeof(unsigned long long));
             HIP_CHECK(hipHostGetDevicePointer((void**)&h->loss_ring_dev, h->loss_ring, 0));
         }
