@@ -1415,7 +1415,15 @@ __global__ __launch_bounds__(256, 2) void head_train_kernel(HeadArgs a, BnFoldJo
         if (a.bn_acc) bnacc_add(a.bn_acc, BNACC_SUM_DZ_XHAT + which, C, ch, v);
         else a.bn_partials[((size_t)ch * 2 + which) * gridDim.x + blockIdx.x] = v;
     }
-    if (bnred && a.bn_acc) bnacc_finish_backward(a.bn_finish, (int)gridDim.x);
+    if (bnred && a.bn_acc) {
+        // The finish forms k0 = gamma * invstd.  The layer's invstd ARRAY is written by a fold job of THIS launch (another workgroup,
+        // possibly behind another XCD's L2): a plain load of it here may still see what memory held before — zero on a trainer's first
+        // step (every gradient below this layer then comes out zero), last step's value afterwards.  This workgroup folded the same
+        // number from the table itself (sfold[5], bnacc_fold_forward: the fold job's own arithmetic): use that.
+        BnBwdFinish fin = a.bn_finish;
+        if (tables) fin.invstd = sfold[5];
+        bnacc_finish_backward(fin, (int)gridDim.x);
+    }
     const int slots = 1 + K + C * K;
     for (int sidx = threadIdx.x; sidx < slots; sidx += blockDim.x) {
         int src;
