@@ -191,8 +191,10 @@ __device__ __forceinline__ void store_pixel_tiles_rmw(const f32x16 (&acc)[NT], c
                     for (int h2 = 0; h2 < 2; ++h2) {
                         const int j = 2 * i + h2;
                         const float dv = h2 ? hi_f(wd[i]) : lo_f(wd[i]), yv = h2 ? hi_f(yv4[i]) : lo_f(yv4[i]);
+                        // running sums of dz*y and dz: sum dz*xhat = invstd * (sum dz*y - mean * sum dz) is formed once per workgroup, in
+                        // double, by the closing reduction (two VALU operations and two table reads fewer per value than carrying xhat)
                         const float dz = fmaf(yv, t0[j], t0[cw + j]) > 0.f ? dv : 0.f;
-                        stat[nt][s][j] = fmaf(dz, (yv - t0[2 * cw + j]) * t0[3 * cw + j], stat[nt][s][j]);
+                        stat[nt][s][j] = fmaf(dz, yv, stat[nt][s][j]);
                         stat[nt][s][8 + j] += dz;
                     }
             }
@@ -1413,13 +1415,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
         init_tables();
         if (DEEP2 && ftile < n_tiles) fetch(R1);
         // ---- PS: bn backward sums of the tile whose epilogue the consumers finished two items ago ----
-        float esc[8], esh[8], emu[8], eis[8], est[16];
+        float esc[8], esh[8], est[16];
         const int ek = tid & (EK - 1), eq0 = tid / EK;   // this thread's chunk (channels 8 ek .. 8 ek + 7 of the workgroup's) and first pixel slot
         int hist1 = -1, hist2 = -1, hist1_it = 0, hist2_it = 0;   // tile (or -1) and item index of the last two items whose epilogue leaves a buffer
         if (PS) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                esc[j] = bnc[ek * 8 + j]; esh[j] = bnc[C_OUT + ek * 8 + j]; emu[j] = bnc[2 * C_OUT + ek * 8 + j]; eis[j] = bnc[3 * C_OUT + ek * 8 + j];
+                esc[j] = bnc[ek * 8 + j]; esh[j] = bnc[C_OUT + ek * 8 + j];
                 est[j] = 0.f; est[8 + j] = 0.f;
             }
         }
@@ -1450,7 +1452,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
                             const int c = 2 * i + h2;
                             const float d = h2 ? hi_f(dv[i]) : lo_f(dv[i]), y = h2 ? hi_f(yv[j][i]) : lo_f(yv[j][i]);
                             const float dz = fmaf(y, esc[c], esh[c]) > 0.f ? d : 0.f;
-                            est[c] = fmaf(dz, (y - emu[c]) * eis[c], est[c]);
+                            est[c] = fmaf(dz, y, est[c]);   // sum dz*y (-> sum dz*xhat in the closing reduction, as the consumer-side form)
                             est[8 + c] += dz;
                         }
                 }
@@ -1659,6 +1661,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
             }
 #pragma unroll
             for (int off = 1; off < GRP; off <<= 1) sum += __shfl_xor(sum, off, 64);
+            if (stat_mode == 2) {   // (sum dz*y, sum dz) of a channel sit in adjacent thread groups: -> (sum dz*xhat, sum dz)
+                const double sum_dz = __shfl_down(sum, GRP, 64);
+                if (which == 0) sum = (double)bnc[3 * C_OUT + ch] * (sum - (double)bnc[2 * C_OUT + ch] * sum_dz);
+            }
             if (part == 0) {
                 long long* table = fuse_stats ? a.stat_acc : a.bnred_acc;
                 double* dst = fuse_stats ? a.stat_partials : a.bnred_partials;
@@ -1679,6 +1685,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
             for (int m = part; m < EQ_STEP; m += GRP) sum += (double)red[(size_t)(k + EK * m) * 16 + which * 8 + j];
 #pragma unroll
             for (int off = 1; off < GRP; off <<= 1) sum += __shfl_xor(sum, off, 64);
+            {
+                const double sum_dz = __shfl_down(sum, GRP, 64);
+                if (which == 0) sum = (double)bnc[3 * C_OUT + ch] * (sum - (double)bnc[2 * C_OUT + ch] * sum_dz);
+            }
             if (part == 0) {
                 if (a.bnred_acc) bnacc_add(a.bnred_acc, BNACC_SUM_DZ_XHAT + which, a.c_out, co_base + ch, sum);
                 else a.bnred_partials[((size_t)(co_base + ch) * 2 + which) * gridDim.x + blockIdx.x] = sum;
