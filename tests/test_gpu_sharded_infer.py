@@ -148,6 +148,18 @@ def test_tile_batch_size_does_not_change_the_result(tmp_path):
     sep = np.load(out)
     for key in ("bf16_labels", "bf16_blended", "bf16_labels_streamed", "fp32_labels", "fp32_blended"):
         np.testing.assert_array_equal(sep[key], runs["4"][key], err_msg=f"head kernel: {key}")
+    # ... on the nets whose last hidden layer has the 32 channels that form covers (width 1.0), for every class count it takes
+    for classes in ("1", "2", "3", "4"):
+        pair = {}
+        for name, env in (("epilogue", {}), ("kernel", {"ANH_HEAD_IN_EPILOGUE": "0"})):
+            out = str(tmp_path / f"w1_{classes}_{name}.npz")
+            r = subprocess.run([sys.executable, os.path.join(here, "helpers", "run_tiled_infer.py"), out, "1.0", "1", classes, "2"], env=dict(os.environ, **env),
+                               capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            pair[name] = np.load(out)
+        for key in ("bf16_labels", "bf16_blended", "bf16_labels_streamed"):
+            np.testing.assert_array_equal(pair["epilogue"][key], pair["kernel"][key], err_msg=f"{classes} classes: {key}")
+        assert np.isfinite(pair["epilogue"]["bf16_blended"]).all() and float(np.abs(pair["epilogue"]["bf16_blended"]).max()) > 0
     # the other bf16 inference form (raw conv outputs stored, consumers re-apply bn + relu: ANH_INFER_POST_ACT=0) differs by bf16
     # rounding points only; the fp32 mode does not have two forms
     out = str(tmp_path / "raw.npz")
