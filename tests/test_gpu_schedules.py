@@ -43,7 +43,7 @@ def default_run(tmp_path_factory):
     ("conv_roles_on_separate_simds", {"ANH_WS_ROLE_MAP": "1"}),
     ("stem_filter_gradient_on_second_stream", {"ANH_STEM_WGRAD_MAIN": "0"}),
     ("conv_filters_streamed_with_every_patch", {"ANH_WS_WEIGHT_RESIDENT": "0"}),
-    ("skip_gradient_written_once", {"ANH_SKIP_GRAD_ONCE": "1"}),
+    ("skip_gradient_written_to_both_sources", {"ANH_SKIP_GRAD_ONCE": "0"}),
 ])
 def test_schedule_is_bit_identical(tmp_path, default_run, name, env):
     got = run_variant(tmp_path, name, env)
