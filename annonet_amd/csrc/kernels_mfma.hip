@@ -1223,7 +1223,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
 #endif
     constexpr int C_OUT = NT * 32, NP = (G::RECS * 4 + 255) / 256, W_ITEMS = 9 * C_OUT * 4, NW = (W_ITEMS + 255) / 256;
     constexpr int X_BYTES_ = G::RECS * 64, W_BYTES = 9 * C_OUT * 64, BUF = X_BYTES_ + W_BYTES;
-    const int wres = wres_ & 1, role_map = (wres_ >> 1) & 1, prio = wres_ >> 2;   // (see the role map below; prio: experiment switch ANH_WS_PRIO)
+    const int wres = wres_ & 1, role_map = (wres_ >> 1) & 1, prio = (wres_ >> 2) & 3, bands = (wres_ >> 4) & 1;   // (see the role map below; prio: experiment switch ANH_WS_PRIO)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // LDS layout.  Streaming form: [X | W] [X | W] tables — the filter slab of every item travels with its patch.
     // Resident form (wres; the filter slabs of ALL reduction slabs fit beside two patches, i.e. 64 reduction channels):
@@ -1243,7 +1243,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
     const int half = lane >> 5, col = lane & 31;
     const int co_base = blockIdx.y * C_OUT;
     const int H = a.h_in, W = a.w_in, c_red = a.c_red;
-    const int n_slabs = c_red >> 5, n_tiles = tiles_x * tiles_y * a.n;
+    const int n_slabs = c_red >> 5, n_tiles_all = tiles_x * tiles_y * a.n;
+    // Which tiles this workgroup walks.  Plain: tile blockIdx.x, then every gridDim.x-th.  XCD bands (`bands`; gridDim.x a multiple of 8):
+    // the hardware deals workgroups round-robin over the 8 XCDs (observed, MI355X_MICROARCH.md: blocks b and b + 8 share one — used for
+    // speed only, any placement gives the same result), so the workgroups with equal blockIdx.x & 7 take ONE contiguous eighth of the
+    // row-major tile list and step through it together, gridDim.x / 8 consecutive tiles at a time: the halo rows and columns a patch
+    // shares with its neighbours are then re-read from that XCD's own L2 instead of once per XCD from the memory side.
+    const int band_len = (n_tiles_all + 7) >> 3;
+    const int tile_first = bands ? (int)(blockIdx.x & 7) * band_len + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int gstep = bands ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+    const int n_tiles = bands ? min(n_tiles_all, ((int)(blockIdx.x & 7) + 1) * band_len) : n_tiles_all;   // end of this workgroup's range
     constexpr bool CAN_STATS = G::ACC * NT <= 4 || FWD;  // register budget of the consumer waves
     const bool fuse_stats = !PS && !ACT && CAN_STATS && (a.stat_partials != nullptr || a.stat_acc != nullptr);   // forward: bn statistics of the output
     const bool fuse_bnred = !FWD && (PS || CAN_STATS) && (a.bnred_partials != nullptr || a.bnred_acc != nullptr);  // backward-data: dgamma / dbeta sums of the layer `out` belongs to
@@ -1253,7 +1262,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
     constexpr int EK = 4 * NT, EQ_STEP = 256 / EK, ECH = G::ACC * 128 / EQ_STEP;   // chunks per pixel; pixel slots between a thread's chunks; chunks per thread
     float* bnc = tab + c_red * 4;            // [scale | shift | mean | invstd][C_OUT] of this workgroup's channels
 
-    int tile = blockIdx.x, slab = 0, it = 0;
+    int tile = tile_first, slab = 0, it = 0;
     auto init_tables = [&]() __attribute__((always_inline)) {   // every thread of the workgroup, from either branch below
         if (KIND == SRC_ACT || KIND == SRC_ACT2) {
             if (a.src.a_tab.acc) {   // table mode: the producers' (scale, shift) are folded here from their accumulator tables (bnacc.h)
@@ -1340,9 +1349,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
         Fetched R0, R1;
         // the fetch cursor runs two items ahead of the commits.  Its tile coordinates advance incrementally (no division per item)
         // and the chunk offsets / validity bits of its tile are computed once per tile, not once per (tile, slab) item.
-        const int gstep = (int)gridDim.x, per_img = tiles_x * tiles_y;
+        const int per_img = tiles_x * tiles_y;
         const int step_x = gstep % tiles_x, step_y = (gstep / tiles_x) % tiles_y, step_n = gstep / per_img;
-        int ftile = blockIdx.x, fslab = 0;
+        int ftile = tile_first, fslab = 0;
         int ftx = ftile % tiles_x, fty = (ftile / tiles_x) % tiles_y, fn = ftile / per_img;
         int foff[NP];
         unsigned fpok = 0;
@@ -1569,7 +1578,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
                 for (int e = 0; e < 16; ++e) stat[nt][s2][e] = 0.f;
         while (tile < n_tiles) {
             int ntile = tile, nslab = slab + 1;
-            if (nslab == n_slabs) { nslab = 0; ntile += gridDim.x; }
+            if (nslab == n_slabs) { nslab = 0; ntile += gstep; }
             const int boff = (it & 1) * x_stride;
             const int woff = wres ? 2 * X_BYTES_ + slab * W_BYTES : boff + X_BYTES_;
             typename G::Bases b;
@@ -1595,7 +1604,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
             const bool rmw = rmw_any && last_slab;
             if (pre_any && last_slab) {  // epilogue operands travel while the MFMAs run
                 if constexpr (DEEP) {
-                    if (tile + (int)gridDim.x < n_tiles) prefetch_epilogue(tile + (int)gridDim.x, old_n, yraw_n, rmw_any, cons_bnred && DEEP_Y);
+                    if (tile + gstep < n_tiles) prefetch_epilogue(tile + gstep, old_n, yraw_n, rmw_any, cons_bnred && DEEP_Y);
                     if constexpr (!DEEP_Y) prefetch_epilogue(tile, old, yraw, false, cons_bnred);
                 } else prefetch_epilogue(tile, old, yraw, rmw_any, cons_bnred);
             }
@@ -1755,7 +1764,10 @@ void launch_ws(const ConvArgs& a, int tiles_x, int tiles_y, int flip, hipStream_
     // 32-output-channel kernels only (their MFMA phase is short; the 64-channel kernels need all four matrix cores)
     static const int role_env = getenv("ANH_WS_ROLE_MAP") ? atoi(getenv("ANH_WS_ROLE_MAP")) : 0;
     static const int prio_env = getenv("ANH_WS_PRIO") ? atoi(getenv("ANH_WS_PRIO")) : 0;
-    const int role_map = (role_env == 1 || (role_env == 2 && NT == 1) ? 1 : 0) | (prio_env << 1);
+    // ANH_WS_XCD_BANDS (1): the workgroups of one XCD walk one contiguous eighth of the tile list (see the kernel); 0 = strided walk
+    static const int bands_env = getenv("ANH_WS_XCD_BANDS") ? atoi(getenv("ANH_WS_XCD_BANDS")) : 1;
+    const int bands = bands_env && grid.x % 8 == 0 && grid.x >= 8 ? 1 : 0;
+    const int role_map = (role_env == 1 || (role_env == 2 && NT == 1) ? 1 : 0) | ((prio_env & 3) << 1) | (bands << 3);
     auto launch = [&](auto kernel) {
         ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), lds);
 #ifndef ANH_WS_PROFILE

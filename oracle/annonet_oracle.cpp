@@ -29,6 +29,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <immintrin.h>
 #include <cstdint>
 #include <cstring>
 #include <deque>
@@ -291,6 +292,208 @@ void conv_backward_filter(const Layer& L, const Tensor& x, const Tensor& dy, std
 }
 
 // ------------------------------------------------------------------------------------------
+// im2col + blocked SGEMM (conv_algo = 1): the CPU design SURVEY.md §8d names as the baseline to time —
+// dlib's CPU path lowers con / cont to im2col (per sample) + BLAS sgemm (cpu_dlib.cpp + BLAS;
+// /root/reference/annonet_train_cpu.vcxproj:93,113,230 list those files).  No BLAS exists in this image, so the
+// SGEMM is written here: a 6 x 16 AVX2 register tile, K unblocked (the operands of one strip fit the core's L2).
+// Every layer is handled through its "con geometry": a big tensor B (cb channels), a small tensor S (cs channels),
+// filters W[(tap, cb)][cs]:
+//   gather   S  = im2col(B) . W             con forward,        cont backward-data
+//   scatter  B += col2im(S . W^T)           con backward-data,  cont forward
+//   filter   dW = im2col(B)^T . S           both filter gradients
+// The direct loops above stay the parity oracle (their summation order is what the GPU parity mode reproduces);
+// this path is checked against them (tests/test_oracle_gemm.py) and is what bench.py times as cpu_baseline.
+// ------------------------------------------------------------------------------------------
+struct ConGeo { int k, s, p, cb, cs; };
+
+// C[M x N] (+)= A . B with A(i, k) = a[i * ars + k * aks], B and C row-major.
+template <int MR>
+static inline void sgemm_tile16(int K, const float* a, ptrdiff_t ars, ptrdiff_t aks, const float* b, int ldb, float* c, int ldc, bool accumulate) {
+    __m256 acc[MR][2];
+    for (int i = 0; i < MR; ++i) {
+        acc[i][0] = accumulate ? _mm256_loadu_ps(c + (size_t)i * ldc) : _mm256_setzero_ps();
+        acc[i][1] = accumulate ? _mm256_loadu_ps(c + (size_t)i * ldc + 8) : _mm256_setzero_ps();
+    }
+    for (int k = 0; k < K; ++k) {
+        const __m256 b0 = _mm256_loadu_ps(b + (size_t)k * ldb), b1 = _mm256_loadu_ps(b + (size_t)k * ldb + 8);
+        for (int i = 0; i < MR; ++i) {
+            const __m256 av = _mm256_broadcast_ss(a + i * ars + k * aks);
+            acc[i][0] = _mm256_fmadd_ps(av, b0, acc[i][0]);
+            acc[i][1] = _mm256_fmadd_ps(av, b1, acc[i][1]);
+        }
+    }
+    for (int i = 0; i < MR; ++i) { _mm256_storeu_ps(c + (size_t)i * ldc, acc[i][0]); _mm256_storeu_ps(c + (size_t)i * ldc + 8, acc[i][1]); }
+}
+template <int MR>
+static inline void sgemm_tile8(int K, const float* a, ptrdiff_t ars, ptrdiff_t aks, const float* b, int ldb, float* c, int ldc, bool accumulate) {
+    __m256 acc[MR];
+    for (int i = 0; i < MR; ++i) acc[i] = accumulate ? _mm256_loadu_ps(c + (size_t)i * ldc) : _mm256_setzero_ps();
+    for (int k = 0; k < K; ++k) {
+        const __m256 b0 = _mm256_loadu_ps(b + (size_t)k * ldb);
+        for (int i = 0; i < MR; ++i) acc[i] = _mm256_fmadd_ps(_mm256_broadcast_ss(a + i * ars + k * aks), b0, acc[i]);
+    }
+    for (int i = 0; i < MR; ++i) _mm256_storeu_ps(c + (size_t)i * ldc, acc[i]);
+}
+static void sgemm_block(int M, int N, int K, const float* a, ptrdiff_t ars, ptrdiff_t aks, const float* b, int ldb, float* c, int ldc, bool accumulate) {
+    for (int i0 = 0; i0 < M; i0 += 6) {
+        const int mr = std::min(6, M - i0);
+        const float* ai = a + (ptrdiff_t)i0 * ars;
+        float* ci = c + (size_t)i0 * ldc;
+        int j0 = 0;
+        for (; j0 + 16 <= N; j0 += 16) {
+            switch (mr) {
+                case 6: sgemm_tile16<6>(K, ai, ars, aks, b + j0, ldb, ci + j0, ldc, accumulate); break;
+                case 5: sgemm_tile16<5>(K, ai, ars, aks, b + j0, ldb, ci + j0, ldc, accumulate); break;
+                case 4: sgemm_tile16<4>(K, ai, ars, aks, b + j0, ldb, ci + j0, ldc, accumulate); break;
+                case 3: sgemm_tile16<3>(K, ai, ars, aks, b + j0, ldb, ci + j0, ldc, accumulate); break;
+                case 2: sgemm_tile16<2>(K, ai, ars, aks, b + j0, ldb, ci + j0, ldc, accumulate); break;
+                default: sgemm_tile16<1>(K, ai, ars, aks, b + j0, ldb, ci + j0, ldc, accumulate); break;
+            }
+        }
+        for (; j0 + 8 <= N; j0 += 8) {
+            switch (mr) {
+                case 6: sgemm_tile8<6>(K, ai, ars, aks, b + j0, ldb, ci + j0, ldc, accumulate); break;
+                case 5: sgemm_tile8<5>(K, ai, ars, aks, b + j0, ldb, ci + j0, ldc, accumulate); break;
+                case 4: sgemm_tile8<4>(K, ai, ars, aks, b + j0, ldb, ci + j0, ldc, accumulate); break;
+                case 3: sgemm_tile8<3>(K, ai, ars, aks, b + j0, ldb, ci + j0, ldc, accumulate); break;
+                case 2: sgemm_tile8<2>(K, ai, ars, aks, b + j0, ldb, ci + j0, ldc, accumulate); break;
+                default: sgemm_tile8<1>(K, ai, ars, aks, b + j0, ldb, ci + j0, ldc, accumulate); break;
+            }
+        }
+        for (; j0 < N; ++j0)   // narrow remainders (the 1x1 head's K = 3 classes)
+            for (int i = 0; i < mr; ++i) {
+                float acc = accumulate ? ci[(size_t)i * ldc + j0] : 0.f;
+                for (int k = 0; k < K; ++k) acc = fmaf(ai[i * ars + k * aks], b[(size_t)k * ldb + j0], acc);
+                ci[(size_t)i * ldc + j0] = acc;
+            }
+    }
+}
+// K is walked in blocks of 256 so that the A and B panels of a register tile stay in L1; C carries the partial sums between blocks
+// exactly (an fp32 store and reload), so every output is still ONE k-ordered fmaf chain from +0.
+static void sgemm(int M, int N, int K, const float* a, ptrdiff_t ars, ptrdiff_t aks, const float* b, int ldb, float* c, int ldc, bool accumulate) {
+    constexpr int KC = 256;
+    for (int k0 = 0; k0 < K; k0 += KC)
+        sgemm_block(M, N, std::min(KC, K - k0), a + (ptrdiff_t)k0 * aks, ars, aks, b + (size_t)k0 * ldb, ldb, c, ldc, accumulate || k0 > 0);
+    if (K == 0 && !accumulate) for (int i = 0; i < M; ++i) std::memset(c + (size_t)i * ldc, 0, sizeof(float) * N);
+}
+
+// one row `sy` of the small tensor: col[sx][(tap, cb)] = B(n, sy*s + ky - p, sx*s + kx - p) or 0 outside the tensor
+static void im2col_row(const ConGeo& g, const Tensor& B, int n, int sy, int ws, float* col) {
+    const int kk = g.k * g.k * g.cb;
+    for (int sx = 0; sx < ws; ++sx) {
+        float* dst = col + (size_t)sx * kk;
+        for (int ky = 0; ky < g.k; ++ky)
+            for (int kx = 0; kx < g.k; ++kx, dst += g.cb) {
+                const int by = sy * g.s + ky - g.p, bx = sx * g.s + kx - g.p;
+                if (by < 0 || by >= B.h || bx < 0 || bx >= B.w) std::memset(dst, 0, sizeof(float) * g.cb);
+                else std::memcpy(dst, B.px(n, by, bx), sizeof(float) * g.cb);
+            }
+    }
+}
+static void gemm_gather(const ConGeo& g, const float* W /*[(tap,cb)][cs]*/, const Tensor& B, Tensor& S) {
+    const int kk = g.k * g.k * g.cb, rows = S.n * S.h;
+#pragma omp parallel
+    {
+        std::vector<float> col((size_t)S.w * kk);
+#pragma omp for schedule(dynamic, 1)
+        for (int r = 0; r < rows; ++r) {
+            const int n = r / S.h, sy = r % S.h;
+            im2col_row(g, B, n, sy, S.w, col.data());
+            sgemm(S.w, g.cs, kk, col.data(), kk, 1, W, g.cs, S.px(n, sy, 0), g.cs, false);
+        }
+    }
+}
+// B += col2im(S . W^T).  Rows of S whose scatter footprints overlap run in different passes (ceil(k / s) colours).
+static void gemm_scatter(const ConGeo& g, const float* WT /*[cs][(tap,cb)]*/, const Tensor& S, Tensor& B) {
+    const int kk = g.k * g.k * g.cb, rows = S.n * S.h, colours = (g.k + g.s - 1) / g.s;
+#pragma omp parallel
+    {
+        std::vector<float> col((size_t)S.w * kk);
+        for (int colour = 0; colour < colours; ++colour) {
+#pragma omp for schedule(dynamic, 1)
+            for (int r = 0; r < rows; ++r) {
+                const int n = r / S.h, sy = r % S.h;
+                if (sy % colours != colour) continue;
+                sgemm(S.w, kk, g.cs, S.px(n, sy, 0), g.cs, 1, WT, kk, col.data(), kk, false);
+                for (int sx = 0; sx < S.w; ++sx) {
+                    const float* src = col.data() + (size_t)sx * kk;
+                    for (int ky = 0; ky < g.k; ++ky)
+                        for (int kx = 0; kx < g.k; ++kx, src += g.cb) {
+                            const int by = sy * g.s + ky - g.p, bx = sx * g.s + kx - g.p;
+                            if (by < 0 || by >= B.h || bx < 0 || bx >= B.w) continue;
+                            float* d = B.px(n, by, bx);
+                            for (int c = 0; c < g.cb; ++c) d[c] += src[c];
+                        }
+                }
+            }   // (implicit barrier: the next colour touches rows this one has finished)
+        }
+    }
+}
+// dW[(tap,cb)][cs] = sum over pixels; float within one row of S, double across rows (as the direct loop)
+static void gemm_filter(const ConGeo& g, const Tensor& B, const Tensor& S, std::vector<double>& dw) {
+    const int kk = g.k * g.k * g.cb, rows = S.n * S.h;
+    const size_t nw = (size_t)kk * g.cs;
+    dw.assign(nw, 0.0);
+#pragma omp parallel
+    {
+        std::vector<float> col((size_t)S.w * kk), part(nw);
+        std::vector<double> local(nw, 0.0);
+#pragma omp for schedule(dynamic, 1)
+        for (int r = 0; r < rows; ++r) {
+            const int n = r / S.h, sy = r % S.h;
+            im2col_row(g, B, n, sy, S.w, col.data());
+            sgemm(kk, g.cs, S.w, col.data(), 1, kk, S.px(n, sy, 0), g.cs, part.data(), g.cs, false);
+            for (size_t i = 0; i < nw; ++i) local[i] += part[i];
+        }
+#pragma omp critical
+        for (size_t i = 0; i < nw; ++i) dw[i] += local[i];
+    }
+}
+// tap-major filters wt[tap][ci][co] of a layer -> the con-geometry operands
+static ConGeo con_geo(const Layer& L) { return ConGeo{L.k, L.stride, L.pad, L.type == 0 ? L.cin : L.cout, L.type == 0 ? L.cout : L.cin}; }
+static std::vector<float> con_w(const Layer& L, const std::vector<float>& wt) {   // [(tap, cb)][cs]
+    if (L.type == 0) return wt;
+    std::vector<float> w(wt.size());
+    const int t = L.k * L.k;
+    for (int tt = 0; tt < t; ++tt) for (int i = 0; i < L.cin; ++i) for (int o = 0; o < L.cout; ++o) w[((size_t)tt * L.cout + o) * L.cin + i] = wt[((size_t)tt * L.cin + i) * L.cout + o];
+    return w;
+}
+static std::vector<float> con_wt(const Layer& L, const std::vector<float>& wt) {  // [cs][(tap, cb)]
+    std::vector<float> w(wt.size());
+    const int t = L.k * L.k, kk = t * (L.type == 0 ? L.cin : L.cout);
+    for (int tt = 0; tt < t; ++tt) for (int i = 0; i < L.cin; ++i) for (int o = 0; o < L.cout; ++o) {
+        const float v = wt[((size_t)tt * L.cin + i) * L.cout + o];
+        if (L.type == 0) w[(size_t)o * kk + tt * L.cin + i] = v; else w[(size_t)i * kk + tt * L.cout + o] = v;
+    }
+    return w;
+}
+void conv_forward_gemm(const Layer& L, const std::vector<float>& wt, const Tensor& x, Tensor& y) {
+    y.resize(x.n, out_dim(L, x.h), out_dim(L, x.w), L.cout);
+    const ConGeo g = con_geo(L);
+    if (L.type == 0) gemm_gather(g, wt.data(), x, y);
+    else { const std::vector<float> w = con_wt(L, wt); gemm_scatter(g, w.data(), x, y); }
+}
+void conv_backward_data_gemm(const Layer& L, const std::vector<float>& wt, const Tensor& dy, Tensor& dx) {   // dx += ...
+    const ConGeo g = con_geo(L);
+    if (L.type == 0) { const std::vector<float> w = con_wt(L, wt); gemm_scatter(g, w.data(), dy, dx); }
+    else {
+        const std::vector<float> w = con_w(L, wt);
+        Tensor t; t.resize(dx.n, dx.h, dx.w, dx.c);
+        gemm_gather(g, w.data(), dy, t);
+        for (size_t i = 0; i < dx.d.size(); ++i) dx.d[i] += t.d[i];
+    }
+}
+void conv_backward_filter_gemm(const Layer& L, const Tensor& x, const Tensor& dy, std::vector<double>& dw) {   // dw[tap][ci][co]
+    const ConGeo g = con_geo(L);
+    if (L.type == 0) { gemm_filter(g, x, dy, dw); return; }
+    std::vector<double> t;
+    gemm_filter(g, dy, x, t);   // [(tap, co)][ci]
+    dw.assign(t.size(), 0.0);
+    const int taps = L.k * L.k;
+    for (int tt = 0; tt < taps; ++tt) for (int i = 0; i < L.cin; ++i) for (int o = 0; o < L.cout; ++o) dw[((size_t)tt * L.cin + i) * L.cout + o] = t[((size_t)tt * L.cout + o) * L.cin + i];
+}
+
+// ------------------------------------------------------------------------------------------
 // The net object
 // ------------------------------------------------------------------------------------------
 struct Net {
@@ -305,6 +508,8 @@ struct Net {
     //   inference passes (1): the stored ACTIVATIONS relu(bn(y)) — the epilogue applies the layer's folded bn + relu to the fp32
     //   accumulators and rounds once; (2): raw-output storage in inference as well (the library with ANH_INFER_POST_ACT=0)
     int emulate_bf16 = 0;
+    // 0: direct convolution loops (the parity oracle); 1: im2col + blocked SGEMM with OpenMP reductions (the timed CPU baseline)
+    int conv_algo = 0;
     // scratch
     std::vector<Tensor> raw, act, dact;
     Tensor image;
@@ -316,6 +521,7 @@ void u8_to_tensor(const uint8_t* img, int n, int h, int w, int c, Tensor& t) {
     // dlib input<matrix<rgb_pixel>>::to_tensor: value / 256.0, channel order R,G,B [UPSTREAM-UNVERIFIED]
     t.resize(n, h, w, c);
     const size_t total = (size_t)n * h * w * c;
+#pragma omp parallel for schedule(static)
     for (size_t i = 0; i < total; ++i) t.d[i] = (float)img[i] * (1.0f / 256.0f);
 }
 
@@ -339,6 +545,7 @@ void gather_input(const Net& net, const Layer& L, const std::vector<Tensor>& act
     else {
         const Tensor& b = act[L.in_b];
         x.resize(a.n, a.h, a.w, a.c);
+#pragma omp parallel for schedule(static)
         for (size_t i = 0; i < x.d.size(); ++i) x.d[i] = a.d[i] + b.d[i];
     }
     if (net.emulate_bf16) round_tensor(x.d);  // the MFMA A operand is bf16
@@ -348,6 +555,27 @@ std::vector<float> layer_weights(const Net& net, const Layer& L) {
     std::vector<float> wt = to_tap_major(L, net.params.data() + L.w_off);
     if (net.emulate_bf16) round_tensor(wt);
     return wt;
+}
+
+// per-channel double sums over pixels of f(p, c) -> (s0, s1).  Serial in the parity mode (one fixed summation order);
+// OpenMP with per-thread partials in the timed baseline mode (conv_algo = 1), where the order is that of the thread team.
+template <typename F>
+static void channel_sums2(size_t P, int C, bool parallel, std::vector<double>& s0, std::vector<double>& s1, const F& f) {
+    s0.assign(C, 0.0); s1.assign(C, 0.0);
+    if (!parallel) {
+        for (size_t p = 0; p < P; ++p)
+            for (int c = 0; c < C; ++c) { double a, b; f(p, c, a, b); s0[c] += a; s1[c] += b; }
+        return;
+    }
+#pragma omp parallel
+    {
+        std::vector<double> l0(C, 0.0), l1(C, 0.0);
+#pragma omp for schedule(static)
+        for (size_t p = 0; p < P; ++p)
+            for (int c = 0; c < C; ++c) { double a, b; f(p, c, a, b); l0[c] += a; l1[c] += b; }
+#pragma omp critical
+        for (int c = 0; c < C; ++c) { s0[c] += l0[c]; s1[c] += l1[c]; }
+    }
 }
 
 // forward; training=false uses running stats, training=true uses batch stats and records
@@ -364,7 +592,7 @@ void forward(Net& net, bool training, std::vector<BnBatch>* bn_out) {
         const Layer& L = s.layers[li];
         gather_input(net, L, net.act, x);
         std::vector<float> wt = layer_weights(net, L);
-        conv_forward(L, wt, x, net.raw[li]);
+        if (net.conv_algo == 1) conv_forward_gemm(L, wt, x, net.raw[li]); else conv_forward(L, wt, x, net.raw[li]);
         Tensor& y = net.raw[li];
         const bool act_storage = net.emulate_bf16 == 1 && !training;
         if (net.emulate_bf16 && !act_storage && L.has_bn) round_tensor(y.d);  // raw conv outputs are stored as bf16; logits stay fp32
@@ -377,9 +605,8 @@ void forward(Net& net, bool training, std::vector<BnBatch>* bn_out) {
             if (!training) affine_from_running(net, L, scale, shift);
             else {
                 BnBatch& bb = (*bn_out)[li];
-                std::vector<double> sum(C, 0.0), sq(C, 0.0);
-                for (size_t p = 0; p < P; ++p)
-                    for (int c = 0; c < C; ++c) { const double v = y.d[p * C + c]; sum[c] += v; sq[c] += v * v; }
+                std::vector<double> sum, sq;
+                channel_sums2(P, C, net.conv_algo == 1, sum, sq, [&](size_t p, int c, double& a, double& b) { const double v = y.d[p * C + c]; a = v; b = v * v; });
                 bb.mean.resize(C); bb.invstd.resize(C); bb.scale.resize(C); bb.shift.resize(C); bb.var.resize(C);
                 scale.resize(C); shift.resize(C);
                 const float* g = net.params.data() + L.g_off;
@@ -396,6 +623,7 @@ void forward(Net& net, bool training, std::vector<BnBatch>* bn_out) {
                 }
                 bb.scale = scale; bb.shift = shift;
             }
+#pragma omp parallel for schedule(static)
             for (size_t p = 0; p < P; ++p)
                 for (int c = 0; c < C; ++c) {
                     const float z = fmaf(y.d[p * C + c], scale[c], shift[c]);
@@ -475,16 +703,16 @@ void train_step(Net& net, const uint8_t* images, const uint16_t* labels, const f
         if (L.has_bn) {
             const BnBatch& bb = bn[li];
             const float* g = net.params.data() + L.g_off;
-            std::vector<double> dg(C, 0.0), db(C, 0.0);
-            for (size_t p = 0; p < P; ++p)
-                for (int c = 0; c < C; ++c) {
-                    const size_t i = p * C + c;
-                    const float dz = net.act[li].d[i] > 0.f ? da.d[i] : 0.f;
-                    const float xhat = (y.d[i] - bb.mean[c]) * bb.invstd[c];
-                    dg[c] += (double)dz * xhat; db[c] += dz;
-                }
+            std::vector<double> dg, db;
+            channel_sums2(P, C, net.conv_algo == 1, dg, db, [&](size_t p, int c, double& a, double& b) {
+                const size_t i = p * C + c;
+                const float dz = net.act[li].d[i] > 0.f ? da.d[i] : 0.f;
+                const float xhat = (y.d[i] - bb.mean[c]) * bb.invstd[c];
+                a = (double)dz * xhat; b = dz;
+            });
             for (int c = 0; c < C; ++c) { net.grads[L.g_off + c] = (float)dg[c]; net.grads[L.beta_off + c] = (float)db[c]; }
             const double invP = 1.0 / (double)P;
+#pragma omp parallel for schedule(static)
             for (size_t p = 0; p < P; ++p)
                 for (int c = 0; c < C; ++c) {
                     const size_t i = p * C + c;
@@ -502,16 +730,21 @@ void train_step(Net& net, const uint8_t* images, const uint16_t* labels, const f
             }
         }
         gather_input(net, L, net.act, x);
-        conv_backward_filter(L, x, dy, dw);
+        if (net.conv_algo == 1) conv_backward_filter_gemm(L, x, dy, dw); else conv_backward_filter(L, x, dy, dw);
         from_tap_major_add(L, dw.data(), net.grads.data() + L.w_off);
         if (L.in_a >= 0) {
             std::vector<float> wt = layer_weights(net, L);
             Tensor dx; dx.resize(x.n, x.h, x.w, x.c);
-            conv_backward_data(L, wt, dy, dx);
+            if (net.conv_algo == 1) conv_backward_data_gemm(L, wt, dy, dx); else conv_backward_data(L, wt, dy, dx);
             const bool r = net.emulate_bf16;
             Tensor& ta = net.dact[L.in_a];
+#pragma omp parallel for schedule(static)
             for (size_t i = 0; i < dx.d.size(); ++i) { ta.d[i] += dx.d[i]; if (r) ta.d[i] = bf16r(ta.d[i]); }
-            if (L.in_b >= 0) { Tensor& tb = net.dact[L.in_b]; for (size_t i = 0; i < dx.d.size(); ++i) { tb.d[i] += dx.d[i]; if (r) tb.d[i] = bf16r(tb.d[i]); } }
+            if (L.in_b >= 0) {
+                Tensor& tb = net.dact[L.in_b];
+#pragma omp parallel for schedule(static)
+                for (size_t i = 0; i < dx.d.size(); ++i) { tb.d[i] += dx.d[i]; if (r) tb.d[i] = bf16r(tb.d[i]); }
+            }
         }
     }
     if (!apply_update) return;
@@ -660,6 +893,7 @@ double* orc_net_running_updates(void* h) { return ((Net*)h)->running_count.data(
 void orc_net_set_hyper(void* h, double lr, double wd, double mom, unsigned long bn_window) {
     Net* n = (Net*)h; n->lr = lr; n->weight_decay = wd; n->mom = mom; n->bn_window = bn_window;
 }
+void orc_net_set_conv_algorithm(void* h, int algo) { ((Net*)h)->conv_algo = algo == 1 ? 1 : 0; }
 void orc_net_set_bf16_emulation(void* h, int mode) { ((Net*)h)->emulate_bf16 = mode < 0 ? 0 : mode; }
 int orc_required_input_dim(void* h) { return required_dim(((Net*)h)->spec); }
 int orc_recommended_input_dim(int levels, int n) { return recommended_dim(levels, n); }

@@ -65,6 +65,7 @@ def lib():
         L.orc_net_running_updates.argtypes = [C.c_void_p]
         L.orc_net_set_hyper.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_ulong]
         L.orc_net_set_bf16_emulation.argtypes = [C.c_void_p, C.c_int]
+        L.orc_net_set_conv_algorithm.argtypes = [C.c_void_p, C.c_int]
         L.orc_required_input_dim.argtypes = [C.c_void_p]
         L.orc_recommended_input_dim.argtypes = [C.c_int, C.c_int]
         L.orc_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
@@ -152,6 +153,11 @@ class OracleNet:
         raw conv outputs, inference passes the activations (on=2: raw outputs in inference too, the library under
         ANH_INFER_POST_ACT=0)."""
         self.L.orc_net_set_bf16_emulation(self.h, int(on))
+
+    def set_conv_algorithm(self, algo):
+        """0: direct convolution loops (the parity oracle, one k-ordered fmaf chain per output); 1: im2col + blocked SGEMM with OpenMP
+        reductions — dlib's CPU design (cpu_dlib.cpp + BLAS), the form bench.py times as cpu_baseline."""
+        self.L.orc_net_set_conv_algorithm(self.h, int(algo))
 
     def required_input_dim(self):
         return self.L.orc_required_input_dim(self.h)

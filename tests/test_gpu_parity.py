@@ -336,6 +336,32 @@ def test_bf16_training_step(levels, scaler, minf, in_ch):
 # ------------------------------------------------------------------------------------------------------------------
 # full-size cases (BASELINE.json configs) and the RCCL plumbing
 # ------------------------------------------------------------------------------------------------------------------
+def test_single_227_tile_through_annonet_infer_on_the_benchmark_net():
+    """BASELINE config [0] on the HIP path: ONE 227 x 227 x 3 random tile of the benchmark net (levels 2, width 1.0, K = 3) through
+    annonet_infer() — tiles.size() == 1, unique == full, no blend ramps (/root/reference/annonet_infer.cpp:42-66,147).
+    fp32: planes and label map bit-exact against the oracle; bf16: the near-tie bar of test_bf16_forward."""
+    img = np.random.default_rng(227).integers(0, 256, (227, 227, 3), dtype=np.uint8)
+    o, net = pair(2, 3, 3, 1.0, 1, aa.ANH_FP32, seed=31)
+    assert o.recommended_input_dim(227) == 227 and len(aa.tiling.get_tiles(227, 227, aa.tiling.parameters(1024, 1024, 35, 35))) == 1
+    want_labels, want = o.infer(img, want_blended=True)
+    labels, planes = aa.annonet_infer(net, img, want_blended=True)
+    np.testing.assert_array_equal(planes, want)
+    np.testing.assert_array_equal(labels, want_labels)
+    np.testing.assert_array_equal(planes, net.Forward(img))          # one tile: the planes ARE the net's output
+    _, net16 = pair(2, 3, 3, 1.0, 1, aa.ANH_BF16, seed=31)
+    labels16, planes16 = aa.annonet_infer(net16, img, want_blended=True)
+    span = want.max() - want.min()
+    tol = 0.03 * span
+    assert np.abs(planes16 - want).max() <= tol
+    mism = labels16 != want_labels
+    srt = np.sort(want, axis=0)
+    assert mism.mean() <= 0.03 and ((srt[-1] - srt[-2])[mism] <= 2 * tol).all()      # only near-ties may flip
+    o.set_bf16_emulation(1 if net16.stores_activations() else 2)
+    emu_labels, emu = o.infer(img, want_blended=True)
+    assert np.abs(planes16 - emu).max() <= 6e-3 * span and np.abs(planes16 - emu).mean() <= 2e-4 * span
+    assert (labels16 != emu_labels).mean() <= 2e-3
+
+
 def test_full_size_training_step_batch32_227():
     """BASELINE config [1]: batch 32 x 3 x 227 x 227, levels 2, width 1.0.  fp32 parity mode against the oracle (which needs
     ~15 s of host time for this batch), and the bf16 mode's loss against both oracles."""
