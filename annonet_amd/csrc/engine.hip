@@ -462,7 +462,8 @@ void Engine::wgrad_dispatch(WgradArgs& a, const char* tag, double flops, double 
     a.splits_out = nullptr;
     if (splits > 0) {  // fixed-order sum of the per-workgroup partials
         const int64_t nw = (int64_t)a.k * a.k * a.c_in * a.c_out;
-        tok = prof.begin(on, "wgrad_reduce_partials", 0, (double)splits * nw * 4.0);
+        // (the reduce of a filter gradient that runs on the MAIN stream — the stem's, in the step's tail — has a name of its own: bench.py's critical_path)
+        tok = prof.begin(on, (on == stream && aux_stream && concurrent_wgrad) ? "wgrad_reduce_partials_main" : "wgrad_reduce_partials", 0, (double)splits * nw * 4.0);
         launch_reduce_partials(a.partials, splits, nw, a.dw, on);
         prof.end(on, tok);
     }

@@ -2181,8 +2181,25 @@ void launch_crop_weights(const uint16_t* d_labels, const float* d_table, int n, 
     HIP_CHECK(hipGetLastError());
 }
 
+// Zero fill as a streaming kernel: the runtime's fill (hipMemsetAsync -> fillBufferAligned) clears the 201 MB of class planes of a
+// 4096^2 image in ~560 us (0.36 TB/s, profiles/r03_infer_kernel_stats.csv) — a seventh of that image's time; 16-byte stores from
+// 2048 workgroups run at the HBM write rate.
+namespace {
+__global__ __launch_bounds__(256) void fill_zero_kernel(uint4* p, size_t n16, unsigned char* tail, int tail_bytes) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride) p[i] = z;
+    if (blockIdx.x == 0 && (int)threadIdx.x < tail_bytes) tail[threadIdx.x] = 0;
+}
+}  // namespace
+
 void launch_fill_zero(void* p, size_t bytes, hipStream_t s) {
-    if (bytes) HIP_CHECK(hipMemsetAsync(p, 0, bytes, s));
+    if (!bytes) return;
+    if (bytes < (size_t)1 << 20 || (reinterpret_cast<uintptr_t>(p) & 15)) { HIP_CHECK(hipMemsetAsync(p, 0, bytes, s)); return; }
+    const size_t n16 = bytes >> 4;
+    const int blocks = (int)std::min<size_t>(2048, (n16 + 255) / 256);
+    hipLaunchKernelGGL(fill_zero_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<uint4*>(p), n16, reinterpret_cast<unsigned char*>(p) + (n16 << 4), (int)(bytes & 15));
+    HIP_CHECK(hipGetLastError());
 }
 
 }  // namespace anh

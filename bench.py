@@ -62,6 +62,7 @@ def _latest_profile(suffix):
 # (tools/collect_profiles.sh points these at the counter passes it has just made on the same box)
 TRAFFIC_JSON = os.environ.get("ANH_TRAFFIC_JSON") or _latest_profile("traffic.json")
 INFER_TRAFFIC_JSON = os.environ.get("ANH_INFER_TRAFFIC_JSON") or _latest_profile("infer_traffic.json")
+SQ_JSON = os.environ.get("ANH_SQ_JSON") or _latest_profile("sq_counters.json")
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -161,6 +162,7 @@ def split_entries(prof, layers, dims, n, per_steps):
                    "design_mb": round(e["bytes"] / e["launches"] / 1e6, 2), "flop_per_byte": round(flops / min_bytes, 1)}
             b = bound_of(flops, min_bytes, t_us * 1e-6)
             row.update(bound=b["bound"], floor_us=round(b["floor_us"], 2), frac=round(b["frac"], 4), achieved=round(b["achieved"], 1), unit=b["unit"])
+            row["mfma_busy_pct"] = mfma_busy(e["name"])
             convs.append(row)
         else:
             other.append({"entry": e["name"], "launches_per_step": e["launches"] / per_steps, "us_per_step": round(1e3 * e["total_ms"] / per_steps, 2),
@@ -178,6 +180,52 @@ def pmc_traffic(entry, path=None):
         return e["traffic_bytes_per_launch"] if e else None
     except (OSError, ValueError, KeyError):
         return None
+
+
+def mfma_busy(entry):
+    """Matrix-pipe occupancy of a profiler entry from the committed SQ counter pass (tools/pmc_counters.py): SQ_VALU_MFMA_BUSY_CYCLES
+    (cycles, summed over the 1024 SIMDs: 32 per v_mfma_f32_32x32x16_bf16) over the kernel's own cycles x 1024 SIMDs, the kernel's cycles
+    being SQ_BUSY_CYCLES / 32 (the counter is summed over the 32 shader engines).  None without a counter pass for the entry."""
+    try:
+        with open(SQ_JSON) as f:
+            e = json.load(f)["entries"].get(entry)
+        if not e or not e.get("SQ_BUSY_CYCLES") or "SQ_VALU_MFMA_BUSY_CYCLES" not in e:
+            return None
+        return round(100.0 * e["SQ_VALU_MFMA_BUSY_CYCLES"] / (e["SQ_BUSY_CYCLES"] / 32.0 * 1024.0), 1)
+    except (OSError, ValueError, KeyError):
+        return None
+
+
+def critical_path(prof, per_steps, step_us):
+    """us per step on the MAIN stream (the step's critical path), from the event pairs of the untimed profile pass: the second stream's
+    filter gradients are listed as `hidden`.  `gaps` = step time - sum of the main-stream kernels: the cross-queue hand-over packets
+    (one per filter gradient handed to the second stream), the join and launch boundaries."""
+    acc = {"forward": 0.0, "head": 0.0, "backward_data": 0.0, "apply": 0.0, "tail": 0.0, "hidden_second_stream": 0.0}
+    for e in prof:
+        us = 1e3 * e["total_ms"] / per_steps
+        n = e["name"]
+        m = ENTRY_RE.search(n)
+        if m and m.group(1) == "fwd":
+            acc["forward"] += us
+        elif m and m.group(1) == "dgrad":
+            acc["backward_data"] += us
+        elif m and m.group(1) == "wgrad":
+            acc["tail" if int(m.group(2)) == 0 else "hidden_second_stream"] += us
+        elif n.startswith("head_") or n in ("softmax_logloss",):
+            acc["head"] += us
+        elif n.startswith("bn_bwd_") or n.startswith("bn_"):
+            acc["apply"] += us
+        elif n in ("wgrad_reduce_partials_main", "sgd_momentum_wd"):
+            acc["tail"] += us
+        elif n == "wgrad_reduce_partials":
+            acc["hidden_second_stream"] += us
+        else:
+            acc["tail"] += us
+    main = sum(v for k, v in acc.items() if k != "hidden_second_stream")
+    out = {k: round(v, 1) for k, v in acc.items()}
+    out.update(main_stream_kernels=round(main, 1), step=round(step_us, 1), gaps=round(step_us - main, 1),
+               note="kernel durations by HIP events in the untimed profile pass (every launch instrumented); step = the timed region's ms_per_step; forward = stem + 3x3 convs, head = fused 1x1 head + loss + its backward, apply = bn backward apply passes (8 launches), tail = stem filter gradient + its reduce + SGD update")
+    return out
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -669,6 +717,28 @@ def main():
     t.synchronize()
     dom = [e for e in t.profile() if e["name"] == dominant]
     loss = t.get_last_loss()
+    # The same K steps with the mini-batch handed over as HOST vectors every step, the way the reference's loop drives StartTraining
+    # (/root/reference/annonet_train_main.cpp:585-609: 32 images + 32 weighted-label images per call; anh_trainer_step packs them into
+    # pinned staging, uploads and runs the step behind the upload) — same step count, same instrumentation (event pairs on the dominant
+    # entry, sampled).  PCIe-inclusive: reported beside `value`, never as it.  One process per GPU only (the N > 1 job feeds resident shards).
+    elapsed_host = None
+    if world == 1 and not use_dist:
+        import ctypes as C
+        wl = [aa.set_weights(lab[i], 0.5, 0.5) for i in range(BATCH)]
+        imgs = [np.ascontiguousarray(img[i]) for i in range(BATCH)]
+        ip = (C.c_void_p * BATCH)(*[a.ctypes.data for a in imgs])
+        lp = (C.c_void_p * BATCH)(*[a.ctypes.data for a in wl])
+
+        def host_step():
+            aa._lib.check(t.L.anh_trainer_step(t.h, ip, lp, BATCH, TILE, TILE))
+        for _ in range(max(args.warmup, 3)):
+            host_step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            host_step()
+        fence()
+        elapsed_host = time.perf_counter() - t0
     t.profile_enable(False)
 
     if rank == 0:
@@ -691,7 +761,11 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": f"training step (fwd+loss+bwd+SGD), batch {BATCH}x3x{TILE}x{TILE} per GPU, encoder-decoder levels={LEVELS} width={WIDTH} K={CLASSES}, random init",
                        "global_batch": BATCH * world, "parallelism": f"dp{world}"},
+            "value_host_inputs": None if elapsed_host is None else BATCH * args.steps / elapsed_host,
+            "value_note": "value: the mini-batch resident in HBM when the timed region starts; value_host_inputs: the same K steps through anh_trainer_step with 32 host images + 32 host weighted-label images handed over every step (reference loop annonet_train_main.cpp:585-609; PCIe-inclusive, same step count and instrumentation)",
             "roofline": roof,
+            "critical_path": critical_path(prof_all, PROFILE_STEPS, 1e3 * ms),
+            "mfma_busy_note": "layers[].mfma_busy_pct = SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CYCLES / 32 shader engines x 1024 SIMDs) from the committed counter pass " + os.path.basename(SQ_JSON) + " (kernels serialised by the profiler); cycles at the clock the kernel held, not the 2.4 GHz of the 2.5 PFLOP/s peak",
             "step_roofline": {"gflop_per_step": round(step_gflop, 1), "achieved_tflops": round(step_gflop / ms, 1), "frac_of_bf16_mfma_peak": round(step_gflop / ms / PEAK_BF16_TFLOPS, 4),
                               "sum_of_layer_floors_us": round(sum(r["floor_us"] for r in layer_rows), 1)},
             "layers": layer_rows,

@@ -153,7 +153,24 @@ int required_dim(const Spec& s) {  // receptive field side of one output pixel
 struct Tensor {  // NHWC fp32
     int n = 0, h = 0, w = 0, c = 0;
     std::vector<float> d;
-    void resize(int n_, int h_, int w_, int c_) { n = n_; h = h_; w = w_; c = c_; d.assign((size_t)n * h * w * c, 0.f); }
+    // all zeros afterwards; a tensor that keeps its size (scratch reused from step to step) is cleared by the thread team instead of
+    // being re-created by one thread (which, once the convs run as GEMMs, was a third of a training step)
+    void resize(int n_, int h_, int w_, int c_) {
+        n = n_; h = h_; w = w_; c = c_;
+        const size_t total = (size_t)n * h * w * c;
+        if (d.size() != total) { d.assign(total, 0.f); return; }
+        float* p = d.data();
+#pragma omp parallel for schedule(static)
+        for (size_t i = 0; i < total; ++i) p[i] = 0.f;
+    }
+    void copy_from(const Tensor& o) {   // *this = o, element copies spread over the thread team
+        n = o.n; h = o.h; w = o.w; c = o.c;
+        if (d.size() != o.d.size()) d.resize(o.d.size());
+        float* p = d.data(); const float* q = o.d.data();
+        const size_t total = o.d.size();
+#pragma omp parallel for schedule(static)
+        for (size_t i = 0; i < total; ++i) p[i] = q[i];
+    }
     size_t pixels() const { return (size_t)n * h * w; }
     float* px(int in, int y, int x) { return d.data() + (((size_t)in * h + y) * w + x) * c; }
     const float* px(int in, int y, int x) const { return d.data() + (((size_t)in * h + y) * w + x) * c; }
@@ -512,7 +529,7 @@ struct Net {
     int conv_algo = 0;
     // scratch
     std::vector<Tensor> raw, act, dact;
-    Tensor image;
+    Tensor image, sx, sdy, sdx;   // sx / sdy / sdx: a layer's gathered input, dy and dx (reused across layers and steps)
     std::vector<float> logits_nchw;
     double last_loss = 0;
 };
@@ -541,7 +558,7 @@ void affine_from_running(const Net& net, const Layer& L, std::vector<float>& sca
 
 void gather_input(const Net& net, const Layer& L, const std::vector<Tensor>& act, Tensor& x) {
     const Tensor& a = L.in_a < 0 ? net.image : act[L.in_a];
-    if (L.in_b == -2) x = a;
+    if (L.in_b == -2) x.copy_from(a);
     else {
         const Tensor& b = act[L.in_b];
         x.resize(a.n, a.h, a.w, a.c);
@@ -587,7 +604,7 @@ void forward(Net& net, bool training, std::vector<BnBatch>* bn_out) {
     const int nl = (int)s.layers.size();
     net.raw.resize(nl); net.act.resize(nl);
     if (bn_out) bn_out->assign(nl, BnBatch());
-    Tensor x;
+    Tensor& x = net.sx;
     for (int li = 0; li < nl; ++li) {
         const Layer& L = s.layers[li];
         gather_input(net, L, net.act, x);
@@ -686,12 +703,13 @@ void train_step(Net& net, const uint8_t* images, const uint16_t* labels, const f
     if (logits.h != h || logits.w != w) throw std::runtime_error("input size is not a valid net input dimension");
     for (size_t p = 0; p < (size_t)n * h * w; ++p)
         if (labels[p] != kIgnore && labels[p] >= s.classes) throw std::runtime_error("label out of range");
-    net.dact.assign(nl, Tensor());
+    net.dact.resize(nl);   // (each tensor is cleared by the resize below)
     for (int li = 0; li < nl; ++li) { const Tensor& a = net.act[li]; net.dact[li].resize(a.n, a.h, a.w, a.c); }
     const double scale = 1.0 / (loss_scale_n * (double)h * (double)w);
     net.last_loss = loss_and_grad(logits, labels, weights, scale, net.dact[nl - 1]);
     net.grads.assign(net.params.size(), 0.f);
-    Tensor x, dy;
+    Tensor& x = net.sx;
+    Tensor& dy = net.sdy;
     std::vector<double> dw;
     for (int li = nl - 1; li >= 0; --li) {
         const Layer& L = s.layers[li];
@@ -722,7 +740,7 @@ void train_step(Net& net, const uint8_t* images, const uint16_t* labels, const f
                 }
             if (net.emulate_bf16) round_tensor(dy.d);
         } else {
-            dy.d = da.d;
+            dy.copy_from(da);
             if (L.has_bias) {
                 std::vector<double> dbias(C, 0.0);
                 for (size_t p = 0; p < P; ++p) for (int c = 0; c < C; ++c) dbias[c] += da.d[p * C + c];
@@ -734,7 +752,7 @@ void train_step(Net& net, const uint8_t* images, const uint16_t* labels, const f
         from_tap_major_add(L, dw.data(), net.grads.data() + L.w_off);
         if (L.in_a >= 0) {
             std::vector<float> wt = layer_weights(net, L);
-            Tensor dx; dx.resize(x.n, x.h, x.w, x.c);
+            Tensor& dx = net.sdx; dx.resize(x.n, x.h, x.w, x.c);
             if (net.conv_algo == 1) conv_backward_data_gemm(L, wt, dy, dx); else conv_backward_data(L, wt, dy, dx);
             const bool r = net.emulate_bf16;
             Tensor& ta = net.dact[L.in_a];

@@ -48,6 +48,18 @@ def test_training_bench_line():
     assert abs(sum(x["gflop"] for x in rows) - (564.6 - 3 * 0.32 - 7.91)) < 1.5      # 564.6 GFLOP per step incl. the 1x1 head (3 passes) and the stem's absent bwd-data
     assert any(o["entry"].startswith("bn_") for o in d["overhead_kernels"])
     assert d["ranks_seen"] == 1 and d["devices"] == [0]
+    # round 4: the host-vector rate of the same K steps (the reference loop's StartTraining), the main stream's critical path, and the
+    # matrix-pipe occupancy of every conv entry with its denominator stated — shapes only
+    assert d["value_host_inputs"] > 0 and "PCIe-inclusive" in d["value_note"]
+    cp = d["critical_path"]
+    for k in ("forward", "head", "backward_data", "apply", "tail", "hidden_second_stream", "main_stream_kernels", "step", "gaps"):
+        assert isinstance(cp[k], float), k
+    assert cp["forward"] > 0 and cp["backward_data"] > 0 and cp["apply"] > 0 and cp["tail"] > 0 and cp["hidden_second_stream"] > 0
+    assert abs(cp["step"] - 1e3 * d["ms_per_step"]) < 0.1 and abs(cp["main_stream_kernels"] + cp["gaps"] - cp["step"]) < 0.2
+    assert "SQ_VALU_MFMA_BUSY_CYCLES" in d["mfma_busy_note"] and "SQ_BUSY_CYCLES" in d["mfma_busy_note"]
+    for x in rows:
+        assert x["mfma_busy_pct"] is None or 0 < x["mfma_busy_pct"] < 100
+    assert "direct_oracle" in c and "im2col" in c["sample"]
     # the same line carries tiled inference (BASELINE.json configs[2]), measured by a child process after the training measurement
     i = d["infer"]
     assert "error" not in i, i
