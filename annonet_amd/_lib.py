@@ -38,6 +38,14 @@ class WLabel(C.Structure):
     _fields_ = [("label", C.c_uint16), ("weight", C.c_float)]
 
 
+class ExchangeStats(C.Structure):   # anh_exchange_stats
+    _fields_ = [("replicas", C.c_int), ("early_reduce", C.c_int), ("uses_rccl", C.c_int), ("rccl_version", C.c_int),
+                ("steps", C.c_int64), ("samples", C.c_int64), ("worker_calls", C.c_int64), ("bucket_bytes", C.c_int64),
+                ("host_us_mean", C.c_double), ("host_us_last", C.c_double),
+                ("allreduce_tail_us_mean", C.c_double), ("allreduce_head_us_mean", C.c_double),
+                ("allreduce_tail_us_last", C.c_double), ("allreduce_head_us_last", C.c_double)]
+
+
 class Rect(C.Structure):
     _fields_ = [("left", C.c_long), ("top", C.c_long), ("right", C.c_long), ("bottom", C.c_long)]
 
@@ -155,6 +163,11 @@ _SIGNATURES = {  # ConvDesc / OpInput are defined above
     "anh_trainer_replica_params": (C.c_int, [_P, C.c_int, _P, C.c_int64]),
     "anh_set_devices": (C.c_int, [C.POINTER(C.c_int), C.c_int]),
     "anh_handle_replicas": (C.c_int, [_P, C.c_int]),
+    "anh_trainer_exchange_stats": (C.c_int, [_P, C.POINTER(ExchangeStats)]),
+    "anh_trainer_reset_exchange_stats": (None, [_P]),
+    "anh_host_register": (C.c_int, [_P, C.c_size_t]),
+    "anh_host_unregister": (C.c_int, [_P]),
+    "anh_labels_rect_to_host": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "anh_shard_range": (C.c_int, [C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "anh_cross_replica_overlaps": (C.c_int, [C.POINTER(Tile), C.c_size_t, C.c_int, C.c_int, C.c_int, C.POINTER(C.POINTER(Rect)), C.POINTER(C.c_size_t)]),
     "anh_profile_launch_order": (C.c_int, [_P, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),

@@ -43,6 +43,9 @@ struct BlobHeader {
 
 namespace anh { void set_last_error(const std::string& message) { g_error = message; } }
 
+// ANH_REPLICA_WORKERS=0: round 3's form (threads created and joined on every call) for the before / after figure of DESIGN.md §6
+static bool persistent_workers() { static const bool on = !(getenv("ANH_REPLICA_WORKERS") && atoi(getenv("ANH_REPLICA_WORKERS")) == 0); return on; }
+
 struct anh_runtime {
     std::unique_ptr<Engine> eng;          // replica 0 (the only one unless anh_set_devices named several devices)
     // anh_set_devices: one process drives several GPUs.  Replica r lives on devices[r]; every replica holds the same weights;
@@ -51,6 +54,8 @@ struct anh_runtime {
     struct Replica { std::unique_ptr<Engine> eng; };
     std::vector<Replica> extra;           // replicas 1 .. R-1
     std::unique_ptr<Collective> coll;
+    std::unique_ptr<ReplicaWorkers> workers;   // persistent host threads, one per replica beyond the first (multidev.h)
+    template <class F> void each_replica(F&& fn) { if (workers && persistent_workers()) workers->run(fn); else for_each_replica(replicas(), fn); }
     struct Exchange { DevBuf packed, rects, offsets; };
     std::vector<Exchange> exchange;       // per replica: scratch of the overlap exchange
     size_t replicas() const { return 1 + extra.size(); }
@@ -62,7 +67,7 @@ struct anh_runtime {
         if (only_device >= 0) devices.assign(1, only_device);
         { DeviceScope scope(device_of(0)); eng = std::make_unique<Engine>(cfg, false); }
         for (size_t r = 1; r < devices.size(); ++r) { DeviceScope scope(devices[r]); extra.push_back(Replica{std::make_unique<Engine>(cfg, false)}); }
-        if (devices.size() > 1) coll = std::make_unique<Collective>(devices);
+        if (devices.size() > 1) { coll = std::make_unique<Collective>(devices); workers = std::make_unique<ReplicaWorkers>(devices); }
         exchange.resize(replicas());
     }
     void set_params_all(const float* params, const float* running) {
@@ -134,6 +139,28 @@ struct anh_trainer {
     struct Replica { std::unique_ptr<Engine> eng; StageSet stage[2]; hipStream_t copy_stream = nullptr; };
     std::vector<std::unique_ptr<Replica>> extra;   // replicas 1 .. R-1
     std::unique_ptr<Collective> coll;
+    std::unique_ptr<ReplicaWorkers> workers;       // persistent host threads, one per replica beyond the first (multidev.h)
+    template <class F> void each_replica(F&& fn) { if (workers && persistent_workers()) workers->run(fn); else for_each_replica(replicas(), fn); }
+    // what one StartTraining costs the host, and the exchange step on the device (anh_trainer_exchange_stats): host time of every call;
+    // on every `xs_every`-th step an event pair around each part of the all-reduce on replica 0's streams (ANH_EXCHANGE_SAMPLE, default 8, 0 = never)
+    struct ExchangeStats {
+        int64_t calls = 0; double host_us_sum = 0, host_us_last = 0;
+        hipEvent_t tail0 = nullptr, tail1 = nullptr, head0 = nullptr, head1 = nullptr;
+        bool pending = false, split = false;
+        int64_t samples = 0; double tail_us_sum = 0, head_us_sum = 0, tail_us_last = 0, head_us_last = 0;
+    } xs;
+    void collect_exchange_sample() {   // the pair of a sampled step, once that step has finished (blocks until then)
+        if (!xs.pending) return;
+        DeviceScope scope(device_of(0));
+        float ms = 0;
+        HIP_CHECK(hipEventSynchronize(xs.head1));
+        HIP_CHECK(hipEventElapsedTime(&ms, xs.head0, xs.head1));
+        xs.head_us_last = 1e3 * ms; xs.head_us_sum += xs.head_us_last;
+        xs.tail_us_last = 0;
+        if (xs.split) { HIP_CHECK(hipEventSynchronize(xs.tail1)); HIP_CHECK(hipEventElapsedTime(&ms, xs.tail0, xs.tail1)); xs.tail_us_last = 1e3 * ms; xs.tail_us_sum += xs.tail_us_last; }
+        ++xs.samples;
+        xs.pending = false;
+    }
     size_t replicas() const { return devices.size() > 1 ? devices.size() : 1; }
     int device_of(size_t r) const { return devices.empty() ? -1 : devices[r]; }
     Engine& replica(size_t r) { return r == 0 ? *eng : *extra[r - 1]->eng; }
@@ -157,6 +184,7 @@ struct anh_trainer {
                 extra.push_back(std::move(rep));
             }
             if (replicas() > 1 && !coll) coll = std::make_unique<Collective>(devices);
+            if (replicas() > 1 && !workers) workers = std::make_unique<ReplicaWorkers>(devices);
             dirty = false;
         }
         if (resume_pending) {   // the reference names the file BEFORE SetClassCount (annonet_train_main.cpp:400-405): resume on first use
@@ -202,6 +230,8 @@ struct anh_trainer {
         if (!pending.empty()) last_loss = pending.back().value;
     }
     ~anh_trainer() {
+        workers.reset();   // the worker threads first: nothing of theirs outlives the replicas
+        for (hipEvent_t ev : {xs.tail0, xs.tail1, xs.head0, xs.head1}) if (ev) (void)hipEventDestroy(ev);
         if (loss_ring) (void)hipHostFree(loss_ring);
         for (auto& st : stage) {
             if (st.pinned) (void)hipHostFree(st.pinned);
@@ -309,6 +339,24 @@ int anh_set_devices(const int* devices, int n) {
 int anh_handle_replicas(void* handle, int is_trainer) {
     if (!handle) return 0;
     return is_trainer ? (int)((anh_trainer*)handle)->replicas() : (int)((anh_runtime*)handle)->replicas();
+}
+int anh_host_register(void* p, size_t bytes) {
+    return guarded([&] { ANH_REQUIRE(p && bytes, "host register: null block"); HIP_CHECK(hipHostRegister(p, bytes, hipHostRegisterDefault)); });
+}
+int anh_host_unregister(void* p) {
+    return guarded([&] { ANH_REQUIRE(p, "host unregister: null block"); HIP_CHECK(hipHostUnregister(p)); });
+}
+int anh_labels_rect_to_host(const uint16_t* d_labels, uint16_t* h_labels, int width, int height, int left, int top, int right, int bottom, void* stream) {
+    return guarded([&] {
+        ANH_REQUIRE(d_labels && h_labels && width >= 1 && height >= 1, "labels to host: null map");
+        ANH_REQUIRE(left >= 0 && top >= 0 && right < width && bottom < height && left <= right && top <= bottom, "labels to host: rectangle outside the map");
+        const size_t off = (size_t)top * width + left;
+        if (left == 0 && right == width - 1)   // whole rows: one contiguous block
+            HIP_CHECK(hipMemcpyAsync(h_labels + off, d_labels + off, (size_t)(bottom - top + 1) * width * 2, hipMemcpyDeviceToHost, (hipStream_t)stream));
+        else
+            HIP_CHECK(hipMemcpy2DAsync(h_labels + off, (size_t)width * 2, d_labels + off, (size_t)width * 2, (size_t)(right - left + 1) * 2, (size_t)(bottom - top + 1),
+                                       hipMemcpyDeviceToHost, (hipStream_t)stream));
+    });
 }
 int anh_shard_range(int64_t n, int world, int rank, int64_t* lo, int64_t* hi) {
     return guarded([&] { ANH_REQUIRE(lo && hi && world >= 1 && rank >= 0 && rank < world && n >= 0, "shard range: bad argument"); shard_range(n, world, rank, *lo, *hi); });
@@ -616,7 +664,7 @@ void infer_multi(anh_runtime* h, const uint8_t* image, int H, int W, const doubl
     std::vector<float*> packed(R, nullptr);
     std::vector<hipStream_t> streams(R);
     std::vector<int64_t> lo(R), hi(R);
-    for_each_replica(R, [&](size_t r) {
+    h->each_replica([&](size_t r) {
         DeviceScope scope(h->device_of(r));
         Engine& e = h->replica(r);
         shard_range((int64_t)tiles.size(), (int)R, (int)r, lo[r], hi[r]);
@@ -640,7 +688,7 @@ void infer_multi(anh_runtime* h, const uint8_t* image, int H, int W, const doubl
     });
     // the table's host vectors must outlive the async uploads: every replica's stream passes the uploads before the collective returns control below
     if (total > 0) h->coll->all_reduce_sum(packed, (size_t)K * total, streams);   // the ONE exchange step of the path
-    for_each_replica(R, [&](size_t r) {
+    h->each_replica([&](size_t r) {
         DeviceScope scope(h->device_of(r));
         Engine& e = h->replica(r);
         if (hi[r] == lo[r]) return;
@@ -906,7 +954,8 @@ int anh_trainer_step(anh_trainer* h, const uint8_t* const* images, const anh_wla
         // data parallel (annonet_train_main.cpp:583-614): replica r takes samples [n r / R, n (r+1) / R); the loss
         // scale 1/(N nr nc) uses the WHOLE batch, so the exchange step is a plain sum of the gradient buckets
         std::vector<anh_trainer::StageSet*> used(R, nullptr);
-        for_each_replica(R, [&](size_t r) {   // packing, upload and the step's launches of every replica in parallel
+        const auto host_t0 = std::chrono::steady_clock::now();
+        h->each_replica([&](size_t r) {   // packing, upload and the step's launches of every replica in parallel (persistent worker threads)
             DeviceScope scope(h->device_of(r));
             int64_t lo, hi;
             shard_range(n, (int)R, (int)r, lo, hi);
@@ -918,7 +967,18 @@ int anh_trainer_step(anh_trainer* h, const uint8_t* const* images, const anh_wla
             for (size_t r = 0; r < R; ++r) { buckets[r] = h->replica(r).grad_bucket(); streams[r] = h->replica(r).stream; }
             const int64_t count = (int64_t)h->eng->spec.n_params + 1, first = h->eng->early_grad_first();   // the trailing slot carries the loss
             static const bool early_on = !(getenv("ANH_EARLY_REDUCE") && atoi(getenv("ANH_EARLY_REDUCE")) == 0);
-            if (early_on && first > 0 && first < count - 1) {
+            static const int xs_every = getenv("ANH_EXCHANGE_SAMPLE") ? atoi(getenv("ANH_EXCHANGE_SAMPLE")) : 8;
+            anh_trainer::ExchangeStats& xs = h->xs;
+            const bool split = early_on && first > 0 && first < count - 1;
+            bool sample = false;
+            if (xs_every > 0 && h->host_steps % (unsigned long)xs_every == (unsigned long)xs_every - 1) {
+                h->collect_exchange_sample();   // (the previous sampled step ended long ago)
+                DeviceScope scope(h->device_of(0));
+                if (!xs.head0) for (hipEvent_t* ev : {&xs.tail0, &xs.tail1, &xs.head0, &xs.head1}) HIP_CHECK(hipEventCreate(ev));
+                sample = true;
+                xs.split = split;
+            }
+            if (split) {
                 // the tail of the bucket (every layer but the first two, head, loss) is final while backward still runs
                 // (Engine::ev_early_grads): reduce it on side streams now, the short head on the replicas' own streams afterwards
                 std::vector<float*> tails(R);
@@ -930,15 +990,22 @@ int anh_trainer_step(anh_trainer* h, const uint8_t* const* images, const anh_wla
                     HIP_CHECK(hipStreamWaitEvent(side[r], e.ev_early_grads, 0));
                     tails[r] = buckets[r] + first;
                 }
+                if (sample) { DeviceScope scope(h->device_of(0)); HIP_CHECK(hipEventRecord(xs.tail0, side[0])); }
                 h->coll->all_reduce_sum(tails, (size_t)(count - first), side);
+                if (sample) { DeviceScope scope(h->device_of(0)); HIP_CHECK(hipEventRecord(xs.tail1, side[0])); HIP_CHECK(hipEventRecord(xs.head0, streams[0])); }
                 h->coll->all_reduce_sum(buckets, (size_t)first, streams);
+                if (sample) { DeviceScope scope(h->device_of(0)); HIP_CHECK(hipEventRecord(xs.head1, streams[0])); xs.pending = true; }
                 for (size_t r = 0; r < R; ++r) {   // the update reads the whole bucket
                     DeviceScope scope(h->device_of(r));
                     Engine& e = h->replica(r);
                     HIP_CHECK(hipEventRecord(e.ev_early_reduced, side[r]));
                     HIP_CHECK(hipStreamWaitEvent(e.stream, e.ev_early_reduced, 0));
                 }
-            } else h->coll->all_reduce_sum(buckets, (size_t)count, streams);
+            } else {
+                if (sample) { DeviceScope scope(h->device_of(0)); HIP_CHECK(hipEventRecord(xs.head0, streams[0])); }
+                h->coll->all_reduce_sum(buckets, (size_t)count, streams);
+                if (sample) { DeviceScope scope(h->device_of(0)); HIP_CHECK(hipEventRecord(xs.head1, streams[0])); xs.pending = true; }
+            }
         }
         const int rc = anh_trainer_apply_update(h, 1.0);
         if (rc != ANH_OK) fail(rc, g_error);
@@ -948,7 +1015,39 @@ int anh_trainer_step(anh_trainer* h, const uint8_t* const* images, const anh_wla
             used[r]->in_flight = true;
         }
         ++h->host_steps;
+        h->xs.host_us_last = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - host_t0).count();
+        h->xs.host_us_sum += h->xs.host_us_last;
+        ++h->xs.calls;
     });
+}
+
+int anh_trainer_exchange_stats(anh_trainer* h, anh_exchange_stats* out) {
+    return guarded([&] {
+        ANH_REQUIRE(h && out, "null argument");
+        h->collect_exchange_sample();
+        const anh_trainer::ExchangeStats& xs = h->xs;
+        *out = anh_exchange_stats{};
+        out->replicas = (int)h->replicas();
+        out->steps = xs.calls;
+        out->host_us_mean = xs.calls ? xs.host_us_sum / (double)xs.calls : 0.0;
+        out->host_us_last = xs.host_us_last;
+        out->samples = xs.samples;
+        out->allreduce_tail_us_mean = xs.samples ? xs.tail_us_sum / (double)xs.samples : 0.0;
+        out->allreduce_head_us_mean = xs.samples ? xs.head_us_sum / (double)xs.samples : 0.0;
+        out->allreduce_tail_us_last = xs.tail_us_last;
+        out->allreduce_head_us_last = xs.head_us_last;
+        out->early_reduce = xs.split ? 1 : 0;
+        out->uses_rccl = h->coll && h->coll->uses_rccl() ? 1 : 0;
+        out->rccl_version = Collective::rccl_version();
+        out->worker_calls = h->workers ? (int64_t)h->workers->calls() : 0;
+        out->bucket_bytes = h->eng ? ((int64_t)h->eng->spec.n_params + 1) * 4 : 0;
+    });
+}
+void anh_trainer_reset_exchange_stats(anh_trainer* h) {
+    if (!h) return;
+    try { h->collect_exchange_sample(); } catch (...) {}
+    anh_trainer::ExchangeStats& xs = h->xs;
+    xs.calls = 0; xs.host_us_sum = 0; xs.samples = 0; xs.tail_us_sum = 0; xs.head_us_sum = 0;
 }
 
 int anh_trainer_grad_buffer(anh_trainer* h, void** d_ptr, int64_t* count) {

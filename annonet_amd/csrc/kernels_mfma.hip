@@ -1208,7 +1208,12 @@ struct GeoUp {
 // 16-byte channel chunk, hence 16 running sums instead of the consumers' NT x 32 — reads them back beside the y it has fetched
 // meanwhile.  In the backward-data convs the producers (plain-copy staging) wait at the hand-over barrier for a third to half of
 // the kernel while the consumers' epilogue is as long as their MFMA phase: this moves that work to where the slack is.
-template <class G, int NT, int KIND, bool FWD = false, bool ACT = false, bool PS = false, bool HEAD = false>
+// PS = 2 (round 4): the sums are SPLIT between the roles — the consumer waves keep them for the accumulator groups g < ACC / 2 (their
+// own y prefetch, their own per-lane running sums), the producer waves for the groups g >= ACC / 2 through the epilogue buffer.  In the
+// plain-copy (backward-data) forms the consumers' epilogue is as long as their MFMA phase while the producers wait at the hand-over
+// barrier for a third to half of the kernel; moving ALL of the sums over (PS = 1) made the producers the long pole in every geometry but
+// one — half of them balances the two roles.
+template <class G, int NT, int KIND, bool FWD = false, bool ACT = false, int PS = 0, bool HEAD = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tiles_x, int tiles_y, int flip, long long* prof, int wres_, int e_off) {
     // per-phase wall-clock accounting, compiled in with -DANH_WS_PROFILE (ANH_WS_PROF=1 then prints one line per launch)
 #ifdef ANH_WS_PROFILE
@@ -1256,10 +1261,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
     constexpr bool CAN_STATS = G::ACC * NT <= 4 || FWD;  // register budget of the consumer waves
     const bool fuse_stats = !PS && !ACT && CAN_STATS && (a.stat_partials != nullptr || a.stat_acc != nullptr);   // forward: bn statistics of the output
     const bool fuse_bnred = !FWD && (PS || CAN_STATS) && (a.bnred_partials != nullptr || a.bnred_acc != nullptr);  // backward-data: dgamma / dbeta sums of the layer `out` belongs to
-    const int stat_mode = fuse_stats ? 1 : (fuse_bnred && !PS) ? 2 : 0;   // sums kept by the CONSUMER waves
-    const bool ps = PS && fuse_bnred;                                      // sums kept by the producer waves
-    constexpr int E_BYTES = G::ACC * 128 * 64 * NT;                        // epilogue buffer: ACC x 128 pixel slots of NT x 64 bytes
-    constexpr int EK = 4 * NT, EQ_STEP = 256 / EK, ECH = G::ACC * 128 / EQ_STEP;   // chunks per pixel; pixel slots between a thread's chunks; chunks per thread
+    const int stat_mode = fuse_stats ? 1 : (fuse_bnred && PS != 1) ? 2 : 0;   // sums kept by the CONSUMER waves (PS = 2: of the groups g < PS_G0)
+    const bool ps = PS != 0 && fuse_bnred;                                 // sums kept by the producer waves (PS = 2: of the groups g >= PS_G0)
+    constexpr int PS_G0 = PS == 2 ? G::ACC / 2 : 0, PS_GROUPS = G::ACC - PS_G0;   // the accumulator groups whose stored values go through the epilogue buffer
+    constexpr int E_BYTES = PS_GROUPS * 128 * 64 * NT;                     // epilogue buffer: PS_GROUPS x 128 pixel slots of NT x 64 bytes
+    constexpr int EK = 4 * NT, EQ_STEP = 256 / EK, ECH = PS_GROUPS * 128 / EQ_STEP;   // chunks per pixel; pixel slots between a thread's chunks; chunks per thread
+    float est[16];   // PS: this producer thread's running sums (sum dz*y | sum dz of its 8 channels), reduced after the stat_mode reduction
     float* bnc = tab + c_red * 4;            // [scale | shift | mean | invstd][C_OUT] of this workgroup's channels
 
     int tile = tile_first, slab = 0, it = 0;
@@ -1424,7 +1431,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
         init_tables();
         if (DEEP2 && ftile < n_tiles) fetch(R1);
         // ---- PS: bn backward sums of the tile whose epilogue the consumers finished two items ago ----
-        float esc[8], esh[8], est[16];
+        float esc[8], esh[8];
         const int ek = tid & (EK - 1), eq0 = tid / EK;   // this thread's chunk (channels 8 ek .. 8 ek + 7 of the workgroup's) and first pixel slot
         int hist1 = -1, hist2 = -1, hist1_it = 0, hist2_it = 0;   // tile (or -1) and item index of the last two items whose epilogue leaves a buffer
         if (PS) {
@@ -1442,7 +1449,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
             for (int j = 0; j < ECH; ++j) {
                 const int q = eq0 + EQ_STEP * j;
                 size_t pix; bool valid;
-                G::out_pixel(q >> 7, a, n, ty, tx, (q >> 5) & 3, q & 31, pix, valid);
+                G::out_pixel((q >> 7) + PS_G0, a, n, ty, tx, (q >> 5) & 3, q & 31, pix, valid);
                 yv[j] = *reinterpret_cast<const u32x4*>(ylayer + pix * a.c_out + co_base + ek * 8);
                 evalid |= (valid ? 1u : 0u) << j;
             }
@@ -1513,9 +1520,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
                 if (hist2 >= 0) { estat_begin(hist2, eyv, evalid); estat_end(hist2_it, eyv, evalid); }
                 __syncthreads();
                 if (hist1 >= 0) { estat_begin(hist1, eyv, evalid); estat_end(hist1_it, eyv, evalid); }
-                float* red = reinterpret_cast<float*>(smem) + (size_t)tid * 16;   // the staging buffers are free now
-#pragma unroll
-                for (int e = 0; e < 16; ++e) red[e] = est[e];
             }
         }
     } else {
@@ -1546,7 +1550,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
         constexpr bool DEEP = !FWD && NT == 1 && G::RMW_PREFETCH, DEEP_Y = false;
         u32x4 old_n[DEEP ? G::ACC : 1][NT][2], yraw_n[DEEP_Y ? G::ACC : 1][NT][2];
         const bool rmw_any = !FWD && G::RMW_PREFETCH && a.out_accumulate;
-        const bool cons_bnred = fuse_bnred && !PS;   // the consumers keep the bn backward sums (and fetch y for them)
+        const bool cons_bnred = fuse_bnred && PS != 1;   // the consumers keep (some of) the bn backward sums (and fetch y for them)
         const bool pre_any = rmw_any || cons_bnred;
         auto prefetch_epilogue = [&](int t, auto& o, auto& y, bool want_old, bool want_y) __attribute__((always_inline)) {
             const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, n = t / (tiles_x * tiles_y);
@@ -1563,7 +1567,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
                     for (int s2 = 0; s2 < 2; ++s2) {
                         if constexpr (!FWD) {
                             if (want_old) o[g][nt][s2] = *reinterpret_cast<const u32x4*>(out + e0 + nt * 32 + 16 * s2);
-                            if (want_y) y[g][nt][s2] = *reinterpret_cast<const u32x4*>(yl + e0 + nt * 32 + 16 * s2);
+                            if (want_y && (PS != 2 || g < PS_G0)) y[g][nt][s2] = *reinterpret_cast<const u32x4*>(yl + e0 + nt * 32 + 16 * s2);
                         }
                     }
             }
@@ -1621,8 +1625,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
                     G::out_pixel(g, a, n, ty, tx, wave, col, pix, valid);
                     if constexpr (HEAD) store_pixel_tiles_head(acc[g][0], a, pix, n, valid, half, bnc, C_OUT, hw, hbias);
                     else if constexpr (ACT) store_pixel_tiles_act<NT>(acc[g], a, pix, valid, half, co_base, bnc, C_OUT);
-                    else store_pixel_tiles_rmw<NT>(acc[g], a, pix, valid, half, co_base, old[FWD ? 0 : g], rmw, stat, stat_mode, yraw[FWD ? 0 : g], bnc,
-                                                   ps ? smem + e_off + (n_slabs == 1 ? (it & 1) * E_BYTES : 0) : nullptr, (g * 4 + wave) * 32 + col);
+                    else {
+                        const bool to_ebuf = ps && g >= PS_G0;   // (compile-time per unrolled g) this group's sums are the producers'
+                        store_pixel_tiles_rmw<NT>(acc[g], a, pix, valid, half, co_base, old[FWD ? 0 : g], rmw, stat, (PS == 2 && g >= PS_G0) ? 0 : stat_mode, yraw[FWD ? 0 : g], bnc,
+                                                  to_ebuf ? smem + e_off + (n_slabs == 1 ? (it & 1) * E_BYTES : 0) : nullptr, ((g - PS_G0) * 4 + wave) * 32 + col);
+                    }
                 }
                 if constexpr (DEEP) {
                     if (pre_any) {
@@ -1684,6 +1691,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
     }
     if constexpr (PS) {
         if (ps) {   // the producers' 16 sums per thread -> (channel, which) = 64 NT sums, each over the 256 / EK threads that own the chunk, fixed order, in double
+            __syncthreads();   // every wave is done with the staging buffers (and with the consumers' reduction above, PS = 2)
+            if (producer) {
+                float* redw = reinterpret_cast<float*>(smem) + (size_t)tid * 16;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) redw[e] = est[e];
+            }
             __syncthreads();
             constexpr int GRP = 512 / (64 * NT);
             const int t = threadIdx.x / GRP, part = threadIdx.x % GRP;
@@ -1720,7 +1733,7 @@ int ws_target_wgs();
 
 // LDS layout of a persistent conv launch and whether it takes the producer-side form of the fused bn backward sums (PS).
 // with_bnred: the sums are wanted (conv_fused_bnred_blocks asks before ConvArgs::bnred_* are set).
-struct WsLayout { int wres; size_t lds; bool ps; int e_off; };
+struct WsLayout { int wres; size_t lds; int ps /* 0 consumer-side sums, 1 producer-side, 2 split by accumulator group */; int e_off; };
 WsLayout ws_layout(const ConvArgs& a, int recs, int acc, int nt, bool with_bnred) {
     const size_t tables = (size_t)a.c_red * 16 + (size_t)nt * 32 * 16;
     const size_t x_bytes = (size_t)recs * 64, w_bytes = (size_t)9 * nt * 32 * 64;
@@ -1740,12 +1753,20 @@ WsLayout ws_layout(const ConvArgs& a, int recs, int acc, int nt, bool with_bnred
     // small — the four-accumulator-group geometry (stride-2 con backward-data, 32 output channels: 119 -> 108 us); the stride-1 and
     // down geometries get slower (32->32: 99 -> 117 us: their producers become the long pole).  ANH_WS_PSTAT: 0 off, 1 (default) the
     // four-group geometry only, 2 every form that fits.
+    // Round 4: ANH_WS_PSTAT 3 / 4 = the SPLIT form (PS = 2 in the kernel: consumers keep the sums of half the accumulator groups, producers
+    // of the other half) for the stride-1 geometry (3), and for the four-group geometry at 32 channels as well (4); everything else as 1.
     static const int ps_env = getenv("ANH_WS_PSTAT") ? atoi(getenv("ANH_WS_PSTAT")) : 1;
-    const bool ps_on = ps_env == 2 || (ps_env == 1 && acc == 4);
-    const size_t e_total = (size_t)acc * 128 * 64 * nt * (n_slabs == 1 ? 2 : 1);
-    if (ps_on && with_bnred && a.src.kind == SRC_RAW && !a.out_scale && !a.stat_partials && !a.stat_acc) {
-        if (L.lds + e_total <= 160 * 1024) L.ps = true;
-        else if (n_slabs == 1 && resident_lds + e_total <= 160 * 1024 && resident_lds - tables >= 16 * 1024) { L.wres = 1; L.lds = resident_lds; L.ps = true; }
+    const bool can_split = acc >= 2 && acc * nt <= 4;   // the consumers must be able to hold per-lane sums (CAN_STATS in the kernel)
+    int mode = 0;
+    if (ps_env == 2) mode = 1;
+    else if (ps_env == 1) mode = acc == 4 ? 1 : 0;
+    else if (ps_env == 3) mode = acc == 4 ? 1 : (can_split ? 2 : 0);
+    else if (ps_env == 4) mode = can_split ? 2 : (acc == 4 ? 1 : 0);
+    const int e_groups = mode == 2 ? acc - acc / 2 : acc;
+    const size_t e_total = (size_t)e_groups * 128 * 64 * nt * (n_slabs == 1 ? 2 : 1);
+    if (mode && with_bnred && a.src.kind == SRC_RAW && !a.out_scale && !a.stat_partials && !a.stat_acc) {
+        if (L.lds + e_total <= 160 * 1024) L.ps = mode;
+        else if (n_slabs == 1 && resident_lds + e_total <= 160 * 1024 && resident_lds - tables >= 16 * 1024) { L.wres = 1; L.lds = resident_lds; L.ps = mode; }
     }
     L.e_off = L.ps ? (int)((L.lds + 15) / 16 * 16) : 0;
     if (L.ps) L.lds = (size_t)L.e_off + e_total;
@@ -1759,7 +1780,7 @@ void launch_ws(const ConvArgs& a, int tiles_x, int tiles_y, int flip, hipStream_
     const WsLayout lay = ws_layout(a, G::RECS, G::ACC, NT, a.bnred_partials != nullptr || a.bnred_acc != nullptr);
     const int wres = lay.wres, e_off = lay.e_off;
     const size_t lds = lay.lds;
-    const bool ps = lay.ps;
+    const int ps = lay.ps;
     // ANH_WS_ROLE_MAP: 0 = one producer + one consumer per SIMD, 1 = consumers on SIMDs 0-1 / producers on SIMDs 2-3, 2 = map 1 for the
     // 32-output-channel kernels only (their MFMA phase is short; the 64-channel kernels need all four matrix cores)
     static const int role_env = getenv("ANH_WS_ROLE_MAP") ? atoi(getenv("ANH_WS_ROLE_MAP")) : 0;
@@ -1847,7 +1868,10 @@ void launch_ws(const ConvArgs& a, int tiles_x, int tiles_y, int flip, hipStream_
             return;
         }
     }
-    if (ps) { launch(conv3x3_ws_kernel<G, NT, SRC_RAW, false, false, true>); HIP_CHECK(hipGetLastError()); return; }
+    if (ps == 1) { launch(conv3x3_ws_kernel<G, NT, SRC_RAW, false, false, 1>); HIP_CHECK(hipGetLastError()); return; }
+    if constexpr (G::ACC >= 2 && G::ACC * NT <= 4) {
+        if (ps == 2) { launch(conv3x3_ws_kernel<G, NT, SRC_RAW, false, false, 2>); HIP_CHECK(hipGetLastError()); return; }
+    }
     switch (a.src.kind) {
         case SRC_RAW: launch(conv3x3_ws_kernel<G, NT, SRC_RAW>); break;
         case SRC_ACT: launch(conv3x3_ws_kernel<G, NT, SRC_ACT>); break;

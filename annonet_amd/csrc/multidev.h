@@ -7,8 +7,11 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <condition_variable>
 #include <exception>
+#include <functional>
 #include <memory>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -50,6 +53,7 @@ class Collective {
     ~Collective();
     void all_reduce_sum(const std::vector<float*>& bufs, size_t count, const std::vector<hipStream_t>& streams);
     bool uses_rccl() const { return !comms_.empty(); }
+    static int rccl_version();   // ncclGetVersion (e.g. 22203), 0 if the call fails
     int world() const { return (int)devices_.size(); }
 
   private:
@@ -72,10 +76,84 @@ void launch_pack_rects(const float* planes, int k, int height, int width, const 
 void launch_unpack_rects(float* planes, int k, int height, int width, const anh_rect* d_rects, const int64_t* d_offsets, int n_rects, int64_t total,
                          const float* packed, hipStream_t s);
 
-// fn(r) for every replica r of a handle: replica 0 on the calling thread, the others on threads of their own.  One host thread
-// enqueues a replica's ~70 launches per training step (or its share of an image's tiles) in 0.3-0.4 ms; eight replicas driven from
-// one thread would be launch-bound at twice the GPU time of a step.  Every fn(r) selects its own device (DeviceScope is per
-// thread) and touches only replica r's state; the first exception is rethrown on the caller.
+// fn(r) for every replica r of a handle: replica 0 on the calling thread, the others on worker threads.  One host thread enqueues a
+// replica's ~50 launches per training step (or its share of an image's tiles) in 0.3-0.4 ms; eight replicas driven from one thread
+// would be launch-bound at twice the GPU time of a step.
+//
+// Round 4: the workers are PERSISTENT.  ReplicaWorkers lives with the handle (anh_trainer / anh_runtime): replicas - 1 threads, each
+// bound to one replica index, with its device selected once at thread start; a call is ONE wake-up (a generation counter under a
+// mutex + condition variable) and one wait for the stragglers.  Round 3's for_each_replica created and joined replicas - 1
+// std::threads on every call — at eight replicas and a 1.6 ms step, seven thread creations per StartTraining, each new thread paying
+// its first hipSetDevice.  Every fn(r) touches only replica r's state; the first exception is rethrown on the caller.
+class ReplicaWorkers {
+  public:
+    explicit ReplicaWorkers(const std::vector<int>& devices) : devices_(devices), failed_(devices.size()) {
+        for (size_t r = 1; r < devices_.size(); ++r) threads_.emplace_back([this, r] { loop(r); });
+    }
+    ~ReplicaWorkers() {
+        { std::lock_guard<std::mutex> lock(mu_); stop_ = true; ++generation_; }
+        go_.notify_all();
+        for (std::thread& t : threads_) t.join();
+    }
+    ReplicaWorkers(const ReplicaWorkers&) = delete;
+    ReplicaWorkers& operator=(const ReplicaWorkers&) = delete;
+    size_t replicas() const { return devices_.size(); }
+    uint64_t calls() const { return calls_; }   // (tests: the pool was used, and how often)
+
+    template <class F>
+    void run(F&& fn) {
+        const size_t R = devices_.size();
+        if (R <= 1) { if (R == 1) fn((size_t)0); return; }
+        std::function<void(size_t)> job = [&fn](size_t r) { fn(r); };
+        {
+            std::lock_guard<std::mutex> lock(mu_);
+            job_ = &job;
+            pending_ = R - 1;
+            for (auto& e : failed_) e = nullptr;
+            ++generation_;
+            ++calls_;
+        }
+        go_.notify_all();
+        try { fn((size_t)0); } catch (...) { failed_[0] = std::current_exception(); }
+        {
+            std::unique_lock<std::mutex> lock(mu_);
+            done_.wait(lock, [this] { return pending_ == 0; });
+            job_ = nullptr;
+        }
+        for (const std::exception_ptr& e : failed_) if (e) std::rethrow_exception(e);
+    }
+
+  private:
+    void loop(size_t r) {
+        (void)hipSetDevice(devices_[r]);   // once: every DeviceScope of this replica's calls is then a no-op
+        uint64_t seen = 0;
+        for (;;) {
+            const std::function<void(size_t)>* job = nullptr;
+            {
+                std::unique_lock<std::mutex> lock(mu_);
+                go_.wait(lock, [&] { return generation_ != seen; });
+                seen = generation_;
+                if (stop_) return;
+                job = job_;
+            }
+            try { (*job)(r); } catch (...) { failed_[r] = std::current_exception(); }
+            bool last;
+            { std::lock_guard<std::mutex> lock(mu_); last = --pending_ == 0; }
+            if (last) done_.notify_one();
+        }
+    }
+    std::vector<int> devices_;
+    std::vector<std::exception_ptr> failed_;
+    std::vector<std::thread> threads_;
+    std::mutex mu_;
+    std::condition_variable go_, done_;
+    const std::function<void(size_t)>* job_ = nullptr;
+    uint64_t generation_ = 0, calls_ = 0;
+    size_t pending_ = 0;
+    bool stop_ = false;
+};
+
+// (the creating / joining form, kept for callers without a handle)
 template <class F>
 void for_each_replica(size_t replicas, F&& fn) {
     if (replicas <= 1) { if (replicas == 1) fn((size_t)0); return; }

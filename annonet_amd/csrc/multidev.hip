@@ -123,6 +123,11 @@ Collective::Collective(const std::vector<int>& devices) : devices_(devices) {
     }
 }
 
+int Collective::rccl_version() {
+    int v = 0;
+    return ncclGetVersion(&v) == ncclSuccess ? v : 0;
+}
+
 Collective::~Collective() {
     for (void* c : comms_) (void)ncclCommDestroy((ncclComm_t)c);
     for (hipEvent_t e : ready_) (void)hipEventDestroy(e);

@@ -43,22 +43,35 @@ class EarlyReduce:
         self.split = 0 < self.first < bucket.numel() - 1
         self.side = torch.cuda.Stream(device=bucket.device) if self.split else None
 
-    def run(self, trainer, bucket, main_stream, group=None):
+    def run(self, trainer, bucket, main_stream, group=None, events=None):
+        """events (a list, optional): ("tail" | "head" | "whole", start, stop) torch events around each collective are appended —
+        bench.py's `exchange` object; an event pair costs stream time, so only on sampled, untimed steps."""
         import torch
         import torch.distributed as dist
         if not self.split:
             with torch.cuda.stream(main_stream):
-                dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=group)
+                _timed_all_reduce(dist, torch, bucket, group, events, "whole")
             return
         trainer.wait_early_grads(self.side.cuda_stream)
         with torch.cuda.stream(self.side):
-            dist.all_reduce(bucket[self.first:], op=dist.ReduceOp.SUM, group=group)
+            _timed_all_reduce(dist, torch, bucket[self.first:], group, events, "tail")
         with torch.cuda.stream(main_stream):
-            dist.all_reduce(bucket[:self.first], op=dist.ReduceOp.SUM, group=group)
+            _timed_all_reduce(dist, torch, bucket[:self.first], group, events, "head")
         main_stream.wait_stream(self.side)      # the update reads the whole bucket
 
 
-def data_parallel_step(trainer, bucket, d_images, d_labels, d_weights, n, h, w, world_size, group=None, force_collective=False, stream=None, early=None):
+def _timed_all_reduce(dist, torch, tensor, group, events, name):
+    if events is None:
+        dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=group)
+        return
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()          # on the current stream (the caller's `with torch.cuda.stream(...)`)
+    dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=group)
+    b.record()
+    events.append((name, a, b))
+
+
+def data_parallel_step(trainer, bucket, d_images, d_labels, d_weights, n, h, w, world_size, group=None, force_collective=False, stream=None, early=None, events=None):
     """One optimiser step of a data-parallel job.  The loss scale uses the GLOBAL batch (n * world_size), so the
     all-reduce is a plain SUM and every rank then applies the identical update.  The collective is
     enqueued on the trainer's own stream (`stream` = handle_stream(trainer), made once by the caller): backward ->
@@ -71,10 +84,10 @@ def data_parallel_step(trainer, bucket, d_images, d_labels, d_weights, n, h, w, 
         if bucket.is_cuda:
             main = stream if stream is not None else handle_stream(trainer)
             if early is not None:
-                early.run(trainer, bucket, main, group)
+                early.run(trainer, bucket, main, group, events=events)
             else:
                 with torch.cuda.stream(main):
-                    dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=group)
+                    _timed_all_reduce(dist, torch, bucket, group, events, "whole")
         else:   # CPU rehearsal of the same logic over gloo (tests/test_dist_gloo.py)
             dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=group)
     trainer.apply_update(1.0)
@@ -262,3 +275,105 @@ def reduce_shard_planes(blended_np_list):
     for b in blended_np_list:
         out = out + b
     return out
+
+
+def tile_cells(tiles, width, height):
+    """One rectangle (left, top, right, bottom; inclusive) per tile such that the rectangles PARTITION the image and each lies inside its
+    tile's full rectangle: per axis the boundary between two neighbouring tiles runs through the middle of their overlap.  After the
+    overlap exchange both owners of an overlap pixel hold the same sums, hence the same label, so any partition assembles the map of the
+    single-process annonet_infer(); this one gives every tile a compact block.  Needs the grid the tiler builds (make_tiles)."""
+    def axis(spans, size):
+        spans = sorted(set(spans))
+        bounds = [0]
+        for (s0, e0), (s1, e1) in zip(spans, spans[1:]):
+            if not (s0 < s1 and e0 < e1 and s1 <= e0 + 1):
+                raise ValueError("tile_cells: the tiles do not form a grid")
+            bounds.append((e0 + s1 + 1) // 2)
+        bounds.append(size)
+        return {span: (bounds[i], bounds[i + 1] - 1) for i, span in enumerate(spans)}
+    xs = axis([(t[0][0], t[0][2]) for t in tiles], width)
+    ys = axis([(t[0][1], t[0][3]) for t in tiles], height)
+    cells = []
+    for full, _ in tiles:
+        (l, r), (t, b) = xs[(full[0], full[2])], ys[(full[1], full[3])]
+        cells.append((max(l, 0), max(t, 0), min(r, width - 1), min(b, height - 1)))
+    if sum((c[2] - c[0] + 1) * (c[3] - c[1] + 1) for c in cells) != width * height:
+        raise ValueError("tile_cells: the tiles do not form a grid")
+    return cells
+
+
+class HostLabelMap:
+    """ONE [H, W] u16 label map in HOST memory shared by every rank of a sharded annonet_infer() (POSIX shared memory; the reference's
+    writer threads consume host label maps, annonet_infer_main.cpp:403-419).  Every rank copies the cells of ITS tiles (tile_cells)
+    from its device-resident map straight into the shared map, over its own PCIe link: rank 0 copies only its share, nothing is
+    gathered in HBM first (LabelGather stays for hosts that need the map on a device).  The mapping is page-locked per rank
+    (anh_host_register), so the copies are asynchronous on the rank's stream; `deliver` returns at once, the caller's stream / event
+    says when the rows have landed.  The creator (rank `owner`) passes name=None and publishes `.name`; the others attach by name."""
+
+    def __init__(self, tiles, world_size, rank, width, height, name=None, pin=True):
+        from multiprocessing import shared_memory
+        import ctypes as C
+        self.width, self.height, self.rank = width, height, rank
+        nbytes = width * height * 2
+        self.creator = name is None
+        self.shm = shared_memory.SharedMemory(create=True, size=nbytes) if self.creator else shared_memory.SharedMemory(name=name)
+        self.name = self.shm.name
+        self.array = np.ndarray((height, width), dtype=np.uint16, buffer=self.shm.buf)
+        self.ptr = C.addressof(C.c_char.from_buffer(self.shm.buf))
+        owner = tile_owner(len(tiles), world_size)
+        cells = tile_cells(tiles, width, height)
+        mine = [c for c, o in zip(cells, owner) if o == rank]
+        # cells of one tile row that reach from the left to the right border merge into one block of whole rows (a contiguous copy)
+        rows = {}
+        for c in mine:
+            rows.setdefault((c[1], c[3]), []).append(c)
+        self.rects = []
+        for (t, b), cs in sorted(rows.items()):
+            cs.sort()
+            if cs[0][0] == 0 and cs[-1][2] == width - 1 and all(a[2] + 1 == b2[0] for a, b2 in zip(cs, cs[1:])):
+                self.rects.append((0, t, width - 1, b))
+            else:
+                self.rects.extend(cs)
+        self.bytes = sum((r[2] - r[0] + 1) * (r[3] - r[1] + 1) for r in self.rects) * 2
+        self.pinned = False
+        if pin:
+            from . import _lib
+            self.pinned = _lib.lib().anh_host_register(self.ptr, nbytes) == 0
+
+    def deliver(self, d_labels_ptr, stream_ptr):
+        """enqueue the copies of this rank's rectangles on `stream_ptr` (a HIP stream handle); d_labels_ptr: the rank's [H, W] u16 map in HBM"""
+        from . import _lib
+        L = _lib.lib()
+        for (l, t, r, b) in self.rects:
+            _lib.check(L.anh_labels_rect_to_host(d_labels_ptr, self.ptr, self.width, self.height, l, t, r, b, stream_ptr))
+
+    def deliver_from_host(self, labels):
+        """the same rectangles from a host array (CPU rehearsal of the ownership logic: tests/test_dist_gloo.py)"""
+        src = np.asarray(labels).view(np.uint16).reshape(self.height, self.width)
+        for (l, t, r, b) in self.rects:
+            self.array[t:b + 1, l:r + 1] = src[t:b + 1, l:r + 1]
+
+    def close(self):
+        if self.shm is None:
+            return
+        if self.pinned:
+            from . import _lib
+            _lib.lib().anh_host_unregister(self.ptr)
+            self.pinned = False
+        self.array = None
+        try:
+            self.shm.close()
+        except BufferError:
+            pass
+        if self.creator:
+            try:
+                self.shm.unlink()
+            except FileNotFoundError:
+                pass
+        self.shm = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -497,6 +497,15 @@ class TrainingNet(_Profiled):
     def replicas(self):
         return self.L.anh_handle_replicas(self.h, 1)
 
+    def exchange_stats(self):
+        """anh_trainer_exchange_stats as a dict: host time per StartTraining, sampled all-reduce times on replica 0, worker wake-ups."""
+        st = _lib.ExchangeStats()
+        check(self.L.anh_trainer_exchange_stats(self.h, C.byref(st)))
+        return {name: getattr(st, name) for name, _ in _lib.ExchangeStats._fields_}
+
+    def reset_exchange_stats(self):
+        self.L.anh_trainer_reset_exchange_stats(self.h)
+
     def replica_params(self, replica):
         p = np.empty(self.n_params, np.float32)
         check(self.L.anh_trainer_replica_params(self.h, replica, _ptr(p), p.size))

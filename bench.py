@@ -438,8 +438,22 @@ def infer_one_size(args, side, with_cpu_baseline, aa, aad, torch, dist, prec, ra
     tiles = aa.tiling.get_tiles(side, side, tp)
     mine = aad.shard_tiles(tiles, rank, world)
     exchange = aad.OverlapExchange(tiles, world, side, side, dev)   # the pixels where tiles of different ranks overlap (none at world 1)
-    gather = aad.LabelGather(tiles, world, rank, side, side, dev, CLASSES) if world > 1 else None   # ONE label map on rank 0
+    gather = aad.LabelGather(tiles, world, rank, side, side, dev, CLASSES) if world > 1 else None   # ONE label map on rank 0 (resident leg)
     ranks_seen, devices = dist_facts(torch, dist, dev, local_rank, world, use_dist)
+    # N > 1, labels on the host: ONE host map per label set in POSIX shared memory, every rank delivering the cells of its own tiles over
+    # its own PCIe link (dist.HostLabelMap) — rank 0 copies only its share, nothing is gathered first
+    host_maps = None
+    if world > 1:
+        host_maps = []
+        for _ in range(2):
+            names = [None]
+            if rank == 0:
+                hm = aad.HostLabelMap(tiles, world, rank, side, side)
+                names = [hm.name]
+            dist.broadcast_object_list(names, src=0)
+            if rank != 0:
+                hm = aad.HostLabelMap(tiles, world, rank, side, side, name=names[0])
+            host_maps.append(hm)
 
     def run(to_host=False):
         # blend this rank's tiles -> all-reduce the plane sums of the cross-rank overlaps -> label this rank's rows
@@ -450,6 +464,12 @@ def infer_one_size(args, side, with_cpu_baseline, aa, aad, torch, dist, prec, ra
             if copied[k] is not None:   # this set's previous image must have left for the host before its map is overwritten
                 net_stream.wait_event(copied[k])
         row0, row1 = aad.sharded_infer(net, image, labels, blended, tiles, rank, world, exchange, tiling_parameters=tp, stream=net_stream)
+        if to_host and host_maps is not None:   # N > 1: every rank's own rows go straight to the shared host map
+            copy_stream.wait_stream(net_stream)
+            host_maps[k].deliver(labels.data_ptr(), copy_stream.cuda_stream)
+            copied[k] = torch.cuda.Event()
+            copied[k].record(copy_stream)
+            return
         if gather is not None:   # N > 1: the result of annonet_infer() is one map — the ranks' shares are assembled on rank 0
             with torch.cuda.stream(net_stream):   # everything that touches `labels` stays on the net's stream
                 whole = gather.run(labels)
@@ -508,6 +528,16 @@ def infer_one_size(args, side, with_cpu_baseline, aa, aad, torch, dist, prec, ra
     elapsed_host = timed(args.steps, to_host=True)
     net.synchronize()
     net.profile_enable(False)
+    # bytes each rank copies to the host per image in the labels-on-host leg (N > 1: its own cells of the shared map; N = 1: the whole map)
+    host_bytes = [side * side * 2]
+    if host_maps is not None:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, host_maps[0].bytes)
+        host_bytes = gathered
+        if rank == 0 and sum(gathered) != side * side * 2:
+            raise SystemExit(f"host label map: the ranks' cells cover {sum(gathered)} bytes of {side * side * 2}")
+        for hm in host_maps:
+            hm.close()
     out = None
     if rank == 0:
         roof = None
@@ -536,9 +566,10 @@ def infer_one_size(args, side, with_cpu_baseline, aa, aad, torch, dist, prec, ra
                "ms_per_step": 1e3 * elapsed / args.steps,
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
                "config": {"workload": f"annonet_infer(): {side}x{side} image, {len(tiles)} tiles ({len(mine)} on rank 0), window {win}, levels={LEVELS} width={WIDTH} K={CLASSES}",
-                          "parallelism": f"tile-shard{world}", "exchanged_pixels": exchange.pixels()},
+                          "parallelism": f"tile-shard{world}", "exchanged_pixels": exchange.pixels(),
+                          "host_bytes_per_rank": host_bytes},
                "value_labels_on_host": side * side * args.steps / elapsed_host / 1e6,
-               "value_note": "value: image and label map resident in HBM; value_labels_on_host: the same passes with the label map copied to pinned host memory inside the timed region (SURVEY 8d's unit; two label maps used alternately, so the copy of one image overlaps the passes of the next; every copy ends inside the region); same step count and instrumentation",
+               "value_note": "value: image and label map resident in HBM (N > 1: ONE map assembled on rank 0, dist.LabelGather); value_labels_on_host: the same passes with the label map copied to pinned host memory inside the timed region (N > 1: every rank copies the cells of its own tiles into ONE shared-memory host map over its own PCIe link, dist.HostLabelMap: config.host_bytes_per_rank) (SURVEY 8d's unit; two label maps used alternately, so the copy of one image overlaps the passes of the next; every copy ends inside the region); same step count and instrumentation",
                "roofline": roof, "kernel_time_share_pct": share, "ranks_seen": ranks_seen, "devices": devices,
                "cpu_baseline": cpu_baseline_infer(aa, cfg, ov) if with_cpu_baseline else None}
     torch.cuda.synchronize()
@@ -595,6 +626,79 @@ def infer_in_child(args, world):
     return d
 
 
+def bench_in_process(args):
+    """Host (B): ONE process drives several GPUs behind the C ABI — anh_set_devices (NetPimpl::SetDevices), then the reference's own loop
+    unchanged: StartTraining with host vectors (/root/reference/annonet_train_main.cpp:583-614), the library splitting the mini-batch
+    along N, RCCL inside the library, persistent worker threads per replica.  Global batch 32 per device; PCIe-inclusive by nature of
+    the interface.  `--devices 0,0` is the rehearsal on one GPU (repeated-device backend: same splits, a fixed-order sum instead of RCCL)."""
+    import ctypes as C
+    import annonet_amd as aa
+    devices = [int(x) for x in args.devices.split(",")] if args.devices else list(range(args.gpus))
+    R = len(devices)
+    aa.set_devices(devices)
+    prec = aa.ANH_BF16 if args.precision == "bf16" else aa.ANH_FP32
+    t = aa.TrainingNet(LEVELS, 3, prec, seed=2)
+    t.SetNetWidth(WIDTH, 1)
+    t.SetClassCount(CLASSES)
+    t.Initialize()
+    t.SetLearningRate(0.1)
+    imgs, wls = [], []
+    for r in range(R):   # replica r gets the shard rank r of the one-process-per-GPU job would hold
+        img, lab, _ = synthetic_batch(r)
+        imgs += [np.ascontiguousarray(img[i]) for i in range(BATCH)]
+        wls += [aa.set_weights(lab[i], 0.5, 0.5) for i in range(BATCH)]
+    n = BATCH * R
+    ip = (C.c_void_p * n)(*[a.ctypes.data for a in imgs])
+    lp = (C.c_void_p * n)(*[a.ctypes.data for a in wls])
+
+    def step():
+        aa._lib.check(t.L.anh_trainer_step(t.h, ip, lp, n, TILE, TILE))
+    prewarm_steps = prewarm(step, t.synchronize, args.prewarm_s)
+    for _ in range(max(args.warmup, 1)):
+        step()
+    t.synchronize()
+    t.reset_exchange_stats()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    t.synchronize()
+    elapsed = time.perf_counter() - t0
+    st = t.exchange_stats()
+    out = {"metric": "227x227 RGB tiles/sec fwd+bwd @ batch 32 per GPU, one process driving all GPUs (anh_set_devices), host vectors every step",
+           "value": n * args.steps / elapsed, "unit": "tiles/s", "n_gpus": len(set(devices)), "replicas": R, "devices": devices, "steps": args.steps, "warmup": args.warmup,
+           "prewarm_s": args.prewarm_s if prewarm_steps else 0.0, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+           "dtype": args.precision, "data": "synthetic", "global_batch": n,
+           "host_us_per_start_training": round(st["host_us_mean"], 1),
+           "host_note": "wall time the calling thread spends inside one StartTraining (packing 32 x replicas samples into pinned staging, uploads, the step's launches on every replica by persistent worker threads, the collectives, the update): the one-thread reference loop cannot step faster than this",
+           "worker_wakeups_per_step": round(st["worker_calls"] / max(st["steps"], 1), 2),
+           "exchange": {"allreduce_tail_us": round(st["allreduce_tail_us_mean"], 1), "allreduce_head_us": round(st["allreduce_head_us_mean"], 1), "sampled_steps": st["samples"],
+                        "early_reduce": bool(st["early_reduce"]), "transport": "rccl" if st["uses_rccl"] else "repeated-device rehearsal (fixed-order sum kernel + copies)",
+                        "rccl_version": st["rccl_version"], "bucket_bytes": st["bucket_bytes"],
+                        "note": "device time of the all-reduce's two parts on replica 0 (event pairs on every 8th step): tail = bucket[first:] on a side stream while backward still runs, head = bucket[:first] on the main stream"},
+           "final_loss": t.get_last_loss()}
+    print(json.dumps(out), flush=True)
+
+
+def in_process_child(args, world):
+    """`bench.py --in-process --gpus N` as a child, after this job's own measurement (the GPUs are free again): host (B)'s figure beside host (A)'s."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--in-process", "--gpus", str(world), "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--precision", args.precision, "--prewarm-s", str(min(args.prewarm_s, 1.0))]
+    if args.one_gpu:
+        cmd += ["--devices", ",".join(["0"] * world)]
+    drop = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE", "ROLE_RANK", "ROLE_WORLD_SIZE", "ROLE_NAME", "MASTER_ADDR", "MASTER_PORT", "OMP_NUM_THREADS")
+    env = {k: v for k, v in os.environ.items() if k not in drop and not k.startswith("TORCHELASTIC_") and not k.startswith("TORCH_NCCL_")}
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=args.infer_timeout, cwd=ROOT)
+    except subprocess.TimeoutExpired:
+        return {"error": f"in-process child exceeded {args.infer_timeout} s", "command": " ".join(cmd[1:])}
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if r.returncode != 0 or len(lines) != 1:
+        return {"error": f"in-process child returned {r.returncode}", "stderr_tail": r.stderr[-800:], "command": " ".join(cmd[1:])}
+    d = json.loads(lines[0])
+    d["measured_by"] = "child process: " + " ".join(["bench.py"] + cmd[2:])
+    return d
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -612,11 +716,16 @@ def main():
     ap.add_argument("--collective-timeout", type=float, default=180.0, help="seconds after which a collective that a rank never joined fails the job")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend: nccl = RCCL over xGMI (the job); gloo = rehearsal transport")
     ap.add_argument("--one-gpu", action="store_true", help="rehearsal of the N > 1 paths on a one-GPU box: every rank drives device 0 (needs --backend gloo: RCCL wants one GPU per rank)")
+    ap.add_argument("--no-in-process", action="store_true", help="N > 1: leave the `in_process` object (host B measured by a child process) out")
+    ap.add_argument("--in-process", action="store_true", help="host (B): ONE process drives --gpus N devices (or --devices) through anh_set_devices and StartTraining with host vectors; prints its own line")
+    ap.add_argument("--devices", default=None, help="--in-process: explicit device list, e.g. 0,0 = two replicas rehearsed on one GPU")
     ap.add_argument("--dump-launch-order", default=None, help="write the step's launch order (profiler entry per kernel-class launch) as JSON: input of tools/pmc_traffic.py")
     args = ap.parse_args()
     if args.mode == "infer" and args.steps == 200:
         args.steps, args.warmup = 20, 3
 
+    if args.in_process:
+        return bench_in_process(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)   # does not return
 
@@ -710,6 +819,7 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    own_elapsed = elapsed
     if use_dist:
         el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
@@ -717,6 +827,28 @@ def main():
     t.synchronize()
     dom = [e for e in t.profile() if e["name"] == dominant]
     loss = t.get_last_loss()
+    # N > 1 (or launched as a rank): what ONE driver run must carry to be diagnosable — every rank's own step time, and the device time of
+    # the exchange step measured by event pairs around each collective on four extra, untimed steps
+    exchange = None
+    if use_dist:
+        mine = torch.tensor([1e3 * own_elapsed / args.steps], device=dev, dtype=torch.float64)
+        per_rank = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(per_rank, mine)
+        ev = []
+        for _ in range(4):
+            aad.data_parallel_step(t, bucket, d_img.data_ptr(), d_lab.data_ptr(), d_w.data_ptr(), BATCH, TILE, TILE, world, force_collective=True, stream=t_stream, early=early, events=ev)
+        t.synchronize()
+        torch.cuda.synchronize()
+        parts = {}
+        for name, a, b in ev:
+            parts.setdefault(name, []).append(1e3 * a.elapsed_time(b))
+        exchange = {"allreduce_us": {k: round(sum(v) / len(v), 1) for k, v in parts.items()}, "sampled_steps": 4,
+                    "early_reduce": bool(early is not None and early.split), "backend": args.backend,
+                    "rccl_version": ".".join(str(x) for x in torch.cuda.nccl.version()) if args.backend == "nccl" else None,
+                    "bucket_bytes": int(bucket.numel()) * 4,
+                    "ms_per_step_per_rank": {"min": round(min(float(x.item()) for x in per_rank), 4), "max": round(max(float(x.item()) for x in per_rank), 4),
+                                             "all": [round(float(x.item()), 4) for x in per_rank]},
+                    "note": "allreduce_us: device time between event pairs around each collective of a step (tail = bucket[first:] on the side stream, head = bucket[:first], or whole = one all-reduce), mean of 4 untimed steps on rank 0; ms_per_step_per_rank: every rank's own wall time over the timed region / K"}
     # The same K steps with the mini-batch handed over as HOST vectors every step, the way the reference's loop drives StartTraining
     # (/root/reference/annonet_train_main.cpp:585-609: 32 images + 32 weighted-label images per call; anh_trainer_step packs them into
     # pinned staging, uploads and runs the step behind the upload) — same step count, same instrumentation (event pairs on the dominant
@@ -765,6 +897,7 @@ def main():
             "value_note": "value: the mini-batch resident in HBM when the timed region starts; value_host_inputs: the same K steps through anh_trainer_step with 32 host images + 32 host weighted-label images handed over every step (reference loop annonet_train_main.cpp:585-609; PCIe-inclusive, same step count and instrumentation)",
             "roofline": roof,
             "critical_path": critical_path(prof_all, PROFILE_STEPS, 1e3 * ms),
+            "exchange": exchange,
             "mfma_busy_note": "layers[].mfma_busy_pct = SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CYCLES / 32 shader engines x 1024 SIMDs) from the committed counter pass " + os.path.basename(SQ_JSON) + " (kernels serialised by the profiler); cycles at the clock the kernel held, not the 2.4 GHz of the 2.5 PFLOP/s peak",
             "step_roofline": {"gflop_per_step": round(step_gflop, 1), "achieved_tflops": round(step_gflop / ms, 1), "frac_of_bf16_mfma_peak": round(step_gflop / ms / PEAK_BF16_TFLOPS, 4),
                               "sum_of_layer_floors_us": round(sum(r["floor_us"] for r in layer_rows), 1)},
@@ -791,6 +924,8 @@ def main():
         under_profiler = "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROFILER_") or k.startswith("ROCP_") for k in os.environ)
         if not args.no_infer and not under_profiler:
             out["infer"] = infer_in_child(args, world)
+        if world > 1 and not under_profiler and not args.no_in_process:
+            out["in_process"] = in_process_child(args, world)   # host (B): the same N GPUs from ONE process (anh_set_devices)
         print(json.dumps(out), flush=True)
 
 

@@ -91,6 +91,27 @@ int anh_device_count(void); /* number of visible GPUs; 0 when none (never fails)
  * exchange then runs as a fixed-order sum on the first replica's stream instead of RCCL. */
 int anh_set_devices(const int* devices, int n);
 int anh_handle_replicas(void* handle, int is_trainer); /* number of replicas (devices) a handle drives */
+/* What the exchange step of data-parallel StartTraining (anh_trainer_step on a handle with several replicas) costs: the HOST time of a
+ * call (the reference's loop is one thread: /root/reference/annonet_train_main.cpp:583-614 — what it spends inside StartTraining bounds
+ * the step rate whatever the GPUs do), and, on every 8th step (ANH_EXCHANGE_SAMPLE), the device time of the all-reduce's two parts on
+ * replica 0 (tail = the bulk of the bucket, reduced on a side stream while backward still runs; head = the first layers, on the main
+ * stream).  The replicas of a handle are driven by persistent worker threads; worker_calls counts their wake-ups. */
+typedef struct {
+    int replicas, early_reduce, uses_rccl, rccl_version;
+    int64_t steps, samples, worker_calls, bucket_bytes;
+    double host_us_mean, host_us_last;
+    double allreduce_tail_us_mean, allreduce_head_us_mean, allreduce_tail_us_last, allreduce_head_us_last;
+} anh_exchange_stats;
+int anh_trainer_exchange_stats(anh_trainer* h, anh_exchange_stats* out);
+void anh_trainer_reset_exchange_stats(anh_trainer* h);
+/* Per-rank delivery of a sharded annonet_infer()'s label map (the reference's writer threads consume HOST label maps,
+ * /root/reference/annonet_infer_main.cpp:403-419): every rank copies the rectangles it answers for from its device-resident map straight
+ * into ONE host map that all ranks of the job map (POSIX shared memory), over its own PCIe link — nothing funnels through rank 0.
+ * anh_host_register page-locks host memory the caller owns (the shared map) so the copies run asynchronously; anh_labels_rect_to_host
+ * enqueues the copy of rows [top, bottom] x columns [left, right] (inclusive) of a [height x width] u16 map on `stream`. */
+int anh_host_register(void* p, size_t bytes);
+int anh_host_unregister(void* p);
+int anh_labels_rect_to_host(const uint16_t* d_labels, uint16_t* h_labels, int width, int height, int left, int top, int right, int bottom, void* stream);
 /* the host logic of the two splits, exported for tests: replica `rank` of `world` takes units [*lo, *hi) of n */
 int anh_shard_range(int64_t n, int world, int rank, int64_t* lo, int64_t* hi);
 

@@ -182,6 +182,61 @@ def test_three_rank_label_gather_over_gloo():
         aad.LabelGather([], 1, 0, 4, 4, torch.device("cpu"), 300)
 
 
+def host_map_worker(rank, world, port, out):
+    """Per-rank label delivery (VERDICT round 3, item 6): every rank writes the cells of ITS tiles into ONE shared-memory host map;
+    rank 0 creates the map and publishes its name, the others attach.  The copies here come from host arrays (deliver_from_host: the
+    ownership logic); on a GPU the same rectangles travel by anh_labels_rect_to_host (tests/test_gpu_sharded_infer.py)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    W, H, K = 301, 230, 5
+    tiles = orc.get_tiles(W, H, 96, 112, 19, 19)
+    truth = np.random.default_rng(98).integers(0, K, size=(H, W)).astype(np.uint16)
+    mine = np.zeros((H, W), dtype=bool)
+    for (full, _) in aad.shard_tiles(tiles, rank, world):
+        mine[max(full[1], 0):min(full[3], H - 1) + 1, max(full[0], 0):min(full[2], W - 1) + 1] = True
+    held = np.where(mine, truth, np.uint16(60000 + rank))          # wrong on purpose outside this rank's tiles
+    names = [None]
+    hm = None
+    if rank == 0:
+        hm = aad.HostLabelMap(tiles, world, rank, W, H, pin=False)
+        hm.array[:] = 12345
+        names = [hm.name]
+    dist.broadcast_object_list(names, src=0)
+    if rank != 0:
+        hm = aad.HostLabelMap(tiles, world, rank, W, H, name=names[0], pin=False)
+    hm.deliver_from_host(held)
+    sizes = [None] * world
+    dist.all_gather_object(sizes, hm.bytes)
+    dist.barrier()
+    if rank == 0:
+        out["map"] = hm.array.copy()
+        out["truth"] = truth
+        out["bytes"] = sizes
+    dist.barrier()
+    hm.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_every_rank_delivers_its_own_rows_into_one_shared_host_map(world):
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(host_map_worker, args=(world, free_port(), out), nprocs=world, join=True)
+    np.testing.assert_array_equal(out["map"], out["truth"])
+    assert sum(out["bytes"]) == 301 * 230 * 2 and all(b > 0 for b in out["bytes"])     # every byte written by exactly one rank
+    # the cells partition the image and lie inside their tiles; a tile list that is not a grid is refused
+    tiles = orc.get_tiles(301, 230, 96, 112, 19, 19)
+    cells = aad.tile_cells(tiles, 301, 230)
+    cover = np.zeros((230, 301), dtype=int)
+    for (full, _), c in zip(tiles, cells):
+        assert full[0] <= c[0] <= c[2] <= full[2] and full[1] <= c[1] <= c[3] <= full[3]
+        cover[c[1]:c[3] + 1, c[0]:c[2] + 1] += 1
+    assert (cover == 1).all()
+    with pytest.raises(ValueError):
+        aad.tile_cells([((0, 0, 9, 9), (0, 0, 9, 9)), ((3, 3, 19, 19), (10, 10, 19, 19))], 20, 20)
+
+
 def test_cross_rank_overlaps_are_exactly_the_pixels_shared_between_ranks():
     """The exchange step of sharded inference moves the plane sums of these pixels and no others."""
     W, H = 301, 230

@@ -113,3 +113,26 @@ def test_two_rank_job_rehearsed_on_one_gpu():
     assert "error" not in i, i
     assert i["n_gpus"] == 2 and i["ranks_seen"] == 2 and i["config"]["parallelism"] == "tile-shard2" and i["config"]["exchanged_pixels"] > 0
     assert i["value"] > 0 and i["value_labels_on_host"] > 0
+    # what makes ONE driver run at N = 8 diagnosable (round 4): the exchange step's device time, every rank's own step time, and host (B)
+    x = d["exchange"]
+    assert x["early_reduce"] is True and set(x["allreduce_us"]) == {"tail", "head"} and all(v > 0 for v in x["allreduce_us"].values())
+    assert x["backend"] == "gloo" and x["rccl_version"] is None and x["bucket_bytes"] == (418435 + 1) * 4
+    r = x["ms_per_step_per_rank"]
+    assert len(r["all"]) == 2 and 0 < r["min"] <= r["max"] and r["max"] <= d["ms_per_step"] * 1.0001
+    b = d["in_process"]
+    assert "error" not in b, b
+    assert b["replicas"] == 2 and b["devices"] == [0, 0] and b["global_batch"] == 64 and b["value"] > 0 and b["host_us_per_start_training"] > 0
+    assert abs(b["value"] - 64 / (b["ms_per_step"] * 1e-3)) <= 1e-6 * b["value"]
+
+
+def test_in_process_host_rehearsed_with_two_replicas_on_one_gpu():
+    """Host (B) as its own line: ONE process, anh_set_devices([0, 0]) — the path /root/reference/annonet_train_main.cpp:583-614 would use
+    unchanged — StartTraining with 64 host samples per step, persistent worker threads, the in-library exchange (rehearsal transport)."""
+    d = run_bench("--in-process", "--devices", "0,0", "--steps", "9", "--warmup", "2", "--prewarm-s", "0.3")
+    assert d["replicas"] == 2 and d["devices"] == [0, 0] and d["n_gpus"] == 1 and d["global_batch"] == 64 and d["unit"] == "tiles/s"
+    assert d["value"] > 0 and abs(d["value"] - 64 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    assert 0 < d["host_us_per_start_training"] <= 1e3 * d["ms_per_step"] * 1.5
+    assert d["worker_wakeups_per_step"] == 1.0                    # ONE wake-up of the persistent workers per StartTraining
+    x = d["exchange"]
+    assert x["early_reduce"] is True and x["sampled_steps"] >= 1 and x["allreduce_tail_us"] > 0 and x["allreduce_head_us"] > 0
+    assert x["transport"].startswith("repeated-device") and x["bucket_bytes"] == (418435 + 1) * 4 and x["rccl_version"] > 0

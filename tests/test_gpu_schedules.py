@@ -56,6 +56,9 @@ def test_schedule_is_bit_identical(tmp_path, default_run, name, env):
     ("bn_sums_as_partials_with_finalize_kernels", {"ANH_BN_TABLES": "0"}),
     ("bn_backward_sums_kept_by_the_consumer_waves", {"ANH_WS_PSTAT": "0"}),
     ("bn_backward_sums_kept_by_the_producer_waves_wherever_they_fit", {"ANH_WS_PSTAT": "2"}),
+    ("bn_backward_sums_split_between_the_roles_stride_1", {"ANH_WS_PSTAT": "3"}),
+    ("bn_backward_sums_split_between_the_roles_every_geometry_that_can", {"ANH_WS_PSTAT": "4"}),
+    ("conv_tiles_walked_with_the_grid_stride", {"ANH_WS_XCD_BANDS": "0"}),
     ("separate_reduce_pass_for_the_layer_behind_the_64_channel_up_conv", {"ANH_WS_WIDE_PS": "0"}),
     ("fused_head_on_768_workgroups", {"ANH_HEAD_BLOCKS": "768"}),
     ("separate_bn_statistics", {"ANH_FUSE_BN_STATS": "0"}),

@@ -47,6 +47,7 @@ def test_sharded_inference_assembles_the_single_process_result(world):
         got_lab = np.full((H, W), -1, dtype=np.int64)
         got_pl = np.zeros((3, H, W), dtype=np.float32)
         bands, gather0 = [], None    # step 4: LabelGather — the coded row bands rank 0 receives, merged there
+        host_maps = []               # step 4': HostLabelMap — every rank copies the cells of its own tiles into ONE shared host map
         for r in range(world):       # steps 2b + 3: scatter the sums back, label the rank's rows
             ex.unpack(planes[r], total)
             lab = torch.zeros((H, W), dtype=torch.int16, device=dev)
@@ -56,6 +57,8 @@ def test_sharded_inference_assembles_the_single_process_result(world):
             g = aad.LabelGather(tiles, world, r, W, H, dev, 3)
             gather0 = gather0 or g
             bands.append(g.code(lab))
+            host_maps.append(aad.HostLabelMap(tiles, world, r, W, H, name=host_maps[0].name if host_maps else None))
+            host_maps[-1].deliver(lab.data_ptr(), stream.cuda_stream)
             torch.cuda.synchronize()
             lab_np, pl_np = lab.cpu().numpy().view(np.uint16), planes[r].cpu().numpy()
             for i, (full, _) in enumerate(tiles):   # a rank answers for the pixels its tiles cover
@@ -69,6 +72,11 @@ def test_sharded_inference_assembles_the_single_process_result(world):
                 got_pl[:, tp_:b + 1, l:rr + 1] = pl_np[:, tp_:b + 1, l:rr + 1]
     assert (got_lab >= 0).all()
     np.testing.assert_array_equal(aad.LabelGather.decode(gather0.merge(bands)).cpu().numpy().view(np.uint16).astype(np.int64), got_lab)   # the ONE map of the job
+    # ... and the ONE host map the ranks filled themselves: the same labels, every byte written by exactly one rank
+    np.testing.assert_array_equal(host_maps[0].array.astype(np.int64), got_lab)
+    assert sum(m.bytes for m in host_maps) == H * W * 2 and all(m.pinned for m in host_maps)
+    for m in reversed(host_maps):
+        m.close()
     want_pl_np, want_lab_np = want_pl.cpu().numpy(), want_lab.cpu().numpy().view(np.uint16).astype(np.int64)
     span = float(want_pl_np.max() - want_pl_np.min())
     np.testing.assert_allclose(got_pl, want_pl_np, rtol=0, atol=2e-6 * span)      # (a+b)+(c+d) vs ((a+b)+c)+d in four-tile corners
