@@ -41,7 +41,7 @@ class WLabel(C.Structure):
 class ExchangeStats(C.Structure):   # anh_exchange_stats
     _fields_ = [("replicas", C.c_int), ("early_reduce", C.c_int), ("uses_rccl", C.c_int), ("rccl_version", C.c_int),
                 ("steps", C.c_int64), ("samples", C.c_int64), ("worker_calls", C.c_int64), ("bucket_bytes", C.c_int64),
-                ("host_us_mean", C.c_double), ("host_us_last", C.c_double),
+                ("host_us_mean", C.c_double), ("host_us_last", C.c_double), ("host_wait_us_mean", C.c_double),
                 ("allreduce_tail_us_mean", C.c_double), ("allreduce_head_us_mean", C.c_double),
                 ("allreduce_tail_us_last", C.c_double), ("allreduce_head_us_last", C.c_double)]
 

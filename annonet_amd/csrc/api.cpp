@@ -128,6 +128,7 @@ struct anh_trainer {
         DevBuf dev;
         hipEvent_t uploaded = nullptr, consumed = nullptr;   // H2D of this set done / the step that read it has finished
         bool in_flight = false;
+        double wait_us = 0;   // how long the last call that packed into this set waited for the GPU to release it
     };
     StageSet stage[2];
     hipStream_t copy_stream = nullptr;
@@ -144,7 +145,8 @@ struct anh_trainer {
     // what one StartTraining costs the host, and the exchange step on the device (anh_trainer_exchange_stats): host time of every call;
     // on every `xs_every`-th step an event pair around each part of the all-reduce on replica 0's streams (ANH_EXCHANGE_SAMPLE, default 8, 0 = never)
     struct ExchangeStats {
-        int64_t calls = 0; double host_us_sum = 0, host_us_last = 0;
+        int64_t calls = 0; double host_us_sum = 0, host_us_last = 0, wait_us_sum = 0;
+        uint64_t worker_calls_base = 0;
         hipEvent_t tail0 = nullptr, tail1 = nullptr, head0 = nullptr, head1 = nullptr;
         bool pending = false, split = false;
         int64_t samples = 0; double tail_us_sum = 0, head_us_sum = 0, tail_us_last = 0, head_us_last = 0;
@@ -899,7 +901,11 @@ anh_trainer::StageSet& stage_and_run(anh_trainer* h, Engine& e, anh_trainer::Sta
         HIP_CHECK(hipEventCreateWithFlags(&st.uploaded, hipEventDisableTiming));
         HIP_CHECK(hipEventCreateWithFlags(&st.consumed, hipEventDisableTiming));
     }
-    if (st.in_flight) HIP_CHECK(hipEventSynchronize(st.uploaded));   // the pinned block is free again (upload of step k-2 done)
+    if (st.in_flight) {   // the pinned block is free again once the upload of step k-2 is done: the one place a call blocks on the GPU
+        const auto w0 = std::chrono::steady_clock::now();
+        HIP_CHECK(hipEventSynchronize(st.uploaded));
+        st.wait_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - w0).count();
+    } else st.wait_us = 0;
     if (total > st.pinned_bytes) {
         if (st.in_flight) HIP_CHECK(hipEventSynchronize(st.consumed));
         if (st.pinned) HIP_CHECK(hipHostFree(st.pinned));
@@ -1017,6 +1023,7 @@ int anh_trainer_step(anh_trainer* h, const uint8_t* const* images, const anh_wla
         ++h->host_steps;
         h->xs.host_us_last = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - host_t0).count();
         h->xs.host_us_sum += h->xs.host_us_last;
+        h->xs.wait_us_sum += used[0]->wait_us;   // replica 0 packs on the calling thread: its wait is wall time of the call
         ++h->xs.calls;
     });
 }
@@ -1031,6 +1038,7 @@ int anh_trainer_exchange_stats(anh_trainer* h, anh_exchange_stats* out) {
         out->steps = xs.calls;
         out->host_us_mean = xs.calls ? xs.host_us_sum / (double)xs.calls : 0.0;
         out->host_us_last = xs.host_us_last;
+        out->host_wait_us_mean = xs.calls ? xs.wait_us_sum / (double)xs.calls : 0.0;
         out->samples = xs.samples;
         out->allreduce_tail_us_mean = xs.samples ? xs.tail_us_sum / (double)xs.samples : 0.0;
         out->allreduce_head_us_mean = xs.samples ? xs.head_us_sum / (double)xs.samples : 0.0;
@@ -1039,7 +1047,7 @@ int anh_trainer_exchange_stats(anh_trainer* h, anh_exchange_stats* out) {
         out->early_reduce = xs.split ? 1 : 0;
         out->uses_rccl = h->coll && h->coll->uses_rccl() ? 1 : 0;
         out->rccl_version = Collective::rccl_version();
-        out->worker_calls = h->workers ? (int64_t)h->workers->calls() : 0;
+        out->worker_calls = h->workers ? (int64_t)(h->workers->calls() - xs.worker_calls_base) : 0;
         out->bucket_bytes = h->eng ? ((int64_t)h->eng->spec.n_params + 1) * 4 : 0;
     });
 }
@@ -1047,7 +1055,8 @@ void anh_trainer_reset_exchange_stats(anh_trainer* h) {
     if (!h) return;
     try { h->collect_exchange_sample(); } catch (...) {}
     anh_trainer::ExchangeStats& xs = h->xs;
-    xs.calls = 0; xs.host_us_sum = 0; xs.samples = 0; xs.tail_us_sum = 0; xs.head_us_sum = 0;
+    xs.calls = 0; xs.host_us_sum = 0; xs.wait_us_sum = 0; xs.samples = 0; xs.tail_us_sum = 0; xs.head_us_sum = 0;
+    xs.worker_calls_base = h->workers ? h->workers->calls() : 0;
 }
 
 int anh_trainer_grad_buffer(anh_trainer* h, void** d_ptr, int64_t* count) {

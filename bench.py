@@ -669,7 +669,8 @@ def bench_in_process(args):
            "prewarm_s": args.prewarm_s if prewarm_steps else 0.0, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
            "dtype": args.precision, "data": "synthetic", "global_batch": n,
            "host_us_per_start_training": round(st["host_us_mean"], 1),
-           "host_note": "wall time the calling thread spends inside one StartTraining (packing 32 x replicas samples into pinned staging, uploads, the step's launches on every replica by persistent worker threads, the collectives, the update): the one-thread reference loop cannot step faster than this",
+           "host_busy_us_per_start_training": round(st["host_us_mean"] - st["host_wait_us_mean"], 1),
+           "host_note": "host_us: wall time the calling thread spends inside one StartTraining; host_busy_us: the same minus the time it is blocked on the GPU (a staging set is reused every second step: the call waits until the upload of step k-2 has left it) = what the host itself needs (packing 32 x replicas samples into pinned staging, uploads, the step's launches on every replica by persistent worker threads, the collectives, the update): the one-thread reference loop cannot step faster than this",
            "worker_wakeups_per_step": round(st["worker_calls"] / max(st["steps"], 1), 2),
            "exchange": {"allreduce_tail_us": round(st["allreduce_tail_us_mean"], 1), "allreduce_head_us": round(st["allreduce_head_us_mean"], 1), "sampled_steps": st["samples"],
                         "early_reduce": bool(st["early_reduce"]), "transport": "rccl" if st["uses_rccl"] else "repeated-device rehearsal (fixed-order sum kernel + copies)",

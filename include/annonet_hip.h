@@ -99,7 +99,7 @@ int anh_handle_replicas(void* handle, int is_trainer); /* number of replicas (de
 typedef struct {
     int replicas, early_reduce, uses_rccl, rccl_version;
     int64_t steps, samples, worker_calls, bucket_bytes;
-    double host_us_mean, host_us_last;
+    double host_us_mean, host_us_last, host_wait_us_mean; /* wall time of a call; of which blocked on the GPU (staging set of step k-2 still uploading) */
     double allreduce_tail_us_mean, allreduce_head_us_mean, allreduce_tail_us_last, allreduce_head_us_last;
 } anh_exchange_stats;
 int anh_trainer_exchange_stats(anh_trainer* h, anh_exchange_stats* out);
