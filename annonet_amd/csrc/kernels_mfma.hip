@@ -99,6 +99,35 @@ __device__ __forceinline__ uint4 add_bf16x8(const uint4& p, const uint4& q) {
                       pack2(lo_f(p.z) + lo_f(q.z), hi_f(p.z) + hi_f(q.z)), pack2(lo_f(p.w) + lo_f(q.w), hi_f(p.w) + hi_f(q.w)));
 }
 
+#ifndef ANH_WS_DEFER_STORES_BUILD
+#define ANH_WS_DEFER_STORES_BUILD 0
+#endif
+// ---- deferred stores (round 4; measured slower, compiled out by default: see CAN_DEFER in conv3x3_ws_kernel) ----
+// The consumers' epilogue used to end with a burst of 16-byte stores (ACC x NT x 2 per lane: 32-64 KB per workgroup and tile) that the
+// wave must ISSUE before it can meet the producers at the barrier and start the next MFMA phase; the write path of a CU takes them at its
+// own pace, so the matrix cores idled behind a full store queue.  Deferred form: the epilogue leaves the packed values and their byte
+// offsets in registers, and the NEXT item's MFMA nest issues them one at a time between its MFMA groups (18 hook points per item), as
+// buffer stores whose offset is 0xFFFFFFF0 for pixels outside the tensor — the buffer's bound check drops those, no branch in the nest.
+struct NoHook { __device__ __forceinline__ void operator()(int) const {} };
+template <int S> struct DeferredStores { u32x4 q[S]; unsigned off[S]; };
+template <int S>
+struct StoreHook {
+    const DeferredStores<S>& d;
+    __amdgpu_buffer_rsrc_t rsrc;
+    __device__ __forceinline__ void operator()(int i) const {
+        constexpr int STEP = 16 / S < 1 ? 1 : 16 / S;          // S = 4 / 8 / 16 stores over hook points 1 .. 16
+        if (i >= 1 && (i - 1) % STEP == 0 && (i - 1) / STEP < S) {
+            const int j = (i - 1) / STEP;
+            __builtin_amdgcn_raw_buffer_store_b128(d.q[j], rsrc, (int)d.off[j], 0, 0);
+        }
+    }
+};
+template <int S>
+__device__ __forceinline__ void flush_deferred(const DeferredStores<S>& d, __amdgpu_buffer_rsrc_t rsrc) {
+#pragma unroll
+    for (int j = 0; j < S; ++j) __builtin_amdgcn_raw_buffer_store_b128(d.q[j], rsrc, (int)d.off[j], 0, 0);
+}
+
 // Epilogue buffer (conv3x3_ws, producer-side bn backward sums): pixel slot q holds the stored values of its NT*32 channels as
 // 16-byte chunks k = channel / 8, chunk index XOR-ed so that the eight lanes of a ds_write_b128 group hit distinct banks.
 template <int NT> __device__ __forceinline__ int ebuf_swizzle(int q) { return NT == 1 ? (q >> 2) & 3 : (q >> 1) & 7; }
@@ -250,6 +279,35 @@ __device__ __forceinline__ void store_pixel_tiles_act(const f32x16 (&acc)[NT], c
             auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
             auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
             if (valid) *reinterpret_cast<uint4*>(out + base + nt * 32 + 16 * s) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+        }
+    }
+}
+
+// The same epilogue with the stores deferred: packed values and byte offsets into `d` (slots s0 .. s0 + 2 NT - 1).
+template <int NT, int S>
+__device__ __forceinline__ void pack_pixel_tiles_act(const f32x16 (&acc)[NT], const ConvArgs& a, size_t pix, bool valid, int half, int co_base, const float* act, int cw,
+                                                     DeferredStores<S>& d, int s0) {
+    const size_t base = pix * a.c_out + co_base + 8 * half;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        float v[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 sc = *reinterpret_cast<const float4*>(act + nt * 32 + 8 * q + 4 * half);
+            const float4 sh = *reinterpret_cast<const float4*>(act + cw + nt * 32 + 8 * q + 4 * half);
+            v[4 * q + 0] = fmaf(acc[nt][4 * q + 0], sc.x, sh.x);
+            v[4 * q + 1] = fmaf(acc[nt][4 * q + 1], sc.y, sh.y);
+            v[4 * q + 2] = fmaf(acc[nt][4 * q + 2], sc.z, sh.z);
+            v[4 * q + 3] = fmaf(acc[nt][4 * q + 3], sc.w, sh.w);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const unsigned a0 = relu_bf16x2(pack2(v[8 * s + 0], v[8 * s + 1])), a1 = relu_bf16x2(pack2(v[8 * s + 2], v[8 * s + 3]));
+            const unsigned b0 = relu_bf16x2(pack2(v[8 * s + 4], v[8 * s + 5])), b1 = relu_bf16x2(pack2(v[8 * s + 6], v[8 * s + 7]));
+            auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+            auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+            d.q[s0 + nt * 2 + s] = u32x4{r0[0], r1[0], r0[1], r1[1]};
+            d.off[s0 + nt * 2 + s] = valid ? (unsigned)((base + nt * 32 + 16 * s) * 2) : 0xFFFFFFF0u;
         }
     }
 }
@@ -1069,8 +1127,8 @@ struct GeoS1 {
     // (Round 3: a hand-pinned two-register-set form of this nest — all ten fragments of step i + 1 requested behind the second MFMA of
     // step i — shortens the instrumented MFMA phase by 17 % (27 -> 22.7 us on the 64->64 forward) and leaves the step where it was:
     // 1.741 vs 1.738 ms for this plain nest, same box.  What did pay is registers: see HAS_FWD_FORM in launch_ws.)
-    template <int NT>
-    __device__ static void mfma(f32x16 (&acc)[ACC][NT], const Bases& b, const char* (&wb)[2]) {
+    template <int NT, class H = NoHook>
+    __device__ static void mfma(f32x16 (&acc)[ACC][NT], const Bases& b, const char* (&wb)[2], const H& hook = H()) {
         constexpr int C_OUT = NT * 32;
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
@@ -1088,6 +1146,7 @@ struct GeoS1 {
 #pragma unroll
                         for (int g = 0; g < 2; ++g) acc[g][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf[g + ky], acc[g][nt], 0, 0, 0);
                     }
+                    hook((kx * 2 + ks) * 3 + ky);   // 18 hook points per item (deferred stores of the previous tile)
                 }
             }
         }
@@ -1118,8 +1177,8 @@ struct GeoDown {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) b.x[kh][ks] = swz_addr(lds_x, wave * 4 * 33 + col + kh, (col + kh) >> 2, ks, half);
     }
-    template <int NT>
-    __device__ static void mfma(f32x16 (&acc)[ACC][NT], const Bases& b, const char* (&wb)[2]) {
+    template <int NT, class H = NoHook>
+    __device__ static void mfma(f32x16 (&acc)[ACC][NT], const Bases& b, const char* (&wb)[2], const H& hook = H()) {
         constexpr int C_OUT = NT * 32;
 #pragma unroll
         for (int tl = 0; tl < 9; ++tl) {
@@ -1132,6 +1191,7 @@ struct GeoDown {
                     const bf16x8 wf = lds_frag(wb[ks] + (tl * C_OUT + nt * 32) * 64);
                     acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc[0][nt], 0, 0, 0);
                 }
+                hook(tl * 2 + ks);
             }
         }
     }
@@ -1156,9 +1216,10 @@ struct GeoUp {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) b.x[ib][ks] = swz_addr(lds_x, wave * 33 + col + 1 - ib, (col + 1 - ib) >> 2, ks, half);
     }
-    template <int NT>
-    __device__ static void mfma(f32x16 (&acc)[ACC][NT], const Bases& b, const char* (&wb)[2]) {
+    template <int NT, class H = NoHook>
+    __device__ static void mfma(f32x16 (&acc)[ACC][NT], const Bases& b, const char* (&wb)[2], const H& hook = H()) {
         constexpr int C_OUT = NT * 32;
+        int hidx = 0;   // (a compile-time constant at every hook call once the nest is unrolled)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 xf[2][2];  // [ia][ib]: input (i - ia, j - ib)
@@ -1180,6 +1241,7 @@ struct GeoUp {
                                 const bf16x8 wf = lds_frag(wb[ks] + (tap * C_OUT + nt * 32) * 64);
                                 acc[py * 2 + px][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf[ia][ib], acc[py * 2 + px][nt], 0, 0, 0);
                             }
+                            hook(hidx++);
                         }
         }
     }
@@ -1213,6 +1275,11 @@ struct GeoUp {
 // plain-copy (backward-data) forms the consumers' epilogue is as long as their MFMA phase while the producers wait at the hand-over
 // barrier for a third to half of the kernel; moving ALL of the sums over (PS = 1) made the producers the long pole in every geometry but
 // one — half of them balances the two roles.
+// PS = 3 (round 4): the consumers keep ALL the sums, but their y operands arrive through LDS: the producer waves — idle at the hand-over
+// barrier for a third to half of a backward-data kernel — fetch the tile's y chunks beside the patch of the next item and leave them in
+// the epilogue buffer; the consumers read them there when the epilogue starts.  The consumers then carry no prefetched y registers
+// (ACC x NT x 8 VGPRs) through their MFMA phase — the register pressure that makes hipcc schedule the backward forms' MFMA nest with
+// three operand sets instead of seven (see HAS_FWD_FORM below) — and never wait on global memory in the epilogue.
 template <class G, int NT, int KIND, bool FWD = false, bool ACT = false, int PS = 0, bool HEAD = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tiles_x, int tiles_y, int flip, long long* prof, int wres_, int e_off) {
     // per-phase wall-clock accounting, compiled in with -DANH_WS_PROFILE (ANH_WS_PROF=1 then prints one line per launch)
@@ -1228,7 +1295,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
 #endif
     constexpr int C_OUT = NT * 32, NP = (G::RECS * 4 + 255) / 256, W_ITEMS = 9 * C_OUT * 4, NW = (W_ITEMS + 255) / 256;
     constexpr int X_BYTES_ = G::RECS * 64, W_BYTES = 9 * C_OUT * 64, BUF = X_BYTES_ + W_BYTES;
-    const int wres = wres_ & 1, role_map = (wres_ >> 1) & 1, prio = (wres_ >> 2) & 3, bands = (wres_ >> 4) & 1;   // (see the role map below; prio: experiment switch ANH_WS_PRIO)
+    const int wres = wres_ & 1, role_map = (wres_ >> 1) & 1, prio = (wres_ >> 2) & 3, bands = (wres_ >> 4) & 1;
+    const bool defer = (wres_ >> 5) & 1;   // the epilogue's stores ride in the next item's MFMA nest (DeferredStores)   // (see the role map below; prio: experiment switch ANH_WS_PRIO)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // LDS layout.  Streaming form: [X | W] [X | W] tables — the filter slab of every item travels with its patch.
     // Resident form (wres; the filter slabs of ALL reduction slabs fit beside two patches, i.e. 64 reduction channels):
@@ -1262,7 +1330,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
     const bool fuse_stats = !PS && !ACT && CAN_STATS && (a.stat_partials != nullptr || a.stat_acc != nullptr);   // forward: bn statistics of the output
     const bool fuse_bnred = !FWD && (PS || CAN_STATS) && (a.bnred_partials != nullptr || a.bnred_acc != nullptr);  // backward-data: dgamma / dbeta sums of the layer `out` belongs to
     const int stat_mode = fuse_stats ? 1 : (fuse_bnred && PS != 1) ? 2 : 0;   // sums kept by the CONSUMER waves (PS = 2: of the groups g < PS_G0)
-    const bool ps = PS != 0 && fuse_bnred;                                 // sums kept by the producer waves (PS = 2: of the groups g >= PS_G0)
+    const bool ps = (PS == 1 || PS == 2) && fuse_bnred;                    // sums kept by the producer waves (PS = 2: of the groups g >= PS_G0)
+    const bool pl = PS == 3 && fuse_bnred;                                 // y operands of the consumers' sums staged through LDS by the producer waves
     constexpr int PS_G0 = PS == 2 ? G::ACC / 2 : 0, PS_GROUPS = G::ACC - PS_G0;   // the accumulator groups whose stored values go through the epilogue buffer
     constexpr int E_BYTES = PS_GROUPS * 128 * 64 * NT;                     // epilogue buffer: PS_GROUPS x 128 pixel slots of NT x 64 bytes
     constexpr int EK = 4 * NT, EQ_STEP = 256 / EK, ECH = PS_GROUPS * 128 / EQ_STEP;   // chunks per pixel; pixel slots between a thread's chunks; chunks per thread
@@ -1434,7 +1503,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
         float esc[8], esh[8];
         const int ek = tid & (EK - 1), eq0 = tid / EK;   // this thread's chunk (channels 8 ek .. 8 ek + 7 of the workgroup's) and first pixel slot
         int hist1 = -1, hist2 = -1, hist1_it = 0, hist2_it = 0;   // tile (or -1) and item index of the last two items whose epilogue leaves a buffer
-        if (PS) {
+        if (PS == 1 || PS == 2) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 esc[j] = bnc[ek * 8 + j]; esh[j] = bnc[C_OUT + ek * 8 + j];
@@ -1474,11 +1543,21 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
                 }
             }
         };
+        auto ystage = [&](int yit, const u32x4 (&yv)[ECH]) __attribute__((always_inline)) {   // PS = 3: this thread's y chunks of the item's tile -> epilogue buffer
+            char* eb = smem + e_off + (n_slabs == 1 ? (yit & 1) * E_BYTES : 0);
+#pragma unroll
+            for (int j = 0; j < ECH; ++j) {
+                const int q = eq0 + EQ_STEP * j;
+                *reinterpret_cast<u32x4*>(eb + q * (64 * NT) + ((ek ^ ebuf_swizzle<NT>(q)) << 4)) = yv[j];
+            }
+        };
         auto one_item = [&](Fetched& R) __attribute__((always_inline)) {
             u32x4 eyv[PS ? ECH : 1];
             unsigned evalid = 0;
             const int et = hist2, eit = hist2_it;
-            if constexpr (PS) { if (ps && et >= 0) estat_begin(et, eyv, evalid); }
+            if constexpr (PS == 1 || PS == 2) { if (ps && et >= 0) estat_begin(et, eyv, evalid); }
+            const bool ynow = PS == 3 && pl && slab == n_slabs - 1;   // the item the consumers' epilogue of `tile` follows
+            if constexpr (PS == 3) { if (ynow) estat_begin(tile, eyv, evalid); }
             TICK();
             commit(R);
 #ifdef ANH_WS_PROFILE
@@ -1488,7 +1567,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
             TICK();
             if (ftile < n_tiles) fetch(R);
             if (!wres && n_slabs > 1 && (slab + 1 < n_slabs || tile + gstep < n_tiles)) fetch_w(slab + 1 < n_slabs ? slab + 1 : 0);
-            if constexpr (PS) { if (ps && et >= 0) estat_end(eit, eyv, evalid); }
+            if constexpr (PS == 1 || PS == 2) { if (ps && et >= 0) estat_end(eit, eyv, evalid); }
+            if constexpr (PS == 3) { if (ynow) ystage(it, eyv); }
             TOCK(t_b);
             TICK();
             __syncthreads();  // buffer it & 1 is full; the consumers are done with buffer (it + 1) & 1
@@ -1513,7 +1593,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
         t_loop_end = wall_clock64();
         c_loop = clock64() - c_loop;
 #endif
-        if constexpr (PS) {
+        if constexpr (PS == 1 || PS == 2) {
             if (ps) {   // the last two items: the one before the last is ready, the last one after the consumers' closing barrier
                 u32x4 eyv[ECH];
                 unsigned evalid = 0;
@@ -1550,7 +1630,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
         constexpr bool DEEP = !FWD && NT == 1 && G::RMW_PREFETCH, DEEP_Y = false;
         u32x4 old_n[DEEP ? G::ACC : 1][NT][2], yraw_n[DEEP_Y ? G::ACC : 1][NT][2];
         const bool rmw_any = !FWD && G::RMW_PREFETCH && a.out_accumulate;
-        const bool cons_bnred = fuse_bnred && PS != 1;   // the consumers keep (some of) the bn backward sums (and fetch y for them)
+        const bool cons_bnred = fuse_bnred && PS != 1;   // the consumers keep (some of) the bn backward sums (and fetch y for them, unless PS = 3)
         const bool pre_any = rmw_any || cons_bnred;
         auto prefetch_epilogue = [&](int t, auto& o, auto& y, bool want_old, bool want_y) __attribute__((always_inline)) {
             const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, n = t / (tiles_x * tiles_y);
@@ -1567,12 +1647,24 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
                     for (int s2 = 0; s2 < 2; ++s2) {
                         if constexpr (!FWD) {
                             if (want_old) o[g][nt][s2] = *reinterpret_cast<const u32x4*>(out + e0 + nt * 32 + 16 * s2);
-                            if (want_y && (PS != 2 || g < PS_G0)) y[g][nt][s2] = *reinterpret_cast<const u32x4*>(yl + e0 + nt * 32 + 16 * s2);
+                            if (want_y && PS != 3 && (PS != 2 || g < PS_G0)) y[g][nt][s2] = *reinterpret_cast<const u32x4*>(yl + e0 + nt * 32 + 16 * s2);
                         }
                     }
             }
         };
         if (DEEP && pre_any && tile < n_tiles) prefetch_epilogue(tile, old, yraw, rmw_any, cons_bnred && DEEP_Y);
+        // deferred stores (ACT forms without the head; `defer` = wres_ bit 5, a launch-time switch): see DeferredStores
+        // MEASURED (same-box A/B, three rounds): 4,320 -> 3,970 Mpx/s — the stores stall the in-order wave INSIDE its MFMA stream instead of
+        // behind it, and the second nest + 16-32 held registers take the stride-1 / up forms from 154-166 to 242 VGPRs.  Compiled out
+        // (-DANH_WS_DEFER_STORES_BUILD=1 brings it back, ANH_WS_DEFER_STORES=0/1 then switches it per process); labels bit-identical either way.
+#ifndef ANH_WS_DEFER_STORES_BUILD
+#define ANH_WS_DEFER_STORES_BUILD 0
+#endif
+        constexpr bool CAN_DEFER = ANH_WS_DEFER_STORES_BUILD && ACT && !HEAD && G::ACC * NT < 8;   // (eight accumulator tiles + sixteen deferred register sets do not fit: 336 spilled VGPRs)
+        constexpr int DS = CAN_DEFER ? G::ACC * NT * 2 : 1;
+        DeferredStores<DS> dst;
+        bool dpending = false;
+        const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)a.out_bytes, 0x00020000);
         float stat[NT][2][16];      // per-lane running sums of this lane's 8 channels per (nt, s): see store_pixel_tiles_rmw
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
@@ -1612,7 +1704,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
                     if constexpr (!DEEP_Y) prefetch_epilogue(tile, old, yraw, false, cons_bnred);
                 } else prefetch_epilogue(tile, old, yraw, rmw_any, cons_bnred);
             }
-            G::template mfma<NT>(acc, b, wb);
+            if constexpr (CAN_DEFER) {
+                if (dpending) { G::template mfma<NT>(acc, b, wb, StoreHook<DS>{dst, out_rsrc}); dpending = false; }
+                else G::template mfma<NT>(acc, b, wb);
+            } else G::template mfma<NT>(acc, b, wb);
 #ifdef ANH_WS_PROFILE
             __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -1624,8 +1719,22 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
                     size_t pix; bool valid;
                     G::out_pixel(g, a, n, ty, tx, wave, col, pix, valid);
                     if constexpr (HEAD) store_pixel_tiles_head(acc[g][0], a, pix, n, valid, half, bnc, C_OUT, hw, hbias);
-                    else if constexpr (ACT) store_pixel_tiles_act<NT>(acc[g], a, pix, valid, half, co_base, bnc, C_OUT);
+                    else if constexpr (ACT) {
+                        if (defer) pack_pixel_tiles_act<NT, DS>(acc[g], a, pix, valid, half, co_base, bnc, C_OUT, dst, g * NT * 2);
+                        else store_pixel_tiles_act<NT>(acc[g], a, pix, valid, half, co_base, bnc, C_OUT);
+                    }
                     else {
+                        if constexpr (PS == 3) {   // the y operands of this group's sums: left in the epilogue buffer by the producer waves
+                            if (pl) {
+                                const char* eb = smem + e_off + (n_slabs == 1 ? (it & 1) * E_BYTES : 0);
+                                const int q = (g * 4 + wave) * 32 + col;
+#pragma unroll
+                                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                                    for (int s2 = 0; s2 < 2; ++s2)
+                                        yraw[g][nt][s2] = *reinterpret_cast<const u32x4*>(eb + q * (64 * NT) + (((nt * 4 + 2 * s2 + half) ^ ebuf_swizzle<NT>(q)) << 4));
+                            }
+                        }
                         const bool to_ebuf = ps && g >= PS_G0;   // (compile-time per unrolled g) this group's sums are the producers'
                         store_pixel_tiles_rmw<NT>(acc[g], a, pix, valid, half, co_base, old[FWD ? 0 : g], rmw, stat, (PS == 2 && g >= PS_G0) ? 0 : stat_mode, yraw[FWD ? 0 : g], bnc,
                                                   to_ebuf ? smem + e_off + (n_slabs == 1 ? (it & 1) * E_BYTES : 0) : nullptr, ((g - PS_G0) * 4 + wave) * 32 + col);
@@ -1643,10 +1752,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
                     }
                 }
             }
+            if constexpr (CAN_DEFER) { if (defer && last_slab) dpending = true; }
             TOCK(t_b);
             tile = ntile; slab = nslab; ++it;
         }
-        if constexpr (PS) { if (ps) __syncthreads(); }   // the consumers' closing barrier: the last tile's epilogue buffer is complete
+        if constexpr (CAN_DEFER) { if (dpending) flush_deferred<DS>(dst, out_rsrc); }
+        if constexpr (PS == 1 || PS == 2) { if (ps) __syncthreads(); }   // the consumers' closing barrier: the last tile's epilogue buffer is complete
         if (stat_mode) {
             __syncthreads();  // (matched by the producers) every wave is done with the staging buffers
             float* red = reinterpret_cast<float*>(smem) + (size_t)(wave * 64 + lane) * (32 * NT);
@@ -1689,7 +1800,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
             }
         }
     }
-    if constexpr (PS) {
+    if constexpr (PS == 1 || PS == 2) {
         if (ps) {   // the producers' 16 sums per thread -> (channel, which) = 64 NT sums, each over the 256 / EK threads that own the chunk, fixed order, in double
             __syncthreads();   // every wave is done with the staging buffers (and with the consumers' reduction above, PS = 2)
             if (producer) {
@@ -1762,6 +1873,8 @@ WsLayout ws_layout(const ConvArgs& a, int recs, int acc, int nt, bool with_bnred
     else if (ps_env == 1) mode = acc == 4 ? 1 : 0;
     else if (ps_env == 3) mode = acc == 4 ? 1 : (can_split ? 2 : 0);
     else if (ps_env == 4) mode = can_split ? 2 : (acc == 4 ? 1 : 0);
+    else if (ps_env == 5) mode = acc == 4 ? 1 : (acc * nt <= 4 ? 3 : 0);   // y through LDS (PS = 3) for the stride-1 and down geometries, the four-group geometry as 1
+    else if (ps_env == 6) mode = acc * nt <= 4 ? 3 : (acc == 4 ? 1 : 0);    // ... and for the four-group geometry at 32 channels
     const int e_groups = mode == 2 ? acc - acc / 2 : acc;
     const size_t e_total = (size_t)e_groups * 128 * 64 * nt * (n_slabs == 1 ? 2 : 1);
     if (mode && with_bnred && a.src.kind == SRC_RAW && !a.out_scale && !a.stat_partials && !a.stat_acc) {
@@ -1788,16 +1901,23 @@ void launch_ws(const ConvArgs& a, int tiles_x, int tiles_y, int flip, hipStream_
     // ANH_WS_XCD_BANDS (1): the workgroups of one XCD walk one contiguous eighth of the tile list (see the kernel); 0 = strided walk
     static const int bands_env = getenv("ANH_WS_XCD_BANDS") ? atoi(getenv("ANH_WS_XCD_BANDS")) : 1;
     const int bands = bands_env && grid.x % 8 == 0 && grid.x >= 8 ? 1 : 0;
-    const int role_map = (role_env == 1 || (role_env == 2 && NT == 1) ? 1 : 0) | ((prio_env & 3) << 1) | (bands << 3);
+    // ANH_WS_DEFER_STORES (1): the activation-storing (inference) forms issue a tile's stores inside the next item's MFMA nest; needs the
+    // output tensor below 4 GiB (32-bit buffer offsets; an offset of 0xFFFFFFF0 must lie outside it)
+    static const int defer_env = getenv("ANH_WS_DEFER_STORES") ? atoi(getenv("ANH_WS_DEFER_STORES")) : 1;
+    const unsigned long long out_bytes = (unsigned long long)a.n * a.h_out * a.w_out * a.c_out * 2ull;
+    const int defer = ANH_WS_DEFER_STORES_BUILD && defer_env && a.out_scale && !a.head_out && G::ACC * NT < 8 && out_bytes < 0xFFFFFF00ull ? 1 : 0;
+    ConvArgs a2 = a;
+    a2.out_bytes = (unsigned)std::min<unsigned long long>(out_bytes, 0xFFFFFF00ull);
+    const int role_map = (role_env == 1 || (role_env == 2 && NT == 1) ? 1 : 0) | ((prio_env & 3) << 1) | (bands << 3) | (defer << 4);
     auto launch = [&](auto kernel) {
         ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), lds);
 #ifndef ANH_WS_PROFILE
-        hipLaunchKernelGGL(kernel, grid, block, lds, s, a, tiles_x, tiles_y, flip, (long long*)nullptr, wres | (role_map << 1), e_off);
+        hipLaunchKernelGGL(kernel, grid, block, lds, s, a2, tiles_x, tiles_y, flip, (long long*)nullptr, wres | (role_map << 1), e_off);
 #else
         static const int prof_on = getenv("ANH_WS_PROF") ? atoi(getenv("ANH_WS_PROF")) : 0;
         static long long* prof = nullptr;
         if (prof_on && !prof) HIP_CHECK(hipMalloc(&prof, 1024 * 8 * 8 * sizeof(long long)));
-        hipLaunchKernelGGL(kernel, grid, block, lds, s, a, tiles_x, tiles_y, flip, prof_on ? prof : nullptr, wres | (role_map << 1), e_off);
+        hipLaunchKernelGGL(kernel, grid, block, lds, s, a2, tiles_x, tiles_y, flip, prof_on ? prof : nullptr, wres | (role_map << 1), e_off);
         if (prof_on) {
             HIP_CHECK(hipStreamSynchronize(s));
             const int nwg = grid.x * grid.y;
@@ -1871,6 +1991,9 @@ void launch_ws(const ConvArgs& a, int tiles_x, int tiles_y, int flip, hipStream_
     if (ps == 1) { launch(conv3x3_ws_kernel<G, NT, SRC_RAW, false, false, 1>); HIP_CHECK(hipGetLastError()); return; }
     if constexpr (G::ACC >= 2 && G::ACC * NT <= 4) {
         if (ps == 2) { launch(conv3x3_ws_kernel<G, NT, SRC_RAW, false, false, 2>); HIP_CHECK(hipGetLastError()); return; }
+    }
+    if constexpr (G::ACC * NT <= 4) {
+        if (ps == 3) { launch(conv3x3_ws_kernel<G, NT, SRC_RAW, false, false, 3>); HIP_CHECK(hipGetLastError()); return; }
     }
     switch (a.src.kind) {
         case SRC_RAW: launch(conv3x3_ws_kernel<G, NT, SRC_RAW>); break;

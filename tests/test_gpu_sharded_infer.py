@@ -156,6 +156,22 @@ def test_tile_batch_size_does_not_change_the_result(tmp_path):
     sep = np.load(out)
     for key in ("bf16_labels", "bf16_blended", "bf16_labels_streamed", "fp32_labels", "fp32_blended"):
         np.testing.assert_array_equal(sep[key], runs["4"][key], err_msg=f"head kernel: {key}")
+    # a tile's stores issued inside the NEXT item's MFMA nest (deferred stores, the default) against the burst at the end of the epilogue
+    # (ANH_WS_DEFER_STORES=0), and the XCD-band tile walk against the grid-stride walk: the same values to the same addresses
+    for env in ({"ANH_WS_DEFER_STORES": "0"}, {"ANH_WS_XCD_BANDS": "0"}):
+        out = str(tmp_path / ("variant_" + "_".join(env) + ".npz"))
+        r = subprocess.run([sys.executable, os.path.join(here, "helpers", "run_tiled_infer.py"), out, "1.0", "1", "3", "2"], env=dict(os.environ, **env),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        variant = np.load(out)
+        if "ref_w1" not in runs:
+            out0 = str(tmp_path / "ref_w1.npz")
+            r = subprocess.run([sys.executable, os.path.join(here, "helpers", "run_tiled_infer.py"), out0, "1.0", "1", "3", "2"], env=dict(os.environ),
+                               capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            runs["ref_w1"] = np.load(out0)
+        for key in ("bf16_labels", "bf16_blended", "bf16_labels_streamed"):
+            np.testing.assert_array_equal(variant[key], runs["ref_w1"][key], err_msg=f"{env}: {key}")
     # ... on the nets whose last hidden layer has the 32 channels that form covers (width 1.0), for every class count it takes
     for classes in ("1", "2", "3", "4"):
         pair = {}

@@ -34,7 +34,7 @@ KERNELS = [
     (r"^conv_mfma_f32:", [r"conv_f32_mfma"]),
     (r"^conv_generic_(bf16|f32):", [r"conv_generic|stem_forward_kernel|head_forward"]),
     (r"^wgrad_generic_(bf16|f32):", [r"wgrad_generic|wgrad_stem"]),
-    (r"^wgrad_reduce_partials$", [r"reduce_partials_kernel"]),
+    (r"^wgrad_reduce_partials(_main)?$", [r"reduce_partials_kernel"]),
     (r"^bn_forward_stats$", [r"bn_stats"]),
     (r"^bn_forward_finalize$", [r"bn_finalize_kernel"]),
     (r"^bn_bwd_reduce$", [r"bn_bwd_reduce"]),
