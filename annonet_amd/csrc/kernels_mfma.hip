@@ -62,6 +62,31 @@ __device__ __forceinline__ unsigned pack2(float lo, float hi) {
 __device__ __forceinline__ float lo_f(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float hi_f(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
 
+// Experiment (build flags, round 4): -DANH_NT_LOADS=1 makes the staging loads of the persistent kernels non-temporal, -DANH_NT_STORES=1
+// the conv epilogues' 16-byte stores (a CU's vector-memory pipeline is shared by the producers' loads and the consumers' stores; what
+// the instrumented build shows as the consumers' "store" phase is mostly stores waiting in that pipeline: profiles/r04_phase_budget_*).
+#ifndef ANH_NT_LOADS
+#define ANH_NT_LOADS 0
+#endif
+#ifndef ANH_NT_STORES
+#define ANH_NT_STORES 0
+#endif
+typedef __attribute__((ext_vector_type(4))) unsigned nt_u32x4;
+__device__ __forceinline__ uint4 load16(const void* p) {
+#if ANH_NT_LOADS
+    const nt_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_u32x4*>(p));
+    return make_uint4(v[0], v[1], v[2], v[3]);
+#else
+    return *reinterpret_cast<const uint4*>(p);
+#endif
+}
+__device__ __forceinline__ void store16(void* p, const uint4& v) {
+#if ANH_NT_STORES
+    __builtin_nontemporal_store(nt_u32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<nt_u32x4*>(p));
+#else
+    *reinterpret_cast<uint4*>(p) = v;
+#endif
+}
 __device__ __forceinline__ float relu_affine(float y, float s, float t) {
     const float z = fmaf(y, s, t);
     return z > 0.f ? z : 0.f;
@@ -132,6 +157,45 @@ __device__ __forceinline__ void flush_deferred(const DeferredStores<S>& d, __amd
 // 16-byte chunks k = channel / 8, chunk index XOR-ed so that the eight lanes of a ds_write_b128 group hit distinct banks.
 template <int NT> __device__ __forceinline__ int ebuf_swizzle(int q) { return NT == 1 ? (q >> 2) & 3 : (q >> 1) & 7; }
 
+#ifndef ANH_WS_TSTORE_BUILD
+#define ANH_WS_TSTORE_BUILD 0
+#endif
+// ---- transposed stores (round 4; MEASURED slower — training 1.685 / 1.679 / 1.665 -> 1.709 / 1.695 / 1.697 ms, inference unchanged, the
+// stride-1 kernels +3 ... +8 us each — and compiled out: -DANH_WS_TSTORE_BUILD=1 brings the form back, ANH_WS_TSTORE=0/1 then switches it) ----
+// After the permlane swap a lane holds 16 bytes of ITS pixel, so one store instruction of a wave is 64 pieces of 16 bytes, 64-256 bytes
+// apart: 64 requests in the CU's in-order texture-address / L1 pipeline where a contiguous kilobyte is 8 (full 128-byte lines).  The
+// instrumented build says the consumers' epilogue is mostly stores waiting to be issued behind the producers' loads in that pipeline
+// (profiles/r04_phase_budget_*), so the hypothesis was that the store's request count is what it pays for — it is not (see above; round 1's
+// address-pattern micro-benchmark had said the same: 5.0-5.4 vs 5.7 TB/s).  Transposed form: the wave writes the row's chunks to
+// a private LDS strip (32 pixels x 64 NT bytes, chunk index swizzled by the pixel), reads them back so that CONSECUTIVE LANES hold
+// CONSECUTIVE 16-byte chunks of memory (lane l: chunk l mod 4NT of pixel l / 4NT + (16 / NT) j), and stores whole lines.  Same wave, LDS
+// operations in program order: no barrier.  stage = nullptr: the direct form.
+struct RowStore {
+    char* stage;        // this wave's strip, or nullptr
+    size_t row_pix0;    // flat pixel index of the row's first pixel (column 32 tx), clamped into the tensor
+    int cols_valid;     // pixels of the row inside the image, counted from that column
+    bool row_valid;
+    int lane;
+};
+template <int NT>
+__device__ __forceinline__ void ts_store(const RowStore& ts, const ConvArgs& a, int co_base, const uint4 (&fin)[NT][2]) {
+    constexpr int CH = 4 * NT, PPI = 64 / CH;
+    const int col = ts.lane & 31, half = ts.lane >> 5;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+            *reinterpret_cast<uint4*>(ts.stage + col * (64 * NT) + (((nt * 4 + 2 * s + half) ^ ebuf_swizzle<NT>(col)) << 4)) = fin[nt][s];
+    bf16* out = reinterpret_cast<bf16*>(a.out);
+    const int k = ts.lane % CH, p0 = ts.lane / CH;
+#pragma unroll
+    for (int j = 0; j < NT * 2; ++j) {
+        const int p = p0 + PPI * j;
+        const uint4 v = *reinterpret_cast<const uint4*>(ts.stage + p * (64 * NT) + ((k ^ ebuf_swizzle<NT>(p)) << 4));
+        if (ts.row_valid && p < ts.cols_valid) store16(out + (ts.row_pix0 + p) * a.c_out + co_base + k * 8, v);
+    }
+}
+
 // NT 32-channel accumulator tiles of one pixel per lane -> NHWC bf16.  Lane = pixel x half; registers 4q..4q+3 of a tile
 // hold channels 8q + 4*half + 0..3, so two v_permlane32_swap per 16 channels leave 8 consecutive channels (16 bytes) in
 // every lane.  With "accumulate" the old values are fetched by one batch of unconditional loads (pix is clamped by the
@@ -145,7 +209,7 @@ __device__ __forceinline__ void store_pixel_tiles_rmw(const f32x16 (&acc)[NT], c
                                                       const u32x4 (&prefetched)[NT][2], bool use_prefetched,
                                                       float (*stat)[2][16] = nullptr, int stat_mode = 0,
                                                       const u32x4 (*yraw)[2] = nullptr, const float* bnc = nullptr,
-                                                      char* ebuf = nullptr, int eq = 0) {
+                                                      char* ebuf = nullptr, int eq = 0, const RowStore& ts = RowStore{nullptr, 0, 0, false, 0}) {
     const int C_OUT = a.c_out;  // a workgroup may own only NT*32 of the layer's output channels, starting at co_base
     uint4 q[NT][2];
 #pragma unroll
@@ -179,11 +243,12 @@ __device__ __forceinline__ void store_pixel_tiles_rmw(const f32x16 (&acc)[NT], c
 #pragma unroll
             for (int s = 0; s < 2; ++s) fin[nt][s] = q[nt][s];
     }
-    if (valid) {
+    if (ts.stage) ts_store<NT>(ts, a, co_base, fin);
+    else if (valid) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int s = 0; s < 2; ++s) *reinterpret_cast<uint4*>(out + base + nt * 32 + 16 * s) = fin[nt][s];
+            for (int s = 0; s < 2; ++s) store16(out + base + nt * 32 + 16 * s, fin[nt][s]);
     }
     if (ebuf) {   // the final values also go to the workgroup's epilogue buffer: the staging waves form the bn backward sums from them
 #pragma unroll
@@ -257,9 +322,11 @@ __device__ __forceinline__ void store_pixel_tiles_rmw(const f32x16 (&acc)[NT], c
 // Register r of a tile holds channel 8 (r >> 2) + 4 half + (r & 3) BEFORE the permlane swap; act = [scale | shift][cw] of the
 // workgroup's channels (LDS table or global memory).
 template <int NT>
-__device__ __forceinline__ void store_pixel_tiles_act(const f32x16 (&acc)[NT], const ConvArgs& a, size_t pix, bool valid, int half, int co_base, const float* act, int cw) {
+__device__ __forceinline__ void store_pixel_tiles_act(const f32x16 (&acc)[NT], const ConvArgs& a, size_t pix, bool valid, int half, int co_base, const float* act, int cw,
+                                                      const RowStore& ts = RowStore{nullptr, 0, 0, false, 0}) {
     bf16* out = reinterpret_cast<bf16*>(a.out);
     const size_t base = pix * a.c_out + co_base + 8 * half;
+    uint4 fin[NT][2];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         float v[16];
@@ -278,8 +345,15 @@ __device__ __forceinline__ void store_pixel_tiles_act(const f32x16 (&acc)[NT], c
             const unsigned b0 = relu_bf16x2(pack2(v[8 * s + 4], v[8 * s + 5])), b1 = relu_bf16x2(pack2(v[8 * s + 6], v[8 * s + 7]));
             auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
             auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
-            if (valid) *reinterpret_cast<uint4*>(out + base + nt * 32 + 16 * s) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+            fin[nt][s] = make_uint4(r0[0], r1[0], r0[1], r1[1]);
         }
+    }
+    if (ts.stage) ts_store<NT>(ts, a, co_base, fin);
+    else if (valid) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) store16(out + base + nt * 32 + 16 * s, fin[nt][s]);
     }
 }
 
@@ -725,8 +799,8 @@ __device__ __forceinline__ void wg_ksteps(const char* ta0, const char* ta1, cons
 template <int KIND>
 __device__ __forceinline__ RawChunk<KIND> side_load_at(const bf16* a, const bf16* b, int off) {
     RawChunk<KIND> r;
-    r.a = *reinterpret_cast<const uint4*>(a + off);
-    if (KIND == SRC_ACT2 || KIND == SRC_SUM2) r.b = *reinterpret_cast<const uint4*>(b + off);
+    r.a = load16(a + off);
+    if (KIND == SRC_ACT2 || KIND == SRC_SUM2) r.b = load16(b + off);
     return r;
 }
 
@@ -1151,6 +1225,13 @@ struct GeoS1 {
             }
         }
     }
+    static constexpr bool TS_OK = true;   // a wave's group is 32 consecutive pixels of one output row: transposed stores apply
+    __device__ static void row_origin(int g, const ConvArgs& a, int n, int ty, int tx, int wave, size_t& row_pix0, bool& row_valid, int& cols_valid) {
+        const int oy = ty * TH + wave * 2 + g, ox0 = tx * TW;
+        row_valid = oy < a.h_out && ox0 < a.w_out;
+        cols_valid = a.w_out - ox0;
+        row_pix0 = ((size_t)n * a.h_out + (row_valid ? oy : 0)) * a.w_out + (row_valid ? ox0 : 0);
+    }
     // output pixel of accumulator group g (one lane = one pixel): row 2*wave + g of the tile
     __device__ static void out_pixel(int g, const ConvArgs& a, int n, int ty, int tx, int wave, int col, size_t& pix, bool& valid) {
         const int oy = ty * TH + wave * 2 + g, ox = tx * TW + col;
@@ -1194,6 +1275,13 @@ struct GeoDown {
                 hook(tl * 2 + ks);
             }
         }
+    }
+    static constexpr bool TS_OK = true;
+    __device__ static void row_origin(int, const ConvArgs& a, int n, int ty, int tx, int wave, size_t& row_pix0, bool& row_valid, int& cols_valid) {
+        const int oy = ty * 4 + wave, ox0 = tx * 32;
+        row_valid = oy < a.h_out && ox0 < a.w_out;
+        cols_valid = a.w_out - ox0;
+        row_pix0 = ((size_t)n * a.h_out + (row_valid ? oy : 0)) * a.w_out + (row_valid ? ox0 : 0);
     }
     __device__ static void out_pixel(int, const ConvArgs& a, int n, int ty, int tx, int wave, int col, size_t& pix, bool& valid) {
         const int oy = ty * 4 + wave, ox = tx * 32 + col;
@@ -1245,6 +1333,8 @@ struct GeoUp {
                         }
         }
     }
+    static constexpr bool TS_OK = false;  // a group's pixels are every second column of an output row
+    __device__ static void row_origin(int, const ConvArgs&, int, int, int, int, size_t& row_pix0, bool& row_valid, int& cols_valid) { row_pix0 = 0; row_valid = false; cols_valid = 0; }
     // accumulator group g = output parity class (py, px) = (g >> 1, g & 1) of low-res position (i, j)
     __device__ static void out_pixel(int g, const ConvArgs& a, int n, int ty, int tx, int wave, int col, size_t& pix, bool& valid) {
         const int oy = 2 * (ty * 4 + wave) + (g >> 1), ox = 2 * (tx * 32 + col) + (g & 1);
@@ -1281,10 +1371,12 @@ struct GeoUp {
 // (ACC x NT x 8 VGPRs) through their MFMA phase — the register pressure that makes hipcc schedule the backward forms' MFMA nest with
 // three operand sets instead of seven (see HAS_FWD_FORM below) — and never wait on global memory in the epilogue.
 template <class G, int NT, int KIND, bool FWD = false, bool ACT = false, int PS = 0, bool HEAD = false>
-__global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tiles_x, int tiles_y, int flip, long long* prof, int wres_, int e_off) {
+__global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tiles_x, int tiles_y, int flip, long long* prof, int wres_, int e_off_) {
     // per-phase wall-clock accounting, compiled in with -DANH_WS_PROFILE (ANH_WS_PROF=1 then prints one line per launch)
 #ifdef ANH_WS_PROFILE
-    long long t_a = 0, t_b = 0, t_c = 0, t0_;
+    long long t_a = 0, t_b = 0, t_c = 0, t_d = 0, t0_;
+    float prof_sink = 0.f;
+    const bool prof_nostore = (wres_ >> 6) & 1;   // ANH_WS_PROF_NOSTORE=1: the epilogue computes but stores nothing (timing only, results wrong)
     const long long t_entry = wall_clock64();   // absolute (the counter is chip-wide): launch skew, prologue and tail of the kernel
     long long t_loop = 0, t_loop_end = 0, c_loop = 0;   // c_loop: shader cycles (s_memtime) over the producers' loop -> the clock the kernel holds
 #define TICK() (t0_ = wall_clock64())
@@ -1296,7 +1388,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
     constexpr int C_OUT = NT * 32, NP = (G::RECS * 4 + 255) / 256, W_ITEMS = 9 * C_OUT * 4, NW = (W_ITEMS + 255) / 256;
     constexpr int X_BYTES_ = G::RECS * 64, W_BYTES = 9 * C_OUT * 64, BUF = X_BYTES_ + W_BYTES;
     const int wres = wres_ & 1, role_map = (wres_ >> 1) & 1, prio = (wres_ >> 2) & 3, bands = (wres_ >> 4) & 1;
-    const bool defer = (wres_ >> 5) & 1;   // the epilogue's stores ride in the next item's MFMA nest (DeferredStores)   // (see the role map below; prio: experiment switch ANH_WS_PRIO)
+    const bool defer = (wres_ >> 5) & 1;   // the epilogue's stores ride in the next item's MFMA nest (DeferredStores)
+    const int ts_off = (int)((unsigned)e_off_ >> 18) << 4, e_off = e_off_ & 0x3ffff;   // transposed stores: offset of the four consumer strips (0 = off)   // (see the role map below; prio: experiment switch ANH_WS_PRIO)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // LDS layout.  Streaming form: [X | W] [X | W] tables — the filter slab of every item travels with its patch.
     // Resident form (wres; the filter slabs of ALL reduction slabs fit beside two patches, i.e. 64 reduction channels):
@@ -1712,16 +1805,36 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
             __builtin_amdgcn_sched_barrier(0);
 #endif
             TOCK(t_a);
+#ifdef ANH_WS_PROFILE
+            // how long the wave waits for its last MFMAs before the first accumulator register can be read (the matrix pipe's drain)
+            TICK();
+            if (last_slab) { asm volatile("v_mov_b32 %0, %1" : "=v"(prof_sink) : "v"(acc[0][0][0])); asm volatile("v_mov_b32 %0, %1" : "=v"(prof_sink) : "v"(acc[G::ACC - 1][NT - 1][15])); }
+            __builtin_amdgcn_sched_barrier(0);
+            TOCK(t_d);
+#endif
             TICK();
             if (last_slab) {
 #pragma unroll
                 for (int g = 0; g < G::ACC; ++g) {
                     size_t pix; bool valid;
                     G::out_pixel(g, a, n, ty, tx, wave, col, pix, valid);
+#ifdef ANH_WS_PROFILE
+                    if (prof_nostore) valid = false;
+#endif
+                    RowStore ts{nullptr, 0, 0, false, lane};
+                    if constexpr (ANH_WS_TSTORE_BUILD && G::TS_OK && !HEAD) {
+                        if (ts_off && !a.out_accumulate && !a.out2) {
+                            ts.stage = smem + ts_off + wave * (32 * 64 * NT);
+                            G::row_origin(g, a, n, ty, tx, wave, ts.row_pix0, ts.row_valid, ts.cols_valid);
+#ifdef ANH_WS_PROFILE
+                            if (prof_nostore) ts.row_valid = false;
+#endif
+                        }
+                    }
                     if constexpr (HEAD) store_pixel_tiles_head(acc[g][0], a, pix, n, valid, half, bnc, C_OUT, hw, hbias);
                     else if constexpr (ACT) {
                         if (defer) pack_pixel_tiles_act<NT, DS>(acc[g], a, pix, valid, half, co_base, bnc, C_OUT, dst, g * NT * 2);
-                        else store_pixel_tiles_act<NT>(acc[g], a, pix, valid, half, co_base, bnc, C_OUT);
+                        else store_pixel_tiles_act<NT>(acc[g], a, pix, valid, half, co_base, bnc, C_OUT, ts);
                     }
                     else {
                         if constexpr (PS == 3) {   // the y operands of this group's sums: left in the epilogue buffer by the producer waves
@@ -1737,7 +1850,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
                         }
                         const bool to_ebuf = ps && g >= PS_G0;   // (compile-time per unrolled g) this group's sums are the producers'
                         store_pixel_tiles_rmw<NT>(acc[g], a, pix, valid, half, co_base, old[FWD ? 0 : g], rmw, stat, (PS == 2 && g >= PS_G0) ? 0 : stat_mode, yraw[FWD ? 0 : g], bnc,
-                                                  to_ebuf ? smem + e_off + (n_slabs == 1 ? (it & 1) * E_BYTES : 0) : nullptr, ((g - PS_G0) * 4 + wave) * 32 + col);
+                                                  to_ebuf ? smem + e_off + (n_slabs == 1 ? (it & 1) * E_BYTES : 0) : nullptr, ((g - PS_G0) * 4 + wave) * 32 + col,
+                                                  ts);
                     }
                 }
                 if constexpr (DEEP) {
@@ -1833,7 +1947,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
 #ifdef ANH_WS_PROFILE
     if (prof && lane == 0) {
         long long* o = prof + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (producer ? 4 : 0) + wave) * 8;
-        o[0] = t_a; o[1] = t_b; o[2] = t_c; o[3] = producer ? c_loop : it; o[4] = t_entry; o[5] = t_loop; o[6] = t_loop_end; o[7] = wall_clock64();
+        o[0] = t_a; o[1] = t_b; o[2] = t_c; o[3] = producer ? c_loop : it; o[4] = t_entry; o[5] = producer ? t_loop : t_d + (prof_sink == 12345.f ? 1 : 0); o[6] = t_loop_end; o[7] = wall_clock64();
     }
 #endif
 #undef TICK
@@ -1891,8 +2005,17 @@ void launch_ws(const ConvArgs& a, int tiles_x, int tiles_y, int flip, hipStream_
     const int n_tiles = tiles_x * tiles_y * a.n, groups = a.c_out / (NT * 32);
     const dim3 grid((unsigned)std::max(1, std::min(n_tiles, ws_target_wgs() / groups)), (unsigned)groups), block(512);
     const WsLayout lay = ws_layout(a, G::RECS, G::ACC, NT, a.bnred_partials != nullptr || a.bnred_acc != nullptr);
-    const int wres = lay.wres, e_off = lay.e_off;
-    const size_t lds = lay.lds;
+    const int wres = lay.wres;
+    size_t lds = lay.lds;
+    // ANH_WS_TSTORE (1): transposed stores (RowStore) — four wave-private LDS strips of 32 pixels x 64 NT bytes behind everything else,
+    // where they fit; the strips' offset rides in the upper bits of the kernel's e_off argument
+    static const int ts_env = getenv("ANH_WS_TSTORE") ? atoi(getenv("ANH_WS_TSTORE")) : 1;
+    int ts_off = 0;
+    if (ANH_WS_TSTORE_BUILD && ts_env && G::TS_OK && !a.head_out && !a.out_accumulate && !a.out2 && a.out_dtype == DT_BF16) {
+        const size_t at = (lds + 15) / 16 * 16, strips = (size_t)4 * 32 * 64 * NT;
+        if (at + strips <= 160 * 1024) { ts_off = (int)at; lds = at + strips; }
+    }
+    const int e_off = lay.e_off | ((ts_off >> 4) << 18);
     const int ps = lay.ps;
     // ANH_WS_ROLE_MAP: 0 = one producer + one consumer per SIMD, 1 = consumers on SIMDs 0-1 / producers on SIMDs 2-3, 2 = map 1 for the
     // 32-output-channel kernels only (their MFMA phase is short; the 64-channel kernels need all four matrix cores)
@@ -1917,18 +2040,19 @@ void launch_ws(const ConvArgs& a, int tiles_x, int tiles_y, int flip, hipStream_
         static const int prof_on = getenv("ANH_WS_PROF") ? atoi(getenv("ANH_WS_PROF")) : 0;
         static long long* prof = nullptr;
         if (prof_on && !prof) HIP_CHECK(hipMalloc(&prof, 1024 * 8 * 8 * sizeof(long long)));
-        hipLaunchKernelGGL(kernel, grid, block, lds, s, a2, tiles_x, tiles_y, flip, prof_on ? prof : nullptr, wres | (role_map << 1), e_off);
+        static const int nostore = getenv("ANH_WS_PROF_NOSTORE") ? atoi(getenv("ANH_WS_PROF_NOSTORE")) : 0;
+        hipLaunchKernelGGL(kernel, grid, block, lds, s, a2, tiles_x, tiles_y, flip, prof_on ? prof : nullptr, wres | (role_map << 1) | (nostore << 6), e_off);
         if (prof_on) {
             HIP_CHECK(hipStreamSynchronize(s));
             const int nwg = grid.x * grid.y;
             std::vector<long long> h((size_t)nwg * 64);
             HIP_CHECK(hipMemcpy(h.data(), prof, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
-            double pa = 0, pb = 0, pc = 0, ca = 0, cb = 0, cc = 0, items = 0;
+            double pa = 0, pb = 0, pc = 0, ca = 0, cb = 0, cc = 0, cd = 0, items = 0;
             long long first_entry = h[4], last_exit = h[7];
             double entry = 0, pro = 0, loop = 0, tail = 0, cycles = 0;   // over the producer waves: entry skew, entry -> loop, loop, loop end -> exit; shader cycles of the loop
             for (int w = 0; w < nwg; ++w) {
                 for (int v = 0; v < 8; ++v) { first_entry = std::min(first_entry, h[(w * 8 + v) * 8 + 4]); last_exit = std::max(last_exit, h[(w * 8 + v) * 8 + 7]); }
-                for (int v = 0; v < 4; ++v) { ca += h[(w * 8 + v) * 8]; cb += h[(w * 8 + v) * 8 + 1]; cc += h[(w * 8 + v) * 8 + 2]; }
+                for (int v = 0; v < 4; ++v) { ca += h[(w * 8 + v) * 8]; cb += h[(w * 8 + v) * 8 + 1]; cc += h[(w * 8 + v) * 8 + 2]; cd += h[(w * 8 + v) * 8 + 5]; }
                 for (int v = 4; v < 8; ++v) { pa += h[(w * 8 + v) * 8]; pb += h[(w * 8 + v) * 8 + 1]; pc += h[(w * 8 + v) * 8 + 2]; }
                 items += h[(w * 8) * 8 + 3];
             }
@@ -1939,9 +2063,9 @@ void launch_ws(const ConvArgs& a, int tiles_x, int tiles_y, int flip, hipStream_
                     cycles += (double)o[3];
                 }
             const double k = 1.0 / (4.0 * nwg) / 100.0;  // wall clock = 100 MHz -> us per wave
-            fprintf(stderr, "[ws prof] geo_recs=%d NT=%d kind=%d c_red=%d wgs=%d items/wg=%.1f | producer us: commit %.1f fetch %.1f barrier %.1f | consumer us: mfma %.1f store %.1f barrier %.1f"
+            fprintf(stderr, "[ws prof] geo_recs=%d NT=%d kind=%d c_red=%d wgs=%d items/wg=%.1f | producer us: commit %.1f fetch %.1f barrier %.1f | consumer us: mfma %.1f drain %.1f store %.1f barrier %.1f"
                             " | kernel %.1f us = launch skew %.1f + prologue %.1f + loop %.1f + tail %.1f (+ drain to the last wave) | clock in the loop %.0f MHz\n",
-                    G::RECS, NT, a.src.kind, a.c_red, nwg, items / nwg, pa * k, pb * k, pc * k, ca * k, cb * k, cc * k,
+                    G::RECS, NT, a.src.kind, a.c_red, nwg, items / nwg, pa * k, pb * k, pc * k, ca * k, cd * k, cb * k, cc * k,
                     (double)(last_exit - first_entry) / 100.0, entry * k, pro * k, loop * k, tail * k, loop > 0 ? cycles / loop * 100.0 : 0.0);
         }
 #endif

@@ -322,6 +322,19 @@ void conv_backward_filter(const Layer& L, const Tensor& x, const Tensor& dy, std
 // this path is checked against them (tests/test_oracle_gemm.py) and is what bench.py times as cpu_baseline.
 // ------------------------------------------------------------------------------------------
 struct ConGeo { int k, s, p, cb, cs; };
+// per-thread scratch that lives as long as the thread: a 0.25-1 MB vector created inside every parallel region is an mmap + page faults
+// + munmap per thread and call, and the unmaps' TLB shootdowns serialise a 16-thread team (measured on the GPU box's host: 16 threads
+// no faster than one)
+static std::vector<float>& tl_floats(int which, size_t n) {
+    static thread_local std::vector<float> buf[2];
+    if (buf[which].size() < n) buf[which].resize(n);
+    return buf[which];
+}
+static std::vector<double>& tl_doubles(size_t n) {
+    static thread_local std::vector<double> buf;
+    if (buf.size() < n) buf.resize(n);
+    return buf;
+}
 
 // C[M x N] (+)= A . B with A(i, k) = a[i * ars + k * aks], B and C row-major.
 template <int MR>
@@ -411,7 +424,7 @@ static void gemm_gather(const ConGeo& g, const float* W /*[(tap,cb)][cs]*/, cons
     const int kk = g.k * g.k * g.cb, rows = S.n * S.h;
 #pragma omp parallel
     {
-        std::vector<float> col((size_t)S.w * kk);
+        std::vector<float>& col = tl_floats(0, (size_t)S.w * kk);
 #pragma omp for schedule(dynamic, 1)
         for (int r = 0; r < rows; ++r) {
             const int n = r / S.h, sy = r % S.h;
@@ -425,7 +438,7 @@ static void gemm_scatter(const ConGeo& g, const float* WT /*[cs][(tap,cb)]*/, co
     const int kk = g.k * g.k * g.cb, rows = S.n * S.h, colours = (g.k + g.s - 1) / g.s;
 #pragma omp parallel
     {
-        std::vector<float> col((size_t)S.w * kk);
+        std::vector<float>& col = tl_floats(0, (size_t)S.w * kk);
         for (int colour = 0; colour < colours; ++colour) {
 #pragma omp for schedule(dynamic, 1)
             for (int r = 0; r < rows; ++r) {
@@ -453,8 +466,10 @@ static void gemm_filter(const ConGeo& g, const Tensor& B, const Tensor& S, std::
     dw.assign(nw, 0.0);
 #pragma omp parallel
     {
-        std::vector<float> col((size_t)S.w * kk), part(nw);
-        std::vector<double> local(nw, 0.0);
+        std::vector<float>& col = tl_floats(0, (size_t)S.w * kk);
+        std::vector<float>& part = tl_floats(1, nw);
+        std::vector<double>& local = tl_doubles(nw);
+        std::fill(local.begin(), local.begin() + nw, 0.0);
 #pragma omp for schedule(dynamic, 1)
         for (int r = 0; r < rows; ++r) {
             const int n = r / S.h, sy = r % S.h;
