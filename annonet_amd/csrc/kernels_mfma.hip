@@ -1389,6 +1389,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
     constexpr int X_BYTES_ = G::RECS * 64, W_BYTES = 9 * C_OUT * 64, BUF = X_BYTES_ + W_BYTES;
     const int wres = wres_ & 1, role_map = (wres_ >> 1) & 1, prio = (wres_ >> 2) & 3, bands = (wres_ >> 4) & 1;
     const bool defer = (wres_ >> 5) & 1;   // the epilogue's stores ride in the next item's MFMA nest (DeferredStores)
+    // ANH_WS_STAGGER (experiment): every second workgroup of an XCD starts 64 x n cycles late — persistent workgroups do identical work per
+    // item, so without it all 256 CUs issue their epilogue stores in the same short window of every item
+    {
+        const int stagger = (wres_ >> 8) & 0xff;
+        if (stagger && ((blockIdx.x >> 3) & 1)) for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(1);
+    }
     const int ts_off = (int)((unsigned)e_off_ >> 18) << 4, e_off = e_off_ & 0x3ffff;   // transposed stores: offset of the four consumer strips (0 = off)   // (see the role map below; prio: experiment switch ANH_WS_PRIO)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // LDS layout.  Streaming form: [X | W] [X | W] tables — the filter slab of every item travels with its patch.
@@ -2031,7 +2037,8 @@ void launch_ws(const ConvArgs& a, int tiles_x, int tiles_y, int flip, hipStream_
     const int defer = ANH_WS_DEFER_STORES_BUILD && defer_env && a.out_scale && !a.head_out && G::ACC * NT < 8 && out_bytes < 0xFFFFFF00ull ? 1 : 0;
     ConvArgs a2 = a;
     a2.out_bytes = (unsigned)std::min<unsigned long long>(out_bytes, 0xFFFFFF00ull);
-    const int role_map = (role_env == 1 || (role_env == 2 && NT == 1) ? 1 : 0) | ((prio_env & 3) << 1) | (bands << 3) | (defer << 4);
+    static const int stagger_env = getenv("ANH_WS_STAGGER") ? atoi(getenv("ANH_WS_STAGGER")) & 0xff : 0;
+    const int role_map = (role_env == 1 || (role_env == 2 && NT == 1) ? 1 : 0) | ((prio_env & 3) << 1) | (bands << 3) | (defer << 4) | (stagger_env << 7);
     auto launch = [&](auto kernel) {
         ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), lds);
 #ifndef ANH_WS_PROFILE

@@ -31,7 +31,8 @@ python3 tools/standalone_table.py $out/bench_one_stream.json > $out/standalone_t
 # `traffic` fields of its roofline objects come from the counter passes of THIS collection
 python3 tools/pmc_traffic.py $out/launch_order.json $out/fetch/*/*_counter_collection.csv $out/write/*/*_counter_collection.csv $out/traffic.json > $out/traffic.txt
 python3 tools/pmc_traffic.py $out/infer_launch_order.json $out/ifetch/*/*_counter_collection.csv $out/iwrite/*/*_counter_collection.csv $out/infer_traffic.json > $out/infer_traffic.txt
-export ANH_TRAFFIC_JSON=$PWD/$out/traffic.json ANH_INFER_TRAFFIC_JSON=$PWD/$out/infer_traffic.json
+python3 tools/pmc_counters.py $out/launch_order.json $out/sq/*/*_counter_collection.csv $out/sq_counters.json > $out/sq_counters.txt
+export ANH_TRAFFIC_JSON=$PWD/$out/traffic.json ANH_INFER_TRAFFIC_JSON=$PWD/$out/infer_traffic.json ANH_SQ_JSON=$PWD/$out/sq_counters.json
 python3 bench.py > $out/bench.json 2> $out/bench.err
 python3 bench.py --mode infer > $out/bench_infer_4096_bf16.json 2>> $out/infer.err
 echo collected; du -sh $out
