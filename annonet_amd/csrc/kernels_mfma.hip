@@ -209,7 +209,7 @@ __device__ __forceinline__ void store_pixel_tiles_rmw(const f32x16 (&acc)[NT], c
                                                       const u32x4 (&prefetched)[NT][2], bool use_prefetched,
                                                       float (*stat)[2][16] = nullptr, int stat_mode = 0,
                                                       const u32x4 (*yraw)[2] = nullptr, const float* bnc = nullptr,
-                                                      char* ebuf = nullptr, int eq = 0, const RowStore& ts = RowStore{nullptr, 0, 0, false, 0}) {
+                                                      char* ebuf = nullptr, int eq = 0, const RowStore& ts = RowStore{nullptr, 0, 0, false, 0}, bool store_global = true) {
     const int C_OUT = a.c_out;  // a workgroup may own only NT*32 of the layer's output channels, starting at co_base
     uint4 q[NT][2];
 #pragma unroll
@@ -244,7 +244,7 @@ __device__ __forceinline__ void store_pixel_tiles_rmw(const f32x16 (&acc)[NT], c
             for (int s = 0; s < 2; ++s) fin[nt][s] = q[nt][s];
     }
     if (ts.stage) ts_store<NT>(ts, a, co_base, fin);
-    else if (valid) {
+    else if (valid && store_global) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -1428,8 +1428,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
     constexpr bool CAN_STATS = G::ACC * NT <= 4 || FWD;  // register budget of the consumer waves
     const bool fuse_stats = !PS && !ACT && CAN_STATS && (a.stat_partials != nullptr || a.stat_acc != nullptr);   // forward: bn statistics of the output
     const bool fuse_bnred = !FWD && (PS || CAN_STATS) && (a.bnred_partials != nullptr || a.bnred_acc != nullptr);  // backward-data: dgamma / dbeta sums of the layer `out` belongs to
-    const int stat_mode = fuse_stats ? 1 : (fuse_bnred && PS != 1) ? 2 : 0;   // sums kept by the CONSUMER waves (PS = 2: of the groups g < PS_G0)
-    const bool ps = (PS == 1 || PS == 2) && fuse_bnred;                    // sums kept by the producer waves (PS = 2: of the groups g >= PS_G0)
+    // PS = 4 / 5 (round 4): the PRODUCER waves issue the tile's global stores.  The consumers leave the final values in the epilogue
+    // buffer only (as PS = 1 does for the sums) and go straight back to the hand-over barrier; two items later a producer thread reads its
+    // chunks back — consecutive lanes hold consecutive 16-byte chunks, whole lines — and stores them.  4: the consumers keep the sums
+    // (as PS = 0); 5: the producers form them as well (as PS = 1).  In the plain-copy forms the producers wait at the barrier for a third
+    // to half of the kernel, and the instrumented build shows the consumers' epilogue as mostly stores waiting to be issued.
+    constexpr bool PST = PS == 4 || PS == 5;
+    const int stat_mode = fuse_stats ? 1 : (fuse_bnred && PS != 1 && PS != 5) ? 2 : 0;   // sums kept by the CONSUMER waves (PS = 2: of the groups g < PS_G0)
+    const bool ps = (PS == 1 || PS == 2 || PS == 5) && fuse_bnred;         // sums kept by the producer waves (PS = 2: of the groups g >= PS_G0)
+    const bool pst = PST && fuse_bnred;                                    // global stores issued by the producer waves
     const bool pl = PS == 3 && fuse_bnred;                                 // y operands of the consumers' sums staged through LDS by the producer waves
     constexpr int PS_G0 = PS == 2 ? G::ACC / 2 : 0, PS_GROUPS = G::ACC - PS_G0;   // the accumulator groups whose stored values go through the epilogue buffer
     constexpr int E_BYTES = PS_GROUPS * 128 * 64 * NT;                     // epilogue buffer: PS_GROUPS x 128 pixel slots of NT x 64 bytes
@@ -1602,7 +1609,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
         float esc[8], esh[8];
         const int ek = tid & (EK - 1), eq0 = tid / EK;   // this thread's chunk (channels 8 ek .. 8 ek + 7 of the workgroup's) and first pixel slot
         int hist1 = -1, hist2 = -1, hist1_it = 0, hist2_it = 0;   // tile (or -1) and item index of the last two items whose epilogue leaves a buffer
-        if (PS == 1 || PS == 2) {
+        if (PS == 1 || PS == 2 || PS == 5) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 esc[j] = bnc[ek * 8 + j]; esh[j] = bnc[C_OUT + ek * 8 + j];
@@ -1610,6 +1617,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
             }
         }
         const bf16* ylayer = reinterpret_cast<const bf16*>(a.bnred_y);
+        unsigned epix[PST ? ECH : 1];
         auto estat_begin = [&](int et, u32x4 (&yv)[ECH], unsigned& evalid) __attribute__((always_inline)) {   // the y operands are requested ...
             const int tx = et % tiles_x, ty = (et / tiles_x) % tiles_y, n = et / per_img;
             evalid = 0;
@@ -1618,7 +1626,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
                 const int q = eq0 + EQ_STEP * j;
                 size_t pix; bool valid;
                 G::out_pixel((q >> 7) + PS_G0, a, n, ty, tx, (q >> 5) & 3, q & 31, pix, valid);
-                yv[j] = *reinterpret_cast<const u32x4*>(ylayer + pix * a.c_out + co_base + ek * 8);
+                if (PS != 4) yv[j] = *reinterpret_cast<const u32x4*>(ylayer + pix * a.c_out + co_base + ek * 8);
+                if constexpr (PST) epix[j] = (unsigned)pix;   // (< 2^31 elements per tensor: host check) where this chunk's pixel is stored
                 evalid |= (valid ? 1u : 0u) << j;
             }
         };
@@ -1628,7 +1637,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
             for (int j = 0; j < ECH; ++j) {
                 const int q = eq0 + EQ_STEP * j;
                 const u32x4 dv = *reinterpret_cast<const u32x4*>(eb + q * (64 * NT) + ((ek ^ ebuf_swizzle<NT>(q)) << 4));
-                if ((evalid >> j) & 1u) {
+                if constexpr (PST) {   // the tile's global store, issued here
+                    if ((evalid >> j) & 1u) store16(reinterpret_cast<bf16*>(a.out) + (size_t)epix[j] * a.c_out + co_base + ek * 8, make_uint4(dv[0], dv[1], dv[2], dv[3]));
+                }
+                if (PS != 4 && ((evalid >> j) & 1u)) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -1654,7 +1666,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
             u32x4 eyv[PS ? ECH : 1];
             unsigned evalid = 0;
             const int et = hist2, eit = hist2_it;
-            if constexpr (PS == 1 || PS == 2) { if (ps && et >= 0) estat_begin(et, eyv, evalid); }
+            if constexpr (PS == 1 || PS == 2 || PST) { if ((ps || pst) && et >= 0) estat_begin(et, eyv, evalid); }
             const bool ynow = PS == 3 && pl && slab == n_slabs - 1;   // the item the consumers' epilogue of `tile` follows
             if constexpr (PS == 3) { if (ynow) estat_begin(tile, eyv, evalid); }
             TICK();
@@ -1666,7 +1678,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
             TICK();
             if (ftile < n_tiles) fetch(R);
             if (!wres && n_slabs > 1 && (slab + 1 < n_slabs || tile + gstep < n_tiles)) fetch_w(slab + 1 < n_slabs ? slab + 1 : 0);
-            if constexpr (PS == 1 || PS == 2) { if (ps && et >= 0) estat_end(eit, eyv, evalid); }
+            if constexpr (PS == 1 || PS == 2 || PST) { if ((ps || pst) && et >= 0) estat_end(eit, eyv, evalid); }
             if constexpr (PS == 3) { if (ynow) ystage(it, eyv); }
             TOCK(t_b);
             TICK();
@@ -1692,8 +1704,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
         t_loop_end = wall_clock64();
         c_loop = clock64() - c_loop;
 #endif
-        if constexpr (PS == 1 || PS == 2) {
-            if (ps) {   // the last two items: the one before the last is ready, the last one after the consumers' closing barrier
+        if constexpr (PS == 1 || PS == 2 || PST) {
+            if (ps || pst) {   // the last two items: the one before the last is ready, the last one after the consumers' closing barrier
                 u32x4 eyv[ECH];
                 unsigned evalid = 0;
                 if (hist2 >= 0) { estat_begin(hist2, eyv, evalid); estat_end(hist2_it, eyv, evalid); }
@@ -1729,7 +1741,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
         constexpr bool DEEP = !FWD && NT == 1 && G::RMW_PREFETCH, DEEP_Y = false;
         u32x4 old_n[DEEP ? G::ACC : 1][NT][2], yraw_n[DEEP_Y ? G::ACC : 1][NT][2];
         const bool rmw_any = !FWD && G::RMW_PREFETCH && a.out_accumulate;
-        const bool cons_bnred = fuse_bnred && PS != 1;   // the consumers keep (some of) the bn backward sums (and fetch y for them, unless PS = 3)
+        const bool cons_bnred = fuse_bnred && PS != 1 && PS != 5;   // the consumers keep (some of) the bn backward sums (and fetch y for them, unless PS = 3)
         const bool pre_any = rmw_any || cons_bnred;
         auto prefetch_epilogue = [&](int t, auto& o, auto& y, bool want_old, bool want_y) __attribute__((always_inline)) {
             const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, n = t / (tiles_x * tiles_y);
@@ -1854,10 +1866,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
                                         yraw[g][nt][s2] = *reinterpret_cast<const u32x4*>(eb + q * (64 * NT) + (((nt * 4 + 2 * s2 + half) ^ ebuf_swizzle<NT>(q)) << 4));
                             }
                         }
-                        const bool to_ebuf = ps && g >= PS_G0;   // (compile-time per unrolled g) this group's sums are the producers'
+                        const bool to_ebuf = (ps && g >= PS_G0) || pst;   // (compile-time per unrolled g) this group's sums are the producers' / its stores are
                         store_pixel_tiles_rmw<NT>(acc[g], a, pix, valid, half, co_base, old[FWD ? 0 : g], rmw, stat, (PS == 2 && g >= PS_G0) ? 0 : stat_mode, yraw[FWD ? 0 : g], bnc,
                                                   to_ebuf ? smem + e_off + (n_slabs == 1 ? (it & 1) * E_BYTES : 0) : nullptr, ((g - PS_G0) * 4 + wave) * 32 + col,
-                                                  ts);
+                                                  ts, !pst);
                     }
                 }
                 if constexpr (DEEP) {
@@ -1877,7 +1889,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
             tile = ntile; slab = nslab; ++it;
         }
         if constexpr (CAN_DEFER) { if (dpending) flush_deferred<DS>(dst, out_rsrc); }
-        if constexpr (PS == 1 || PS == 2) { if (ps) __syncthreads(); }   // the consumers' closing barrier: the last tile's epilogue buffer is complete
+        if constexpr (PS == 1 || PS == 2 || PST) { if (ps || pst) __syncthreads(); }   // the consumers' closing barrier: the last tile's epilogue buffer is complete
         if (stat_mode) {
             __syncthreads();  // (matched by the producers) every wave is done with the staging buffers
             float* red = reinterpret_cast<float*>(smem) + (size_t)(wave * 64 + lane) * (32 * NT);
@@ -1920,7 +1932,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
             }
         }
     }
-    if constexpr (PS == 1 || PS == 2) {
+    if constexpr (PS == 1 || PS == 2 || PS == 5) {
         if (ps) {   // the producers' 16 sums per thread -> (channel, which) = 64 NT sums, each over the 256 / EK threads that own the chunk, fixed order, in double
             __syncthreads();   // every wave is done with the staging buffers (and with the consumers' reduction above, PS = 2)
             if (producer) {
@@ -1986,7 +1998,10 @@ WsLayout ws_layout(const ConvArgs& a, int recs, int acc, int nt, bool with_bnred
     // four-group geometry only, 2 every form that fits.
     // Round 4: ANH_WS_PSTAT 3 / 4 = the SPLIT form (PS = 2 in the kernel: consumers keep the sums of half the accumulator groups, producers
     // of the other half) for the stride-1 geometry (3), and for the four-group geometry at 32 channels as well (4); everything else as 1.
-    static const int ps_env = getenv("ANH_WS_PSTAT") ? atoi(getenv("ANH_WS_PSTAT")) : 1;
+    // Default 7 (round 4): the plain-copy forms' global stores are issued by the producer waves (PS = 4 / 5) — bit-identical to 1 (the same
+    // values, the same sums by the same waves), five same-box rounds 1.7356 / 1.7400 / 1.7374 / 1.7360 / 1.7383 -> 1.7264 / 1.7179 / 1.7178 /
+    // 1.7224 / 1.7187 ms per step (-1.0 %; the 64->32 stride-2 backward-data conv 66 -> 58 us, the 32->64 one 109 -> 105).
+    static const int ps_env = getenv("ANH_WS_PSTAT") ? atoi(getenv("ANH_WS_PSTAT")) : 7;
     const bool can_split = acc >= 2 && acc * nt <= 4;   // the consumers must be able to hold per-lane sums (CAN_STATS in the kernel)
     int mode = 0;
     if (ps_env == 2) mode = 1;
@@ -1995,6 +2010,8 @@ WsLayout ws_layout(const ConvArgs& a, int recs, int acc, int nt, bool with_bnred
     else if (ps_env == 4) mode = can_split ? 2 : (acc == 4 ? 1 : 0);
     else if (ps_env == 5) mode = acc == 4 ? 1 : (acc * nt <= 4 ? 3 : 0);   // y through LDS (PS = 3) for the stride-1 and down geometries, the four-group geometry as 1
     else if (ps_env == 6) mode = acc * nt <= 4 ? 3 : (acc == 4 ? 1 : 0);    // ... and for the four-group geometry at 32 channels
+    else if (ps_env == 7) mode = acc == 4 ? (nt == 1 ? 5 : 1) : (acc * nt <= 4 ? 4 : 0);   // producer-issued stores: consumer sums (4) for stride-1 / down, producer sums + stores (5) for the four-group geometry at 32 channels (at 64 it spills 18 VGPRs: stays 1)
+    else if (ps_env == 8) mode = acc == 4 ? 1 : (acc * nt <= 4 ? 4 : 0);    // ... the four-group geometry left as 1
     const int e_groups = mode == 2 ? acc - acc / 2 : acc;
     const size_t e_total = (size_t)e_groups * 128 * 64 * nt * (n_slabs == 1 ? 2 : 1);
     if (mode && with_bnred && a.src.kind == SRC_RAW && !a.out_scale && !a.stat_partials && !a.stat_acc) {
@@ -2125,7 +2142,10 @@ void launch_ws(const ConvArgs& a, int tiles_x, int tiles_y, int flip, hipStream_
     }
     if constexpr (G::ACC * NT <= 4) {
         if (ps == 3) { launch(conv3x3_ws_kernel<G, NT, SRC_RAW, false, false, 3>); HIP_CHECK(hipGetLastError()); return; }
+        if (ps == 4 && !a.out2) { launch(conv3x3_ws_kernel<G, NT, SRC_RAW, false, false, 4>); HIP_CHECK(hipGetLastError()); return; }
     }
+    if (ps == 5 && !a.out2) { launch(conv3x3_ws_kernel<G, NT, SRC_RAW, false, false, 5>); HIP_CHECK(hipGetLastError()); return; }
+    if (ps == 5) { launch(conv3x3_ws_kernel<G, NT, SRC_RAW, false, false, 1>); HIP_CHECK(hipGetLastError()); return; }
     switch (a.src.kind) {
         case SRC_RAW: launch(conv3x3_ws_kernel<G, NT, SRC_RAW>); break;
         case SRC_ACT: launch(conv3x3_ws_kernel<G, NT, SRC_ACT>); break;

@@ -44,6 +44,8 @@ def default_run(tmp_path_factory):
     ("stem_filter_gradient_on_second_stream", {"ANH_STEM_WGRAD_MAIN": "0"}),
     ("conv_filters_streamed_with_every_patch", {"ANH_WS_WEIGHT_RESIDENT": "0"}),
     ("skip_gradient_written_to_both_sources", {"ANH_SKIP_GRAD_ONCE": "0"}),
+    ("backward_data_stores_issued_by_the_consumer_waves", {"ANH_WS_PSTAT": "1"}),     # round 3's form; the default (7) lets the producer waves issue them
+    ("backward_data_stores_by_the_producers_for_stride_1_and_down_only", {"ANH_WS_PSTAT": "8"}),
 ])
 def test_schedule_is_bit_identical(tmp_path, default_run, name, env):
     got = run_variant(tmp_path, name, env)
