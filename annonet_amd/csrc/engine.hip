@@ -95,8 +95,8 @@ Engine::Engine(const anh_net_config& cfg, bool training_) : spec(Spec::build(cfg
         HIP_CHECK(hipMemsetAsync(momentum.p, 0, np * 4, stream));
         HIP_CHECK(hipMemsetAsync(grad.p, 0, (np + 1) * 4, stream));
     }
-    scalars.reserve(64);
-    HIP_CHECK(hipMemsetAsync(scalars.p, 0, 64, stream));
+    scalars.reserve(256);   // [loss | error flag | ...] in the first 64 bytes; bytes 64..255 stay zero for ever (ConvArgs::zeros)
+    HIP_CHECK(hipMemsetAsync(scalars.p, 0, 256, stream));
     loss_dev = scalars.as<double>();
     error_flag = reinterpret_cast<int*>(scalars.as<char>() + 16);
 
@@ -436,7 +436,9 @@ void Engine::build_fold_jobs() {
     }
 }
 
-void Engine::conv_dispatch(const ConvArgs& a, const char* tag, double flops, double bytes) {
+void Engine::conv_dispatch(const ConvArgs& a_in, const char* tag, double flops, double bytes) {
+    ConvArgs a = a_in;
+    a.zeros = scalars.p ? static_cast<const char*>(scalars.p) + 64 : nullptr;   // zeros for ever (Engine::scalars, bytes 64..255): what padding pixels read in the LDS-DMA staging form
     const bool fast = conv_takes_mfma(a, dtype);
     // the entry names the kernel family that runs: bf16 MFMA, fp32 MFMA (the parity mode on v_mfma_f32_32x32x2_f32), or the VALU kernels
     std::string name = std::string(fast ? "conv_mfma_bf16:" : conv_f32_mfma_ok(a) ? "conv_mfma_f32:" : (dtype == DT_BF16 ? "conv_generic_bf16:" : "conv_generic_f32:")) + tag;

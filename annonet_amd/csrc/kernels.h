@@ -65,6 +65,7 @@ struct ConvArgs {
     const void* w_bf16 = nullptr;     // [tap][c_out][c_red] bf16 (MFMA B operand, k contiguous)
     const float* bias = nullptr;
     void* out = nullptr; int out_dtype = DT_F32; int out_accumulate = 0;
+    const void* zeros = nullptr;   // >= 64 bytes of zeros in device memory: what padding pixels read in the LDS-DMA staging form (conv3x3_ws, DMA)
     unsigned out_bytes = 0;   // conv3x3_ws with deferred stores: size of `out` for the buffer descriptor (set by launch_ws)
     void* out2 = nullptr; int out2_accumulate = 0;  // optional second destination (skip-add gradient)
     int out_nchw = 0;                               // fp32 NCHW destination (boundary layout)

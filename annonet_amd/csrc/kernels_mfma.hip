@@ -323,7 +323,7 @@ __device__ __forceinline__ void store_pixel_tiles_rmw(const f32x16 (&acc)[NT], c
 // workgroup's channels (LDS table or global memory).
 template <int NT>
 __device__ __forceinline__ void store_pixel_tiles_act(const f32x16 (&acc)[NT], const ConvArgs& a, size_t pix, bool valid, int half, int co_base, const float* act, int cw,
-                                                      const RowStore& ts = RowStore{nullptr, 0, 0, false, 0}) {
+                                                      const RowStore& ts = RowStore{nullptr, 0, 0, false, 0}, char* ebuf = nullptr, int eq = 0) {
     bf16* out = reinterpret_cast<bf16*>(a.out);
     const size_t base = pix * a.c_out + co_base + 8 * half;
     uint4 fin[NT][2];
@@ -348,7 +348,12 @@ __device__ __forceinline__ void store_pixel_tiles_act(const f32x16 (&acc)[NT], c
             fin[nt][s] = make_uint4(r0[0], r1[0], r0[1], r1[1]);
         }
     }
-    if (ts.stage) ts_store<NT>(ts, a, co_base, fin);
+    if (ebuf) {   // producer-issued stores (PS = 4): the values go to the workgroup's epilogue buffer only
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) *reinterpret_cast<uint4*>(ebuf + eq * (64 * NT) + (((nt * 4 + 2 * s + half) ^ ebuf_swizzle<NT>(eq)) << 4)) = fin[nt][s];
+    } else if (ts.stage) ts_store<NT>(ts, a, co_base, fin);
     else if (valid) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
@@ -1182,6 +1187,24 @@ __device__ __forceinline__ const char* swz_addr(const char* base, int rec, int k
 }
 __device__ __forceinline__ bf16x8 lds_frag(const char* p) { return *reinterpret_cast<const bf16x8*>(p); }
 
+// -DANH_WS_PIN_NEST=1 (experiment, round 4): the stride-1 nest's instruction order pinned with sched_group_barrier — the LDS reads of
+// (kx, k-step) group i + 1 are issued BETWEEN the MFMAs of group i (one group = 6 NT MFMAs and 4 + 3 NT reads), instead of wherever the
+// list scheduler leaves them (hipcc: one to two MFMAs ahead, 22 lgkmcnt(1) waits per 72 MFMAs).  ISA checked: the waits become
+// lgkmcnt(5..8).  MEASURED: training 1.7586 / 1.7773 / 1.7682 -> 1.7708 / 1.7781 / 1.7712 ms, inference 4,189 / 4,159 / 4,227 -> 4,176 /
+// 4,122 / 4,157 Mpx/s: as round 3's hand-pinned nest, a shorter MFMA phase shortens nothing.  Compiled out.
+#ifndef ANH_WS_PIN_NEST
+#define ANH_WS_PIN_NEST 0
+#endif
+template <int M_, int R_, int m>
+struct PinGroup {
+    __device__ __forceinline__ static void go() {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                       // one MFMA
+        constexpr int r = ((m + 1) * R_) / M_ - (m * R_) / M_;
+        if constexpr (r > 0) __builtin_amdgcn_sched_group_barrier(0x100, r, 0);   // r LDS reads of the next group
+        if constexpr (m + 1 < M_) PinGroup<M_, R_, m + 1>::go();
+    }
+};
+
 struct GeoS1 {
     static constexpr int RECS = PATCH_PIX, ACC = 2;
     static constexpr bool RMW_PREFETCH = false;  // read-modify-write destinations prefetched before the MFMA phase (register cost)
@@ -1224,6 +1247,14 @@ struct GeoS1 {
                 }
             }
         }
+#if ANH_WS_PIN_NEST
+        {
+            constexpr int R = 4 + 3 * NT, M = 6 * NT;
+            __builtin_amdgcn_sched_group_barrier(0x100, R, 0);
+            PinGroup<M, R, 0>::go(); PinGroup<M, R, 0>::go(); PinGroup<M, R, 0>::go(); PinGroup<M, R, 0>::go(); PinGroup<M, R, 0>::go();
+            __builtin_amdgcn_sched_group_barrier(0x008, M, 0);
+        }
+#endif
     }
     static constexpr bool TS_OK = true;   // a wave's group is 32 consecutive pixels of one output row: transposed stores apply
     __device__ static void row_origin(int g, const ConvArgs& a, int n, int ty, int tx, int wave, size_t& row_pix0, bool& row_valid, int& cols_valid) {
@@ -1370,7 +1401,13 @@ struct GeoUp {
 // the epilogue buffer; the consumers read them there when the epilogue starts.  The consumers then carry no prefetched y registers
 // (ACC x NT x 8 VGPRs) through their MFMA phase — the register pressure that makes hipcc schedule the backward forms' MFMA nest with
 // three operand sets instead of seven (see HAS_FWD_FORM below) — and never wait on global memory in the epilogue.
-template <class G, int NT, int KIND, bool FWD = false, bool ACT = false, int PS = 0, bool HEAD = false>
+// DMA (round 4; plain-copy staging with every filter slab resident): the producer waves move the patches with LDS-DMA
+// (global_load_lds_dwordx4: the data goes from the memory pipeline straight into LDS — no staging registers, no commit phase, no VALU).
+// A lane's 16 bytes land at M0 + 16 x lane, so one wave instruction fills 16 consecutive 64-byte records; the column swizzle of the
+// record layout becomes a choice of WHICH chunk of its pixel a lane asks for (chunk (lane & 3) ^ key), padding pixels read a block of
+// zeros.  The patch buffers form a ring of `rd` (2 or 3, what LDS allows): item m's transfers are issued in the producers' iteration
+// m - (rd - 2) and must have landed (s_waitcnt vmcnt) before the barrier that hands item m over.
+template <class G, int NT, int KIND, bool FWD = false, bool ACT = false, int PS = 0, bool HEAD = false, bool DMA = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tiles_x, int tiles_y, int flip, long long* prof, int wres_, int e_off_) {
     // per-phase wall-clock accounting, compiled in with -DANH_WS_PROFILE (ANH_WS_PROF=1 then prints one line per launch)
 #ifdef ANH_WS_PROFILE
@@ -1401,8 +1438,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
     // Resident form (wres; the filter slabs of ALL reduction slabs fit beside two patches, i.e. 64 reduction channels):
     // [X] [X] [W slab 0] [W slab 1] ... tables — the producers stage the filter once and then move patches only.
     const int n_slabs_l = a.c_red >> 5;
-    const int x_stride = wres ? X_BYTES_ : BUF;                                   // between the two patch buffers
-    const int tab_off = wres ? 2 * X_BYTES_ + n_slabs_l * W_BYTES : 2 * BUF;
+    constexpr int X_PAD = NP * 4096;                                              // DMA: a patch buffer holds whole wave instructions (64 records per round of the four waves)
+    const int rd = DMA ? 2 + ((wres_ >> 16) & 1) : 2;                             // DMA: depth of the patch ring
+    const int x_stride = DMA ? X_PAD : wres ? X_BYTES_ : BUF;                     // between the patch buffers
+    const int w_base = DMA ? rd * X_PAD : 2 * X_BYTES_;                           // resident filter slabs
+    const int tab_off = DMA ? w_base + n_slabs_l * W_BYTES : wres ? 2 * X_BYTES_ + n_slabs_l * W_BYTES : 2 * BUF;
     float* tab = reinterpret_cast<float*>(smem + tab_off);  // [a_scale | a_shift | b_scale | b_shift][c_red]
 
     // wres_ bit 0: filter-resident form; bit 1: role map.  The hardware deals the eight waves of a workgroup round the four SIMDs
@@ -1436,7 +1476,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
     constexpr bool PST = PS == 4 || PS == 5;
     const int stat_mode = fuse_stats ? 1 : (fuse_bnred && PS != 1 && PS != 5) ? 2 : 0;   // sums kept by the CONSUMER waves (PS = 2: of the groups g < PS_G0)
     const bool ps = (PS == 1 || PS == 2 || PS == 5) && fuse_bnred;         // sums kept by the producer waves (PS = 2: of the groups g >= PS_G0)
-    const bool pst = PST && fuse_bnred;                                    // global stores issued by the producer waves
+    const bool pst = PST && (fuse_bnred || ACT);                           // global stores issued by the producer waves (also the plain-copy inference forms)
     const bool pl = PS == 3 && fuse_bnred;                                 // y operands of the consumers' sums staged through LDS by the producer waves
     constexpr int PS_G0 = PS == 2 ? G::ACC / 2 : 0, PS_GROUPS = G::ACC - PS_G0;   // the accumulator groups whose stored values go through the epilogue buffer
     constexpr int E_BYTES = PS_GROUPS * 128 * 64 * NT;                     // epilogue buffer: PS_GROUPS x 128 pixel slots of NT x 64 bytes
@@ -1486,7 +1526,90 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
     if (prio == 1 && !producer) __builtin_amdgcn_s_setprio(1);
     if (prio == 2 && producer) __builtin_amdgcn_s_setprio(1);
     if (prio == 3) { if (producer) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2); }
-    if (producer) {
+    if (producer && DMA) {
+      if constexpr (DMA) {
+        const bf16* wsrc = reinterpret_cast<const bf16*>(a.w_bf16);
+        const bf16* xa = reinterpret_cast<const bf16*>(a.src.a);
+        const bf16* zeros = reinterpret_cast<const bf16*>(a.zeros);
+        const size_t plane = (size_t)H * W * c_red;
+        // this lane's records: jj-th instruction of wave `wave` covers records (wave * 16 + 64 jj) .. + 15; the lane asks for chunk (lane & 3) ^ key
+        int pgeo[NP], pchunk[NP];
+#pragma unroll
+        for (int jj = 0; jj < NP; ++jj) {
+            const int rec = min((tid >> 2) + 64 * jj, G::RECS - 1);   // (records past the patch: any valid pixel, nobody reads them)
+            int py, px, key;
+            G::decode(rec, py, px, key);
+            pgeo[jj] = py | (px << 8);
+            pchunk[jj] = ((c16 ^ key) & 3) * 8;
+        }
+        const int per_img = tiles_x * tiles_y;
+        const int step_x = gstep % tiles_x, step_y = (gstep / tiles_x) % tiles_y, step_n = gstep / per_img;
+        int ftile = tile_first, fslab = 0;
+        int ftx = ftile % tiles_x, fty = (ftile / tiles_x) % tiles_y, fn = ftile / per_img;
+        int foff[NP];
+        unsigned fpok = 0;
+        auto enter_tile = [&]() __attribute__((always_inline)) {
+            const int x0 = G::in_x0(ftx), y0 = G::in_y0(fty);
+            fpok = 0;
+#pragma unroll
+            for (int jj = 0; jj < NP; ++jj) {
+                const int iy = y0 + (pgeo[jj] & 255), ix = x0 + (pgeo[jj] >> 8);
+                const int cy = min(max(iy, 0), H - 1), cx = min(max(ix, 0), W - 1);
+                foff[jj] = (cy * W + cx) * c_red + pchunk[jj];
+                fpok |= ((iy == cy && ix == cx) ? 1u : 0u) << jj;
+            }
+        };
+        int fit = 0;   // index of the item the cursor points at
+        auto issue = [&]() __attribute__((always_inline)) {   // the cursor's item -> ring slot fit % rd; advances the cursor
+            const bf16* pa = xa + (size_t)fn * plane + fslab * 32;
+            char* lbase = smem + (fit % rd) * X_PAD + wave * 1024;
+#pragma unroll
+            for (int jj = 0; jj < NP; ++jj) {
+                const bf16* g = ((fpok >> jj) & 1u) ? pa + foff[jj] : zeros + (lane & 3) * 8;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)(lbase + jj * 4096), 16, 0, 0);
+            }
+            ++fit;
+            if (++fslab == n_slabs) {
+                fslab = 0; ftile += gstep;
+                ftx += step_x; if (ftx >= tiles_x) { ftx -= tiles_x; ++fty; }
+                fty += step_y; if (fty >= tiles_y) { fty -= tiles_y; ++fn; }
+                fn += step_n;
+                if (ftile < n_tiles) enter_tile();
+            }
+        };
+        if (ftile < n_tiles) { enter_tile(); issue(); }                      // item 0
+        if (tile < n_tiles) {   // every filter slab to its own LDS block, once (through registers: a few KB from L2)
+            constexpr int NWd = (W_ITEMS + 255) / 256;
+            for (int sl = 0; sl < n_slabs; ++sl) {
+                u32x4 wr[NWd];
+#pragma unroll
+                for (int j = 0; j < NWd; ++j) {
+                    const int rec = min((tid >> 2) + 64 * j, 9 * C_OUT - 1);
+                    const int tl = rec / C_OUT, co = rec - tl * C_OUT;
+                    const int tap = flip ? 8 - tl : tl;
+                    wr[j] = *reinterpret_cast<const u32x4*>(wsrc + (tap * a.c_out + co_base + co) * c_red + c16 * 8 + sl * 32);
+                }
+#pragma unroll
+                for (int j = 0; j < NWd; ++j) {
+                    const int rec = (tid >> 2) + 64 * j;
+                    const int co = rec % C_OUT;
+                    if (rec < 9 * C_OUT) *reinterpret_cast<u32x4*>(smem + w_base + sl * W_BYTES + rec * 64 + ((c16 ^ ((co >> 2) & 3)) << 4)) = wr[j];
+                }
+            }
+        }
+        init_tables();
+        while (tile < n_tiles) {   // iteration `it`: hand item `it` over at its closing barrier
+            bool ahead = false;
+            if (rd == 3 && ftile < n_tiles) { issue(); ahead = true; }       // item it + 1 into the slot the consumers left at the last barrier
+            if (ahead) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");   // item it (issued one iteration ago) has landed; item it + 1 may still fly
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (rd == 2 && ftile < n_tiles) issue();                           // ring of two: item it + 1 goes into the slot item it - 1 just left
+            if (++slab == n_slabs) { slab = 0; tile += gstep; }
+            ++it;
+        }
+      }
+    } else if (producer) {
         // The producers request their FIRST patch and the filter blocks before the tables are loaded and the workgroup meets:
         // those round trips overlap instead of adding up.
         const bf16* wsrc = reinterpret_cast<const bf16*>(a.w_bf16);
@@ -1786,8 +1909,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
         while (tile < n_tiles) {
             int ntile = tile, nslab = slab + 1;
             if (nslab == n_slabs) { nslab = 0; ntile += gstep; }
-            const int boff = (it & 1) * x_stride;
-            const int woff = wres ? 2 * X_BYTES_ + slab * W_BYTES : boff + X_BYTES_;
+            const int boff = (DMA ? it % rd : (it & 1)) * x_stride;
+            const int woff = DMA ? w_base + slab * W_BYTES : wres ? 2 * X_BYTES_ + slab * W_BYTES : boff + X_BYTES_;
             typename G::Bases b;
 #pragma unroll
             for (int i = 0; i < G::NB; ++i)
@@ -1852,7 +1975,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
                     if constexpr (HEAD) store_pixel_tiles_head(acc[g][0], a, pix, n, valid, half, bnc, C_OUT, hw, hbias);
                     else if constexpr (ACT) {
                         if (defer) pack_pixel_tiles_act<NT, DS>(acc[g], a, pix, valid, half, co_base, bnc, C_OUT, dst, g * NT * 2);
-                        else store_pixel_tiles_act<NT>(acc[g], a, pix, valid, half, co_base, bnc, C_OUT, ts);
+                        else store_pixel_tiles_act<NT>(acc[g], a, pix, valid, half, co_base, bnc, C_OUT, ts,
+                                                       pst ? smem + e_off + (n_slabs == 1 ? (it & 1) * E_BYTES : 0) : nullptr, (g * 4 + wave) * 32 + col);
                     }
                     else {
                         if constexpr (PS == 3) {   // the y operands of this group's sums: left in the epilogue buffer by the producer waves
@@ -2014,6 +2138,17 @@ WsLayout ws_layout(const ConvArgs& a, int recs, int acc, int nt, bool with_bnred
     else if (ps_env == 8) mode = acc == 4 ? 1 : (acc * nt <= 4 ? 4 : 0);    // ... the four-group geometry left as 1
     const int e_groups = mode == 2 ? acc - acc / 2 : acc;
     const size_t e_total = (size_t)e_groups * 128 * 64 * nt * (n_slabs == 1 ? 2 : 1);
+    // inference (activation-storing, plain-copy forms without the head): producer-issued stores too, where the epilogue buffer fits
+    // (ANH_WS_INFER_PSTORE, default 1)
+    // MEASURED: for every such form 4,245 -> 4,097 Mpx/s (-3.5 %: in inference the producers are the busier role); 0 = off (default),
+    // 1 = every form, 2 = the four-group geometry at 32 channels only, 3 = the stride-1 form at 64 -> 64 only, 4 = both of those
+    static const int infer_pstore = getenv("ANH_WS_INFER_PSTORE") ? atoi(getenv("ANH_WS_INFER_PSTORE")) : 0;
+    const bool up32 = acc == 4 && nt == 1, s1_64 = acc == 2 && nt == 2 && n_slabs == 2;
+    const bool pstore_here = infer_pstore == 1 || (infer_pstore == 2 && up32) || (infer_pstore == 3 && s1_64) || (infer_pstore == 4 && (up32 || s1_64));
+    if (pstore_here && a.out_scale && !a.head_out && a.src.kind == SRC_RAW && !a.out2 && !a.out_accumulate) {
+        const size_t e_inf = (size_t)acc * 128 * 64 * nt * (n_slabs == 1 ? 2 : 1);
+        if (L.lds + e_inf <= 160 * 1024) { L.ps = 4; L.e_off = (int)((L.lds + 15) / 16 * 16); L.lds = (size_t)L.e_off + e_inf; return L; }
+    }
     if (mode && with_bnred && a.src.kind == SRC_RAW && !a.out_scale && !a.stat_partials && !a.stat_acc) {
         if (L.lds + e_total <= 160 * 1024) L.ps = mode;
         else if (n_slabs == 1 && resident_lds + e_total <= 160 * 1024 && resident_lds - tables >= 16 * 1024) { L.wres = 1; L.lds = resident_lds; L.ps = mode; }
@@ -2039,6 +2174,7 @@ void launch_ws(const ConvArgs& a, int tiles_x, int tiles_y, int flip, hipStream_
         if (at + strips <= 160 * 1024) { ts_off = (int)at; lds = at + strips; }
     }
     const int e_off = lay.e_off | ((ts_off >> 4) << 18);
+    int extra_bits = 0;   // (bit 16: the DMA form's patch ring has three slots)
     const int ps = lay.ps;
     // ANH_WS_ROLE_MAP: 0 = one producer + one consumer per SIMD, 1 = consumers on SIMDs 0-1 / producers on SIMDs 2-3, 2 = map 1 for the
     // 32-output-channel kernels only (their MFMA phase is short; the 64-channel kernels need all four matrix cores)
@@ -2059,13 +2195,13 @@ void launch_ws(const ConvArgs& a, int tiles_x, int tiles_y, int flip, hipStream_
     auto launch = [&](auto kernel) {
         ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), lds);
 #ifndef ANH_WS_PROFILE
-        hipLaunchKernelGGL(kernel, grid, block, lds, s, a2, tiles_x, tiles_y, flip, (long long*)nullptr, wres | (role_map << 1), e_off);
+        hipLaunchKernelGGL(kernel, grid, block, lds, s, a2, tiles_x, tiles_y, flip, (long long*)nullptr, wres | (role_map << 1) | extra_bits, e_off);
 #else
         static const int prof_on = getenv("ANH_WS_PROF") ? atoi(getenv("ANH_WS_PROF")) : 0;
         static long long* prof = nullptr;
         if (prof_on && !prof) HIP_CHECK(hipMalloc(&prof, 1024 * 8 * 8 * sizeof(long long)));
         static const int nostore = getenv("ANH_WS_PROF_NOSTORE") ? atoi(getenv("ANH_WS_PROF_NOSTORE")) : 0;
-        hipLaunchKernelGGL(kernel, grid, block, lds, s, a2, tiles_x, tiles_y, flip, prof_on ? prof : nullptr, wres | (role_map << 1) | (nostore << 6), e_off);
+        hipLaunchKernelGGL(kernel, grid, block, lds, s, a2, tiles_x, tiles_y, flip, prof_on ? prof : nullptr, wres | (role_map << 1) | (nostore << 6) | extra_bits, e_off);
         if (prof_on) {
             HIP_CHECK(hipStreamSynchronize(s));
             const int nwg = grid.x * grid.y;
@@ -2111,7 +2247,23 @@ void launch_ws(const ConvArgs& a, int tiles_x, int tiles_y, int flip, hipStream_
             return;
         }
         switch (a.src.kind) {
-            case SRC_RAW: launch(conv3x3_ws_kernel<G, NT, SRC_RAW, true, true>); break;
+            case SRC_RAW: {
+                // ANH_WS_DMA (0): patches by LDS-DMA where every filter slab fits beside a ring of 3 (else 2) padded patch buffers (2: rings of
+                // three only).  MEASURED, labels bit-identical: 4,379 / 4,363 / 4,347 -> 4,348 / 4,346 / 4,316 Mpx/s (1), 4,340 / 4,326 / 4,300 (2):
+                // with the producers' registers, commit phase and VALU work gone and two items in flight, nothing moves — in inference too
+                // the consumer waves are the long pole.  Off by default, kept as a tested form.
+                static const int dma_env = getenv("ANH_WS_DMA") ? atoi(getenv("ANH_WS_DMA")) : 0;
+                const size_t n_slabs = (size_t)(a.c_red >> 5), x_pad = (size_t)((G::RECS * 4 + 255) / 256) * 4096;
+                const size_t fixed = n_slabs * 9 * NT * 32 * 64 + (size_t)a.c_red * 16 + (size_t)NT * 32 * 16;
+                const int rd = 3 * x_pad + fixed <= 160 * 1024 ? 3 : 2 * x_pad + fixed <= 160 * 1024 ? 2 : 0;
+                if (dma_env && a.zeros && ps == 0 && rd && (dma_env < 2 || rd == 3)) {
+                    lds = (size_t)rd * x_pad + fixed;
+                    extra_bits = (rd == 3) << 16;
+                    launch(conv3x3_ws_kernel<G, NT, SRC_RAW, true, true, 0, false, true>);
+                } else if (ps == 4) launch(conv3x3_ws_kernel<G, NT, SRC_RAW, true, true, 4>);
+                else launch(conv3x3_ws_kernel<G, NT, SRC_RAW, true, true>);
+                break;
+            }
             case SRC_SUM2: launch(conv3x3_ws_kernel<G, NT, SRC_SUM2, true, true>); break;
             default: fail(ANH_ERR_INTERNAL, "conv_ws: the activation-storing form reads post-activation tensors");
         }
