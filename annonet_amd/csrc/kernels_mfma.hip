@@ -1441,8 +1441,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
     constexpr int X_PAD = NP * 4096;                                              // DMA: a patch buffer holds whole wave instructions (64 records per round of the four waves)
     const int rd = DMA ? 2 + ((wres_ >> 16) & 1) : 2;                             // DMA: depth of the patch ring
     const int x_stride = DMA ? X_PAD : wres ? X_BYTES_ : BUF;                     // between the patch buffers
-    const int w_base = DMA ? rd * X_PAD : 2 * X_BYTES_;                           // resident filter slabs
-    const int tab_off = DMA ? w_base + n_slabs_l * W_BYTES : wres ? 2 * X_BYTES_ + n_slabs_l * W_BYTES : 2 * BUF;
+    // Two items per barrier (round 4, `ipb` = wres_ bit 17; resident-filter forms whose LDS holds FOUR patch buffers): the roles meet
+    // after every second item; item `it` lives in patch buffer it & 3.  tools/micro/ws_interference.hip: the stride-1 nest alone, one
+    // workgroup barrier per 72 MFMAs, 1.65 us per item; one barrier per two items 1.43-1.55.
+    const int ipb = DMA ? 1 : 1 + ((wres_ >> 17) & 1);
+    const int nbuf_mask = wres && !DMA ? 2 * ipb - 1 : 1;                          // patch buffers - 1 (non-DMA forms)
+    const int w_base = DMA ? rd * X_PAD : (nbuf_mask + 1) * X_BYTES_;             // resident filter slabs
+    const int tab_off = DMA ? w_base + n_slabs_l * W_BYTES : wres ? w_base + n_slabs_l * W_BYTES : 2 * BUF;
     float* tab = reinterpret_cast<float*>(smem + tab_off);  // [a_scale | a_shift | b_scale | b_shift][c_red]
 
     // wres_ bit 0: filter-resident form; bit 1: role map.  The hardware deals the eight waves of a workgroup round the four SIMDs
@@ -1691,7 +1696,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
             for (int j = 0; j < NW; ++j) wraw[j] = *reinterpret_cast<const u32x4*>(wsrc + wsrc_off[j] + slab_ * 32);
         };
         auto commit = [&](Fetched& R) __attribute__((always_inline)) {
-            char* lbuf = smem + (it & 1) * x_stride;
+            char* lbuf = smem + (it & nbuf_mask) * x_stride;
             char* wbuf = lbuf + X_BYTES_;     // streaming form only
             // a single-slab layer's filter block goes into both buffers once (its registers are not refetched)
             const bool stage_w = !wres && (it < 2 || n_slabs > 1);
@@ -1723,7 +1728,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
                 fetch_w(sl);
 #pragma unroll
                 for (int j = 0; j < NW; ++j)
-                    if ((tid >> 2) + 64 * j < 9 * C_OUT) *reinterpret_cast<u32x4*>(smem + 2 * X_BYTES_ + sl * W_BYTES + wdst[j]) = wraw[j];
+                    if ((tid >> 2) + 64 * j < 9 * C_OUT) *reinterpret_cast<u32x4*>(smem + w_base + sl * W_BYTES + wdst[j]) = wraw[j];
             }
         }
         init_tables();
@@ -1805,7 +1810,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
             if constexpr (PS == 3) { if (ynow) ystage(it, eyv); }
             TOCK(t_b);
             TICK();
-            __syncthreads();  // buffer it & 1 is full; the consumers are done with buffer (it + 1) & 1
+            // buffer `it` is full; the consumers are done with the buffer(s) the next item(s) go to.  ipb = 2: only behind odd items and the last one
+            if (ipb == 1 || (it & 1) || (slab == n_slabs - 1 && tile + gstep >= n_tiles)) __syncthreads();
             TOCK(t_c);
             hist2 = hist1; hist2_it = hist1_it;
             hist1 = slab == n_slabs - 1 ? tile : -1; hist1_it = it;
@@ -1909,8 +1915,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
         while (tile < n_tiles) {
             int ntile = tile, nslab = slab + 1;
             if (nslab == n_slabs) { nslab = 0; ntile += gstep; }
-            const int boff = (DMA ? it % rd : (it & 1)) * x_stride;
-            const int woff = DMA ? w_base + slab * W_BYTES : wres ? 2 * X_BYTES_ + slab * W_BYTES : boff + X_BYTES_;
+            const int boff = (DMA ? it % rd : (it & nbuf_mask)) * x_stride;
+            const int woff = (DMA || wres) ? w_base + slab * W_BYTES : boff + X_BYTES_;
             typename G::Bases b;
 #pragma unroll
             for (int i = 0; i < G::NB; ++i)
@@ -1926,7 +1932,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
                         for (int r = 0; r < 16; ++r) acc[g][nt][r] = 0.f;
             }
             TICK();
-            __syncthreads();  // buffer it & 1 is full
+            if (ipb == 1 || !(it & 1)) __syncthreads();  // buffer `it` (ipb = 2: and it + 1) is full
             TOCK(t_c);
             TICK();
             const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
@@ -2100,7 +2106,7 @@ int ws_target_wgs();
 
 // LDS layout of a persistent conv launch and whether it takes the producer-side form of the fused bn backward sums (PS).
 // with_bnred: the sums are wanted (conv_fused_bnred_blocks asks before ConvArgs::bnred_* are set).
-struct WsLayout { int wres; size_t lds; int ps /* 0 consumer-side sums, 1 producer-side, 2 split by accumulator group */; int e_off; };
+struct WsLayout { int wres; size_t lds; int ps /* 0 consumer-side sums, 1 producer-side, 2 split by accumulator group, ... */; int e_off; int ipb = 1; };
 WsLayout ws_layout(const ConvArgs& a, int recs, int acc, int nt, bool with_bnred) {
     const size_t tables = (size_t)a.c_red * 16 + (size_t)nt * 32 * 16;
     const size_t x_bytes = (size_t)recs * 64, w_bytes = (size_t)9 * nt * 32 * 64;
@@ -2155,6 +2161,13 @@ WsLayout ws_layout(const ConvArgs& a, int recs, int acc, int nt, bool with_bnred
     }
     L.e_off = L.ps ? (int)((L.lds + 15) / 16 * 16) : 0;
     if (L.ps) L.lds = (size_t)L.e_off + e_total;
+    // two items per barrier (ANH_WS_IPB=2; default 1): every filter slab resident beside FOUR patch buffers, no epilogue buffer in use.
+    // MEASURED (four rounds): training 1.7241 -> 1.7311 ms, inference 4,293 -> 4,164 Mpx/s (-3 %) — although the nest alone gains 5-13 % from
+    // it in tools/micro/ws_interference.hip: with real producers a hand-over every second item lets the roles drift two items apart and the
+    // consumers wait longer at each meeting than they save.  Off; kept as a tested form.
+    static const int ipb_env = getenv("ANH_WS_IPB") ? atoi(getenv("ANH_WS_IPB")) : 1;
+    const size_t four = 4 * x_bytes + (size_t)n_slabs * w_bytes + tables;
+    if (ipb_env == 2 && !L.ps && resident_on && four <= 160 * 1024) { L.wres = 1; L.ipb = 2; L.lds = four; }
     return L;
 }
 
@@ -2174,7 +2187,7 @@ void launch_ws(const ConvArgs& a, int tiles_x, int tiles_y, int flip, hipStream_
         if (at + strips <= 160 * 1024) { ts_off = (int)at; lds = at + strips; }
     }
     const int e_off = lay.e_off | ((ts_off >> 4) << 18);
-    int extra_bits = 0;   // (bit 16: the DMA form's patch ring has three slots)
+    int extra_bits = (lay.ipb == 2) << 17;   // (bit 16: the DMA form's patch ring has three slots; bit 17: two items per barrier)
     const int ps = lay.ps;
     // ANH_WS_ROLE_MAP: 0 = one producer + one consumer per SIMD, 1 = consumers on SIMDs 0-1 / producers on SIMDs 2-3, 2 = map 1 for the
     // 32-output-channel kernels only (their MFMA phase is short; the 64-channel kernels need all four matrix cores)
@@ -2258,7 +2271,7 @@ void launch_ws(const ConvArgs& a, int tiles_x, int tiles_y, int flip, hipStream_
                 const int rd = 3 * x_pad + fixed <= 160 * 1024 ? 3 : 2 * x_pad + fixed <= 160 * 1024 ? 2 : 0;
                 if (dma_env && a.zeros && ps == 0 && rd && (dma_env < 2 || rd == 3)) {
                     lds = (size_t)rd * x_pad + fixed;
-                    extra_bits = (rd == 3) << 16;
+                    extra_bits = (rd == 3) << 16;   // (the DMA form meets after every item)
                     launch(conv3x3_ws_kernel<G, NT, SRC_RAW, true, true, 0, false, true>);
                 } else if (ps == 4) launch(conv3x3_ws_kernel<G, NT, SRC_RAW, true, true, 4>);
                 else launch(conv3x3_ws_kernel<G, NT, SRC_RAW, true, true>);

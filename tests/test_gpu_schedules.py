@@ -61,6 +61,7 @@ def test_schedule_is_bit_identical(tmp_path, default_run, name, env):
     ("bn_backward_sums_split_between_the_roles_stride_1", {"ANH_WS_PSTAT": "3"}),
     ("bn_backward_sums_split_between_the_roles_every_geometry_that_can", {"ANH_WS_PSTAT": "4"}),
     ("conv_tiles_walked_with_the_grid_stride", {"ANH_WS_XCD_BANDS": "0"}),
+    ("conv_roles_meet_after_every_second_item", {"ANH_WS_IPB": "2"}),
     ("bn_backward_y_operands_staged_through_lds_by_the_producer_waves", {"ANH_WS_PSTAT": "5"}),
     ("bn_backward_y_operands_staged_through_lds_every_geometry_that_can", {"ANH_WS_PSTAT": "6"}),
     ("separate_reduce_pass_for_the_layer_behind_the_64_channel_up_conv", {"ANH_WS_WIDE_PS": "0"}),

@@ -1,0 +1,5 @@
+set -e
+cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out
+timeout -k 10 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_parity.py tests/test_golden.py tests/test_gpu_sharded_infer.py tests/test_gpu_schedules.py tests/test_gpu_first_step_dirty_memory.py -x -q > gpurun_out/call21_tests.txt 2>&1 || true
+tail -6 gpurun_out/call21_tests.txt
+bash tools/ab_env.sh 4 "ANH_WS_IPB=1" "ANH_WS_IPB=2" 2>&1 | tee gpurun_out/call21_ab.txt
