@@ -1407,8 +1407,16 @@ struct GeoUp {
 // record layout becomes a choice of WHICH chunk of its pixel a lane asks for (chunk (lane & 3) ^ key), padding pixels read a block of
 // zeros.  The patch buffers form a ring of `rd` (2 or 3, what LDS allows): item m's transfers are issued in the producers' iteration
 // m - (rd - 2) and must have landed (s_waitcnt vmcnt) before the barrier that hands item m over.
-template <class G, int NT, int KIND, bool FWD = false, bool ACT = false, int PS = 0, bool HEAD = false, bool DMA = false>
-__global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tiles_x, int tiles_y, int flip, long long* prof, int wres_, int e_off_) {
+// TEAMS = 2 (round 4, "ping-pong"): TWO consumer teams of four waves (768 threads: waves 0-3 team 0, 4-7 team 1, 8-11 the producers; three
+// waves per SIMD, <= 168 VGPRs).  A consumer wave's item is an MFMA phase followed by an epilogue that is mostly stores waiting to be
+// issued, during which its SIMD's matrix core idles — the producer wave beside it runs no MFMA.  With two teams the tiles
+// alternate between them: in the interval in which one team runs the MFMA phase of tile k, the other runs the epilogue of tile k - 1 on
+// the same four SIMDs.  Still ONE workgroup barrier per item and two patch buffers: the epilogue needs only the team's registers.
+// (tools/micro/conv_bytes.hip: a copy kernel with this kernel's addresses and roles and a 1.5 us sleep before every tile's stores takes
+// 55 us per launch with one workgroup per CU and 34 with two.)  Forms: PS = 0, no DMA staging; statistics / bn backward sums as TEAMS = 1
+// (per-lane running sums in each team's waves; the closing reduction takes eight waves' partials in a fixed order).
+template <class G, int NT, int KIND, bool FWD = false, bool ACT = false, int PS = 0, bool HEAD = false, bool DMA = false, int TEAMS = 1>
+__global__ __launch_bounds__(256 * (TEAMS + 1), (TEAMS == 2 ? 3 : 2)) void conv3x3_ws_kernel(ConvArgs a, int tiles_x, int tiles_y, int flip, long long* prof, int wres_, int e_off_) {
     // per-phase wall-clock accounting, compiled in with -DANH_WS_PROFILE (ANH_WS_PROF=1 then prints one line per launch)
 #ifdef ANH_WS_PROFILE
     long long t_a = 0, t_b = 0, t_c = 0, t_d = 0, t0_;
@@ -1422,6 +1430,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
 #define TICK()
 #define TOCK(acc_)
 #endif
+    static_assert(TEAMS == 1 || (TEAMS == 2 && PS == 0 && !DMA), "conv3x3_ws: two consumer teams exist for the PS = 0, register-staged forms");
+    constexpr int NTHR = 256 * (TEAMS + 1);
     constexpr int C_OUT = NT * 32, NP = (G::RECS * 4 + 255) / 256, W_ITEMS = 9 * C_OUT * 4, NW = (W_ITEMS + 255) / 256;
     constexpr int X_BYTES_ = G::RECS * 64, W_BYTES = 9 * C_OUT * 64, BUF = X_BYTES_ + W_BYTES;
     const int wres = wres_ & 1, role_map = (wres_ >> 1) & 1, prio = (wres_ >> 2) & 3, bands = (wres_ >> 4) & 1;
@@ -1454,8 +1464,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
     // (wave w -> SIMD w & 3).  Map 0 puts one producer and one consumer on every SIMD (all four matrix cores in use); map 1 puts
     // the consumers on SIMDs 0-1 and the producers on SIMDs 2-3, so the staging VALU work never queues behind an MFMA.
     const int hw_wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    const bool producer = role_map ? ((hw_wave >> 1) & 1) != 0 : hw_wave >= 4;
-    const int wave = role_map ? ((hw_wave & 1) | ((hw_wave >> 2) << 1)) : (hw_wave & 3);   // index within the role (0..3)
+    const bool producer = TEAMS == 2 ? hw_wave >= 8 : role_map ? ((hw_wave >> 1) & 1) != 0 : hw_wave >= 4;
+    const int wave = TEAMS == 2 ? (hw_wave & 3) : role_map ? ((hw_wave & 1) | ((hw_wave >> 2) << 1)) : (hw_wave & 3);   // index within the role / team (0..3)
+    const int team = TEAMS == 2 && !producer ? hw_wave >> 2 : 0;
     const int lane = threadIdx.x & 63, tid = wave * 64 + lane, c16 = tid & 3;
     const int half = lane >> 5, col = lane & 31;
     const int co_base = blockIdx.y * C_OUT;
@@ -1494,16 +1505,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
         if (KIND == SRC_ACT || KIND == SRC_ACT2) {
             if (a.src.a_tab.acc) {   // table mode: the producers' (scale, shift) are folded here from their accumulator tables (bnacc.h)
                 const int sides = KIND == SRC_ACT2 ? 2 : 1;
-                for (int i = threadIdx.x; i < sides * c_red; i += 512) {
+                for (int i = threadIdx.x; i < sides * c_red; i += NTHR) {
                     const int side = i >= c_red, ch = i - side * c_red;
                     const BnTable& t = side ? a.src.b_tab : a.src.a_tab;
                     const BnFolded f = bnacc_fold_forward(t.acc, t.c, ch, t.pixels, t.gamma[ch], t.beta[ch], t.eps);
                     tab[2 * side * c_red + ch] = f.scale;
                     tab[(2 * side + 1) * c_red + ch] = f.shift;
                 }
-                if (KIND != SRC_ACT2) for (int i = threadIdx.x; i < c_red; i += 512) { tab[2 * c_red + i] = 0.f; tab[3 * c_red + i] = 0.f; }
+                if (KIND != SRC_ACT2) for (int i = threadIdx.x; i < c_red; i += NTHR) { tab[2 * c_red + i] = 0.f; tab[3 * c_red + i] = 0.f; }
             } else {
-                for (int i = threadIdx.x; i < c_red; i += 512) {
+                for (int i = threadIdx.x; i < c_red; i += NTHR) {
                     tab[i] = a.src.a_scale[i];
                     tab[c_red + i] = a.src.a_shift[i];
                     tab[2 * c_red + i] = KIND == SRC_ACT2 ? a.src.b_scale[i] : 0.f;
@@ -1512,13 +1523,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
             }
         }
         if (ACT) {
-            for (int i = threadIdx.x; i < C_OUT; i += 512) {
+            for (int i = threadIdx.x; i < C_OUT; i += NTHR) {
                 bnc[i] = a.out_scale[co_base + i];
                 bnc[C_OUT + i] = a.out_shift[co_base + i];
             }
         }
         if (fuse_bnred) {
-            for (int i = threadIdx.x; i < C_OUT; i += 512) {
+            for (int i = threadIdx.x; i < C_OUT; i += NTHR) {
                 bnc[i] = a.bnred_scale[co_base + i];
                 bnc[C_OUT + i] = a.bnred_shift[co_base + i];
                 bnc[2 * C_OUT + i] = a.bnred_mean[co_base + i];
@@ -1663,7 +1674,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
         const int step_x = gstep % tiles_x, step_y = (gstep / tiles_x) % tiles_y, step_n = gstep / per_img;
         int ftile = tile_first, fslab = 0;
         int ftx = ftile % tiles_x, fty = (ftile / tiles_x) % tiles_y, fn = ftile / per_img;
-        int foff[NP];
+        // Round 4, "VALU diet" (tools/micro/simd_sharing.hip: on a SIMD, MFMAs and the VALU instructions of EVERY wave share one issue port —
+        // a conv item's time is the sum of its MFMA cycles and 4 x the VALU instructions of both roles): the patch and filter fetches are
+        // BUFFER loads — address = per-image descriptor (SGPRs) + a 32-bit byte offset computed once per tile (VGPR) + the slab's offset
+        // (SGPR): no sign extension, no 64-bit add per load (3 VALU each before); a padding pixel's offset lies outside the descriptor, so
+        // the load returns zeros by itself and the plain-copy kinds need neither clamped addresses nor a mask (5 VALU per chunk before).
+    #ifndef ANH_WS_BUFFER_LOADS
+    #define ANH_WS_BUFFER_LOADS 1
+    #endif
+        constexpr bool BUFL = ANH_WS_BUFFER_LOADS != 0;
+        constexpr bool NEED_MASK = !BUFL || KIND == SRC_ACT || KIND == SRC_ACT2;   // relu(0 * scale + shift) is not zero: the bn kinds zero their padding after the prologue
+        const int plane_bytes = (int)(unsigned)(plane * 2);   // (< 0xFFFFF000: host check, conv_plan)
+        int foff[NP];   // BUFL: byte offset within the image (0xFFFFF000 = padding); else element offset of the clamped pixel
         unsigned fpok = 0;
         auto enter_tile = [&]() __attribute__((always_inline)) {
             const int x0 = G::in_x0(ftx), y0 = G::in_y0(fty);
@@ -1671,9 +1693,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
     #pragma unroll
             for (int jj = 0; jj < NP; ++jj) {
                 const int iy = y0 + (pgeo[jj] & 255), ix = x0 + (pgeo[jj] >> 8);
-                const int cy = min(max(iy, 0), H - 1), cx = min(max(ix, 0), W - 1);
-                foff[jj] = (cy * W + cx) * c_red + c16 * 8;
-                fpok |= ((iy == cy && ix == cx) ? 1u : 0u) << jj;
+                if constexpr (BUFL) {
+                    const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                    foff[jj] = ok ? ((iy * W + ix) * c_red + c16 * 8) * 2 : (int)0xFFFFF000u;   // (+ the slab's offset: still outside the image)
+                    if constexpr (NEED_MASK) fpok |= (ok ? 1u : 0u) << jj;
+                } else {
+                    const int cy = min(max(iy, 0), H - 1), cx = min(max(ix, 0), W - 1);
+                    foff[jj] = (cy * W + cx) * c_red + c16 * 8;
+                    fpok |= ((iy == cy && ix == cx) ? 1u : 0u) << jj;
+                }
             }
         };
         auto fetch = [&](Fetched& R) __attribute__((always_inline)) {
@@ -1681,8 +1709,25 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
             const bf16* pb = (KIND == SRC_ACT2 || KIND == SRC_SUM2) ? xb + (size_t)fn * plane : nullptr;
             const int cc = fslab * 32;
             R.pok = fpok;
+            if constexpr (BUFL) {
+                const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(pa), 0, plane_bytes, 0x00020000);
     #pragma unroll
-            for (int jj = 0; jj < NP; ++jj) R.praw[jj] = side_load_at<KIND>(pa, pb, foff[jj] + cc);
+                for (int jj = 0; jj < NP; ++jj) {
+                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ra, foff[jj], cc * 2, 0);
+                    R.praw[jj].a = make_uint4(v[0], v[1], v[2], v[3]);
+                }
+                if constexpr (KIND == SRC_ACT2 || KIND == SRC_SUM2) {
+                    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(pb), 0, plane_bytes, 0x00020000);
+    #pragma unroll
+                    for (int jj = 0; jj < NP; ++jj) {
+                        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rb, foff[jj], cc * 2, 0);
+                        R.praw[jj].b = make_uint4(v[0], v[1], v[2], v[3]);
+                    }
+                }
+            } else {
+    #pragma unroll
+                for (int jj = 0; jj < NP; ++jj) R.praw[jj] = side_load_at<KIND>(pa, pb, foff[jj] + cc);
+            }
             if (++fslab == n_slabs) {   // cursor -> the workgroup's next tile
                 fslab = 0; ftile += gstep;
                 ftx += step_x; if (ftx >= tiles_x) { ftx -= tiles_x; ++fty; }
@@ -1691,9 +1736,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
                 if (ftile < n_tiles) enter_tile();
             }
         };
+        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(wsrc), 0, 9 * a.c_out * c_red * 2, 0x00020000);
         auto fetch_w = [&](int slab_) __attribute__((always_inline)) {
     #pragma unroll
-            for (int j = 0; j < NW; ++j) wraw[j] = *reinterpret_cast<const u32x4*>(wsrc + wsrc_off[j] + slab_ * 32);
+            for (int j = 0; j < NW; ++j) {
+                if constexpr (BUFL) wraw[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, wsrc_off[j] * 2, slab_ * 64, 0);
+                else wraw[j] = *reinterpret_cast<const u32x4*>(wsrc + wsrc_off[j] + slab_ * 32);
+            }
         };
         auto commit = [&](Fetched& R) __attribute__((always_inline)) {
             char* lbuf = smem + (it & nbuf_mask) * x_stride;
@@ -1713,7 +1762,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
     #pragma unroll
             for (int jj = 0; jj < NP; ++jj) {
                 uint4 v = chunk_convert<KIND>(R.praw[jj], sa, ta, sb, tb);
-                if (!((R.pok >> jj) & 1u)) v = make_uint4(0u, 0u, 0u, 0u);
+                if constexpr (NEED_MASK) { if (!((R.pok >> jj) & 1u)) v = make_uint4(0u, 0u, 0u, 0u); }
                 if ((tid >> 2) + 64 * jj < G::RECS) *reinterpret_cast<uint4*>(lbuf + pdst[jj]) = v;
             }
             if (stage_w) {
@@ -1912,55 +1961,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) stat[nt][s2][e] = 0.f;
-        while (tile < n_tiles) {
-            int ntile = tile, nslab = slab + 1;
-            if (nslab == n_slabs) { nslab = 0; ntile += gstep; }
-            const int boff = (DMA ? it % rd : (it & nbuf_mask)) * x_stride;
-            const int woff = (DMA || wres) ? w_base + slab * W_BYTES : boff + X_BYTES_;
-            typename G::Bases b;
-#pragma unroll
-            for (int i = 0; i < G::NB; ++i)
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) b.x[i][ks] = b0.x[i][ks] + boff;
-            const char* wb[2] = {wb0[0] + woff, wb0[1] + woff};
-            if (slab == 0) {
-#pragma unroll
-                for (int g = 0; g < G::ACC; ++g)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[g][nt][r] = 0.f;
-            }
-            TICK();
-            if (ipb == 1 || !(it & 1)) __syncthreads();  // buffer `it` (ipb = 2: and it + 1) is full
-            TOCK(t_c);
-            TICK();
-            const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
-            const bool last_slab = slab == n_slabs - 1;
-            const bool rmw = rmw_any && last_slab;
-            if (pre_any && last_slab) {  // epilogue operands travel while the MFMAs run
-                if constexpr (DEEP) {
-                    if (tile + gstep < n_tiles) prefetch_epilogue(tile + gstep, old_n, yraw_n, rmw_any, cons_bnred && DEEP_Y);
-                    if constexpr (!DEEP_Y) prefetch_epilogue(tile, old, yraw, false, cons_bnred);
-                } else prefetch_epilogue(tile, old, yraw, rmw_any, cons_bnred);
-            }
-            if constexpr (CAN_DEFER) {
-                if (dpending) { G::template mfma<NT>(acc, b, wb, StoreHook<DS>{dst, out_rsrc}); dpending = false; }
-                else G::template mfma<NT>(acc, b, wb);
-            } else G::template mfma<NT>(acc, b, wb);
-#ifdef ANH_WS_PROFILE
-            __builtin_amdgcn_sched_barrier(0);
-#endif
-            TOCK(t_a);
-#ifdef ANH_WS_PROFILE
-            // how long the wave waits for its last MFMAs before the first accumulator register can be read (the matrix pipe's drain)
-            TICK();
-            if (last_slab) { asm volatile("v_mov_b32 %0, %1" : "=v"(prof_sink) : "v"(acc[0][0][0])); asm volatile("v_mov_b32 %0, %1" : "=v"(prof_sink) : "v"(acc[G::ACC - 1][NT - 1][15])); }
-            __builtin_amdgcn_sched_barrier(0);
-            TOCK(t_d);
-#endif
-            TICK();
-            if (last_slab) {
+        // TEAMS = 2: this team's tiles are those of its parity in the workgroup's walk; the epilogue of a finished tile runs in the NEXT interval
+        // (the other team's MFMA phase); `pend_*`: that tile and the item index its epilogue belongs to
+        int tord = 0, pend_tile = -1, pend_it = 0;
+        for (;;) {
+            // the epilogue of tile `et`, whose last item was `eit` (TEAMS = 1: right behind its MFMA phase)
+            auto epilogue = [&](int et, int eit) __attribute__((always_inline)) {
+                const int tx = et % tiles_x, ty = (et / tiles_x) % tiles_y, n = et / (tiles_x * tiles_y);
+                const bool rmw = rmw_any;
 #pragma unroll
                 for (int g = 0; g < G::ACC; ++g) {
                     size_t pix; bool valid;
@@ -1980,14 +1988,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
                     }
                     if constexpr (HEAD) store_pixel_tiles_head(acc[g][0], a, pix, n, valid, half, bnc, C_OUT, hw, hbias);
                     else if constexpr (ACT) {
-                        if (defer) pack_pixel_tiles_act<NT, DS>(acc[g], a, pix, valid, half, co_base, bnc, C_OUT, dst, g * NT * 2);
-                        else store_pixel_tiles_act<NT>(acc[g], a, pix, valid, half, co_base, bnc, C_OUT, ts,
-                                                       pst ? smem + e_off + (n_slabs == 1 ? (it & 1) * E_BYTES : 0) : nullptr, (g * 4 + wave) * 32 + col);
+                        bool packed = false;
+                        if constexpr (CAN_DEFER) { if (defer) { pack_pixel_tiles_act<NT, DS>(acc[g], a, pix, valid, half, co_base, bnc, C_OUT, dst, g * NT * 2); packed = true; } }
+                        if (!packed) store_pixel_tiles_act<NT>(acc[g], a, pix, valid, half, co_base, bnc, C_OUT, ts,
+                                                                   pst ? smem + e_off + (n_slabs == 1 ? (eit & 1) * E_BYTES : 0) : nullptr, (g * 4 + wave) * 32 + col);
                     }
                     else {
                         if constexpr (PS == 3) {   // the y operands of this group's sums: left in the epilogue buffer by the producer waves
                             if (pl) {
-                                const char* eb = smem + e_off + (n_slabs == 1 ? (it & 1) * E_BYTES : 0);
+                                const char* eb = smem + e_off + (n_slabs == 1 ? (eit & 1) * E_BYTES : 0);
                                 const int q = (g * 4 + wave) * 32 + col;
 #pragma unroll
                                 for (int nt = 0; nt < NT; ++nt)
@@ -1998,7 +2007,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
                         }
                         const bool to_ebuf = (ps && g >= PS_G0) || pst;   // (compile-time per unrolled g) this group's sums are the producers' / its stores are
                         store_pixel_tiles_rmw<NT>(acc[g], a, pix, valid, half, co_base, old[FWD ? 0 : g], rmw, stat, (PS == 2 && g >= PS_G0) ? 0 : stat_mode, yraw[FWD ? 0 : g], bnc,
-                                                  to_ebuf ? smem + e_off + (n_slabs == 1 ? (it & 1) * E_BYTES : 0) : nullptr, ((g - PS_G0) * 4 + wave) * 32 + col,
+                                                  to_ebuf ? smem + e_off + (n_slabs == 1 ? (eit & 1) * E_BYTES : 0) : nullptr, ((g - PS_G0) * 4 + wave) * 32 + col,
                                                   ts, !pst);
                     }
                 }
@@ -2013,16 +2022,83 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
                             }
                     }
                 }
+            };
+            if (tile >= n_tiles) {
+                if constexpr (TEAMS == 2) { if (pend_tile >= 0) epilogue(pend_tile, pend_it); }   // the tile this team finished in the workgroup's last interval(s)
+                break;
+            }
+            int ntile = tile, nslab = slab + 1;
+            if (nslab == n_slabs) { nslab = 0; ntile += gstep; }
+            const bool mine = TEAMS == 1 || (tord & 1) == team;
+            const int boff = (DMA ? it % rd : (it & nbuf_mask)) * x_stride;
+            const int woff = (DMA || wres) ? w_base + slab * W_BYTES : boff + X_BYTES_;
+            typename G::Bases b;
+#pragma unroll
+            for (int i = 0; i < G::NB; ++i)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) b.x[i][ks] = b0.x[i][ks] + boff;
+            const char* wb[2] = {wb0[0] + woff, wb0[1] + woff};
+            if (slab == 0 && mine) {
+#pragma unroll
+                for (int g = 0; g < G::ACC; ++g)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[g][nt][r] = 0.f;
+            }
+            TICK();
+            if (ipb == 1 || !(it & 1)) __syncthreads();  // buffer `it` (ipb = 2: and it + 1) is full
+            TOCK(t_c);
+            TICK();
+            const bool last_slab = slab == n_slabs - 1;
+            if constexpr (TEAMS == 2) {
+                if (!mine) {   // the other team's MFMA phase: this team's finished tile leaves now
+                    if (pend_tile >= 0) { epilogue(pend_tile, pend_it); pend_tile = -1; }
+                    TOCK(t_b);
+                    if (nslab == 0) ++tord;
+                    tile = ntile; slab = nslab; ++it;
+                    continue;
+                }
+            }
+            if (pre_any && last_slab) {  // epilogue operands travel while the MFMAs run
+                if constexpr (DEEP) {
+                    if (tile + gstep < n_tiles) prefetch_epilogue(tile + gstep, old_n, yraw_n, rmw_any, cons_bnred && DEEP_Y);
+                    if constexpr (!DEEP_Y) prefetch_epilogue(tile, old, yraw, false, cons_bnred);
+                } else prefetch_epilogue(tile, old, yraw, rmw_any, cons_bnred);
+            }
+            // TEAMS = 2: the team in its MFMA phase outranks the team in its epilogue at the SIMD's issue arbiter (bit 18 of wres_ switches it off)
+            if constexpr (TEAMS == 2) { if (!((wres_ >> 18) & 1)) __builtin_amdgcn_s_setprio(3); }
+            if constexpr (CAN_DEFER) {
+                if (dpending) { G::template mfma<NT>(acc, b, wb, StoreHook<DS>{dst, out_rsrc}); dpending = false; }
+                else G::template mfma<NT>(acc, b, wb);
+            } else G::template mfma<NT>(acc, b, wb);
+            if constexpr (TEAMS == 2) { if (!((wres_ >> 18) & 1)) __builtin_amdgcn_s_setprio(0); }
+#ifdef ANH_WS_PROFILE
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+            TOCK(t_a);
+#ifdef ANH_WS_PROFILE
+            // how long the wave waits for its last MFMAs before the first accumulator register can be read (the matrix pipe's drain)
+            TICK();
+            if (last_slab) { asm volatile("v_mov_b32 %0, %1" : "=v"(prof_sink) : "v"(acc[0][0][0])); asm volatile("v_mov_b32 %0, %1" : "=v"(prof_sink) : "v"(acc[G::ACC - 1][NT - 1][15])); }
+            __builtin_amdgcn_sched_barrier(0);
+            TOCK(t_d);
+#endif
+            TICK();
+            if (last_slab) {
+                if constexpr (TEAMS == 2) { pend_tile = tile; pend_it = it; }
+                else epilogue(tile, it);
             }
             if constexpr (CAN_DEFER) { if (defer && last_slab) dpending = true; }
             TOCK(t_b);
+            if (nslab == 0) ++tord;
             tile = ntile; slab = nslab; ++it;
         }
         if constexpr (CAN_DEFER) { if (dpending) flush_deferred<DS>(dst, out_rsrc); }
         if constexpr (PS == 1 || PS == 2 || PST) { if (ps || pst) __syncthreads(); }   // the consumers' closing barrier: the last tile's epilogue buffer is complete
         if (stat_mode) {
             __syncthreads();  // (matched by the producers) every wave is done with the staging buffers
-            float* red = reinterpret_cast<float*>(smem) + (size_t)(wave * 64 + lane) * (32 * NT);
+            float* red = reinterpret_cast<float*>(smem) + (size_t)((team * 4 + wave) * 64 + lane) * (32 * NT);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -2038,13 +2114,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
         // 512 / (64 NT) adjacent threads shares one sum (strided columns, then an xor-shuffle tree)
         constexpr int GRP = 512 / (64 * NT);   // 8 or 4 threads per sum
         const int t = threadIdx.x / GRP, part = threadIdx.x % GRP;
-        {
+        if (TEAMS == 1 || threadIdx.x < 512) {   // (TEAMS = 2: eight consumer waves' partials, the first 512 threads fold them)
             const int ch = t >> 1, which = t & 1;
             const int nt = ch >> 5, s2 = (ch >> 4) & 1, hf = (ch >> 3) & 1, j = ch & 7;
             const float* red = reinterpret_cast<const float*>(smem);
             double sum = 0.0;
 #pragma unroll 4
-            for (int e = part; e < 128; e += GRP) {
+            for (int e = part; e < 128 * TEAMS; e += GRP) {
                 const int w = e >> 5, c = e & 31;
                 sum += (double)red[(size_t)(w * 64 + hf * 32 + c) * (32 * NT) + (nt * 2 + s2) * 16 + which * 8 + j];
             }
@@ -2094,7 +2170,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
     if (fuse_bnred && a.bnred_acc) bnacc_finish_backward(a.bnred_finish, (int)(gridDim.x * gridDim.y));
 #ifdef ANH_WS_PROFILE
     if (prof && lane == 0) {
-        long long* o = prof + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (producer ? 4 : 0) + wave) * 8;
+        long long* o = prof + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * (4 * TEAMS + 4) + (producer ? 4 * TEAMS : 4 * team) + wave) * 8;
         o[0] = t_a; o[1] = t_b; o[2] = t_c; o[3] = producer ? c_loop : it; o[4] = t_entry; o[5] = producer ? t_loop : t_d + (prof_sink == 12345.f ? 1 : 0); o[6] = t_loop_end; o[7] = wall_clock64();
     }
 #endif
@@ -2106,7 +2182,7 @@ int ws_target_wgs();
 
 // LDS layout of a persistent conv launch and whether it takes the producer-side form of the fused bn backward sums (PS).
 // with_bnred: the sums are wanted (conv_fused_bnred_blocks asks before ConvArgs::bnred_* are set).
-struct WsLayout { int wres; size_t lds; int ps /* 0 consumer-side sums, 1 producer-side, 2 split by accumulator group, ... */; int e_off; int ipb = 1; };
+struct WsLayout { int wres; size_t lds; int ps /* 0 consumer-side sums, 1 producer-side, 2 split by accumulator group, ... */; int e_off; int ipb = 1; int teams = 1; };
 WsLayout ws_layout(const ConvArgs& a, int recs, int acc, int nt, bool with_bnred) {
     const size_t tables = (size_t)a.c_red * 16 + (size_t)nt * 32 * 16;
     const size_t x_bytes = (size_t)recs * 64, w_bytes = (size_t)9 * nt * 32 * 64;
@@ -2118,6 +2194,22 @@ WsLayout ws_layout(const ConvArgs& a, int recs, int acc, int nt, bool with_bnred
     WsLayout L{};
     L.wres = resident_on && n_slabs >= 2 && resident_lds <= 160 * 1024 && 2 * x_bytes + (size_t)n_slabs * w_bytes >= (size_t)32 * 1024 * nt;
     L.lds = L.wres ? resident_lds : 2 * (x_bytes + w_bytes) + tables;
+    // Two consumer teams (TEAMS = 2 in the kernel; ANH_WS_TEAMS: 0 off, 1 every form that has one, 2 inference forms only, 3 training forms
+    // only, 4 training forward forms only): the forms whose waves fit 168 VGPRs — inference: stride-1 at 32 and 64 output channels, the up conv at 32; training: the
+    // stride-1 conv at 32 channels, forward and backward-data.  They keep every sum in the consumer waves (PS = 0) and meet after every item;
+    // with sums, the closing reduction borrows 64 NT KiB from the start of the buffer.
+    {
+        static const int teams_env = getenv("ANH_WS_TEAMS") ? atoi(getenv("ANH_WS_TEAMS")) : 0;
+        const bool infer = a.out_scale != nullptr, s1 = recs == 340, up = recs == 165;
+        bool teams = false;
+        if (infer) teams = (teams_env == 1 || teams_env == 2) && (s1 || (up && nt == 1)) && (a.src.kind == SRC_RAW || a.src.kind == SRC_SUM2);
+        else {
+            const bool fwd = (a.stat_partials || a.stat_acc) && !with_bnred && !a.out_accumulate && !a.out2;
+            teams = (teams_env == 1 || teams_env == 3 || (teams_env == 4 && fwd)) && s1 && nt == 1 && L.lds - tables >= (size_t)64 * 1024 * nt &&
+                    (fwd ? (a.src.kind == SRC_RAW || a.src.kind == SRC_ACT || a.src.kind == SRC_ACT2) : a.src.kind == SRC_RAW);
+        }
+        if (teams) { L.teams = 2; return L; }
+    }
     // Producer-side bn backward sums (the PS forms): plain-copy staging with the fused reduction, when the epilogue buffer fits —
     // one buffer of ACC x 128 pixel slots, two (alternating by item) for single-slab layers whose every item ends a tile.  A
     // single-slab layer may take the resident layout to make room (one filter block instead of a copy per patch buffer; whatever
@@ -2174,7 +2266,7 @@ WsLayout ws_layout(const ConvArgs& a, int recs, int acc, int nt, bool with_bnred
 template <class G, int NT>
 void launch_ws(const ConvArgs& a, int tiles_x, int tiles_y, int flip, hipStream_t s) {
     const int n_tiles = tiles_x * tiles_y * a.n, groups = a.c_out / (NT * 32);
-    const dim3 grid((unsigned)std::max(1, std::min(n_tiles, ws_target_wgs() / groups)), (unsigned)groups), block(512);
+    const dim3 grid((unsigned)std::max(1, std::min(n_tiles, ws_target_wgs() / groups)), (unsigned)groups);
     const WsLayout lay = ws_layout(a, G::RECS, G::ACC, NT, a.bnred_partials != nullptr || a.bnred_acc != nullptr);
     const int wres = lay.wres;
     size_t lds = lay.lds;
@@ -2187,7 +2279,8 @@ void launch_ws(const ConvArgs& a, int tiles_x, int tiles_y, int flip, hipStream_
         if (at + strips <= 160 * 1024) { ts_off = (int)at; lds = at + strips; }
     }
     const int e_off = lay.e_off | ((ts_off >> 4) << 18);
-    int extra_bits = (lay.ipb == 2) << 17;   // (bit 16: the DMA form's patch ring has three slots; bit 17: two items per barrier)
+    static const int teams_prio_env = getenv("ANH_WS_TEAMS_PRIO") ? atoi(getenv("ANH_WS_TEAMS_PRIO")) : 1;
+    int extra_bits = ((lay.ipb == 2) << 17) | ((teams_prio_env ? 0 : 1) << 18);   // (bit 16: the DMA form's patch ring has three slots; bit 17: two items per barrier; bit 18: two teams without the MFMA phase's priority)
     const int ps = lay.ps;
     // ANH_WS_ROLE_MAP: 0 = one producer + one consumer per SIMD, 1 = consumers on SIMDs 0-1 / producers on SIMDs 2-3, 2 = map 1 for the
     // 32-output-channel kernels only (their MFMA phase is short; the 64-channel kernels need all four matrix cores)
@@ -2205,33 +2298,35 @@ void launch_ws(const ConvArgs& a, int tiles_x, int tiles_y, int flip, hipStream_
     a2.out_bytes = (unsigned)std::min<unsigned long long>(out_bytes, 0xFFFFFF00ull);
     static const int stagger_env = getenv("ANH_WS_STAGGER") ? atoi(getenv("ANH_WS_STAGGER")) & 0xff : 0;
     const int role_map = (role_env == 1 || (role_env == 2 && NT == 1) ? 1 : 0) | ((prio_env & 3) << 1) | (bands << 3) | (defer << 4) | (stagger_env << 7);
-    auto launch = [&](auto kernel) {
+    auto launch = [&](auto kernel, unsigned threads = 512) {
+        const dim3 block(threads);
         ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), lds);
 #ifndef ANH_WS_PROFILE
         hipLaunchKernelGGL(kernel, grid, block, lds, s, a2, tiles_x, tiles_y, flip, (long long*)nullptr, wres | (role_map << 1) | extra_bits, e_off);
 #else
         static const int prof_on = getenv("ANH_WS_PROF") ? atoi(getenv("ANH_WS_PROF")) : 0;
         static long long* prof = nullptr;
-        if (prof_on && !prof) HIP_CHECK(hipMalloc(&prof, 1024 * 8 * 8 * sizeof(long long)));
+        if (prof_on && !prof) HIP_CHECK(hipMalloc(&prof, 1024 * 12 * 8 * sizeof(long long)));
         static const int nostore = getenv("ANH_WS_PROF_NOSTORE") ? atoi(getenv("ANH_WS_PROF_NOSTORE")) : 0;
         hipLaunchKernelGGL(kernel, grid, block, lds, s, a2, tiles_x, tiles_y, flip, prof_on ? prof : nullptr, wres | (role_map << 1) | (nostore << 6) | extra_bits, e_off);
         if (prof_on) {
             HIP_CHECK(hipStreamSynchronize(s));
-            const int nwg = grid.x * grid.y;
-            std::vector<long long> h((size_t)nwg * 64);
+            const int nwg = grid.x * grid.y, nw = (int)threads / 64, nc = nw - 4;   // waves per workgroup, consumer waves among them
+            std::vector<long long> h((size_t)nwg * nw * 8);
             HIP_CHECK(hipMemcpy(h.data(), prof, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
             double pa = 0, pb = 0, pc = 0, ca = 0, cb = 0, cc = 0, cd = 0, items = 0;
             long long first_entry = h[4], last_exit = h[7];
             double entry = 0, pro = 0, loop = 0, tail = 0, cycles = 0;   // over the producer waves: entry skew, entry -> loop, loop, loop end -> exit; shader cycles of the loop
             for (int w = 0; w < nwg; ++w) {
-                for (int v = 0; v < 8; ++v) { first_entry = std::min(first_entry, h[(w * 8 + v) * 8 + 4]); last_exit = std::max(last_exit, h[(w * 8 + v) * 8 + 7]); }
-                for (int v = 0; v < 4; ++v) { ca += h[(w * 8 + v) * 8]; cb += h[(w * 8 + v) * 8 + 1]; cc += h[(w * 8 + v) * 8 + 2]; cd += h[(w * 8 + v) * 8 + 5]; }
-                for (int v = 4; v < 8; ++v) { pa += h[(w * 8 + v) * 8]; pb += h[(w * 8 + v) * 8 + 1]; pc += h[(w * 8 + v) * 8 + 2]; }
-                items += h[(w * 8) * 8 + 3];
+                for (int v = 0; v < nw; ++v) { first_entry = std::min(first_entry, h[(w * nw + v) * 8 + 4]); last_exit = std::max(last_exit, h[(w * nw + v) * 8 + 7]); }
+                for (int v = 0; v < nc; ++v) { ca += h[(w * nw + v) * 8]; cb += h[(w * nw + v) * 8 + 1]; cc += h[(w * nw + v) * 8 + 2]; cd += h[(w * nw + v) * 8 + 5]; }
+                for (int v = nc; v < nw; ++v) { pa += h[(w * nw + v) * 8]; pb += h[(w * nw + v) * 8 + 1]; pc += h[(w * nw + v) * 8 + 2]; }
+                items += h[(w * nw) * 8 + 3];
             }
+            ca *= 4.0 / nc; cb *= 4.0 / nc; cc *= 4.0 / nc; cd *= 4.0 / nc;   // per consumer wave (two teams: each runs the MFMA phase of every second tile)
             for (int w = 0; w < nwg; ++w)
-                for (int v = 4; v < 8; ++v) {   // producer waves carry the loop stamps
-                    const long long* o = &h[(w * 8 + v) * 8];
+                for (int v = nc; v < nw; ++v) {   // producer waves carry the loop stamps
+                    const long long* o = &h[(w * nw + v) * 8];
                     entry += (double)(o[4] - first_entry); pro += (double)(o[5] - o[4]); loop += (double)(o[6] - o[5]); tail += (double)(o[7] - o[6]);
                     cycles += (double)o[3];
                 }
@@ -2250,6 +2345,12 @@ void launch_ws(const ConvArgs& a, int tiles_x, int tiles_y, int flip, hipStream_
         if (a.head_out) {   // the layer under the 1x1 head: logits instead of the activation
             if constexpr (std::is_same<G, GeoS1>::value && NT == 1) {
                 ANH_REQUIRE(conv_head_in_epilogue_ok(a) && a.head_w && a.head_bias, "conv_ws: this layer cannot take the head in its epilogue");
+                if (lay.teams == 2) {
+                    if (a.src.kind == SRC_RAW) launch(conv3x3_ws_kernel<G, NT, SRC_RAW, true, true, 0, true, false, 2>, 768);
+                    else launch(conv3x3_ws_kernel<G, NT, SRC_SUM2, true, true, 0, true, false, 2>, 768);
+                    HIP_CHECK(hipGetLastError());
+                    return;
+                }
                 switch (a.src.kind) {
                     case SRC_RAW: launch(conv3x3_ws_kernel<G, NT, SRC_RAW, true, true, false, true>); break;
                     case SRC_SUM2: launch(conv3x3_ws_kernel<G, NT, SRC_SUM2, true, true, false, true>); break;
@@ -2258,6 +2359,14 @@ void launch_ws(const ConvArgs& a, int tiles_x, int tiles_y, int flip, hipStream_
             } else fail(ANH_ERR_INTERNAL, "conv_ws: the head-in-epilogue form exists for the stride-1 32-channel kernel only");
             HIP_CHECK(hipGetLastError());
             return;
+        }
+        if constexpr (std::is_same<G, GeoS1>::value || (std::is_same<G, GeoUp>::value && NT == 1)) {
+            if (lay.teams == 2) {
+                if (a.src.kind == SRC_RAW) launch(conv3x3_ws_kernel<G, NT, SRC_RAW, true, true, 0, false, false, 2>, 768);
+                else launch(conv3x3_ws_kernel<G, NT, SRC_SUM2, true, true, 0, false, false, 2>, 768);
+                HIP_CHECK(hipGetLastError());
+                return;
+            }
         }
         switch (a.src.kind) {
             case SRC_RAW: {
@@ -2289,6 +2398,19 @@ void launch_ws(const ConvArgs& a, int tiles_x, int tiles_y, int flip, hipStream_
     // Same-box A/B: 1.757 -> 1.738 ms per step; the skip-add 64->64 forward 72.7 -> 63.1 us.)
     constexpr bool HAS_FWD_FORM = true;
     const bool fwd_form = HAS_FWD_FORM && (a.stat_partials || a.stat_acc) && !a.bnred_partials && !a.bnred_acc && !a.out_accumulate && !a.out2;
+    if constexpr (std::is_same<G, GeoS1>::value && NT == 1) {
+        if (lay.teams == 2) {
+            if (fwd_form) {
+                switch (a.src.kind) {
+                    case SRC_RAW: launch(conv3x3_ws_kernel<G, NT, SRC_RAW, true, false, 0, false, false, 2>, 768); break;
+                    case SRC_ACT: launch(conv3x3_ws_kernel<G, NT, SRC_ACT, true, false, 0, false, false, 2>, 768); break;
+                    default: launch(conv3x3_ws_kernel<G, NT, SRC_ACT2, true, false, 0, false, false, 2>, 768); break;
+                }
+            } else launch(conv3x3_ws_kernel<G, NT, SRC_RAW, false, false, 0, false, false, 2>, 768);
+            HIP_CHECK(hipGetLastError());
+            return;
+        }
+    }
     if constexpr (HAS_FWD_FORM) {
         if (fwd_form) {
             switch (a.src.kind) {
@@ -2962,7 +3084,8 @@ int ws_target_wgs() { static const int t = getenv("ANH_WS_WGS") ? atoi(getenv("A
 ConvPlan conv_plan(const ConvArgs& a) {
     static const int wsm = getenv("ANH_CONV_WS") ? atoi(getenv("ANH_CONV_WS")) : 7;  // bit 0: stride 1, bit 1: down, bit 2: up (0 = the classic one-tile kernels)
     // the persistent kernels index within one image with 32-bit element offsets
-    const bool small_plane = (int64_t)a.h_in * a.w_in * a.c_red < (1ll << 31);
+    // (and fetch through buffer descriptors of one image each: its bytes, and the padding offset 0xFFFFF000 + a slab's offset, stay below 2^32)
+    const bool small_plane = (int64_t)a.h_in * a.w_in * a.c_red * 2 < 0xFFFFF000ll;
     ConvPlan p{};
     p.geo = a.stride == 1 ? 0 : (a.gather == 0 ? 1 : 2);
     p.nt = a.c_out == 32 ? 1 : 2;  // 64, or 128 as two workgroup groups of 64 output channels

@@ -515,6 +515,9 @@ def infer_one_size(args, side, with_cpu_baseline, aa, aad, torch, dist, prec, ra
         with open(args.dump_launch_order, "w") as f:
             json.dump({"order": net.profile_launch_order()}, f, indent=0)
     net.profile_reset()
+    if os.environ.get("ANH_BENCH_VERBOSE") and rank == 0:   # every kernel class of one image, serialised by the event pairs
+        for e in sorted(prof_all, key=lambda e: -e["total_ms"]):
+            print(f"  {e['name']:52s} {e['total_ms']:8.3f} ms/image  {e['launches']:4d} launches", file=sys.stderr)
     win = aa.RuntimeNet.GetRecommendedInputDimension(LEVELS, tiles[0][0][2] - tiles[0][0][0] + 1)   # side of a tile's input window
     layers, dims = layer_geometry(aa, cfg, win)
     convs = [e for e in prof_all if ENTRY_RE.search(e["name"]) and layers[int(ENTRY_RE.search(e["name"]).group(2))].k > 1]

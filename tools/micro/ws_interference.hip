@@ -6,6 +6,9 @@
 //   2 + ~300 VALU operations per item            3 + 6 x 16-byte global loads per thread and item (the fetch), consumed next item
 //   4 all of 1-3                                 5 all of 1-3 and the consumers store 8 x 16 bytes per lane every second item (the epilogue)
 //   6 / 7 / 8: as 0 with ONE barrier per 2 / 3 / 4 items
+//   12 / 13: TWO consumer teams (768 threads, three waves per SIMD) taking turns: in the interval in which one team runs the nest, the other
+//   issues the four stores of its previous item (12), after ~150 VALU operations (13: the epilogue's arithmetic); producers as in 4.
+//   To be read against 10 (one team: nest, then four stores, every item).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -13,16 +16,31 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 template <int MODE>
-__global__ __launch_bounds__(512, 2) void k(float* out, const u32x4* src, u32x4* dst, int iters, size_t src_elems) {
+__global__ __launch_bounds__((MODE >= 12 ? 768 : 512), (MODE >= 12 ? 3 : 2)) void k(float* out, const u32x4* src, u32x4* dst, int iters, size_t src_elems) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    for (int i = threadIdx.x; i < 120 * 1024 / 4; i += 512) reinterpret_cast<float*>(smem)[i] = 0.001f * i;
+    constexpr int NTHR = MODE >= 12 ? 768 : 512;
+    for (int i = threadIdx.x; i < 120 * 1024 / 4; i += NTHR) reinterpret_cast<float*>(smem)[i] = 0.001f * i;
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (wave < 4) {
+    const int lane = threadIdx.x & 63, hw_wave = threadIdx.x >> 6, wave = hw_wave & 3, team = MODE >= 12 ? hw_wave >> 2 : 0;
+    if (hw_wave < NTHR / 64 - 4) {
         f32x16 acc[2][2];
         for (int g = 0; g < 2; ++g) for (int t = 0; t < 2; ++t) for (int r = 0; r < 16; ++r) acc[g][t][r] = 0.f;
         for (int it = 0; it < iters; ++it) {
             if (MODE < 6 || MODE > 8 || (it % (MODE - 4)) == 0) __syncthreads();   // MODE 6 / 7 / 8: one barrier per 2 / 3 / 4 items
+            if (MODE >= 12 && (it & 1) != team) {   // the other team's nest: this team's previous item leaves
+                if (it > 0) {
+                    if (MODE == 13) {
+#pragma unroll
+                        for (int r = 0; r < 9; ++r)
+#pragma unroll
+                            for (int j = 0; j < 16; ++j) acc[0][0][j] = fmaf(acc[0][0][j], 1.0001f, 0.5f);
+                    }
+                    u32x4* o = dst + ((size_t)blockIdx.x * 64 + (it >> 1) % 64) * 2048 + (team * 1024 + wave * 64 + lane);
+                    for (int s = 0; s < 4; ++s)
+                        o[s * 256] = u32x4{__float_as_uint(acc[0][0][s]), __float_as_uint(acc[0][1][s]), __float_as_uint(acc[1][0][s]), __float_as_uint(acc[1][1][s])};
+                }
+                continue;
+            }
             // the conv kernel's conflict-free layout: 64-byte pixel records, 16-byte chunk index XOR-ed with (column >> 2) & 3
             const int col = lane & 31, half = lane >> 5;
             const char* xbase = smem + (it & 1) * 22 * 1024;
@@ -58,9 +76,9 @@ __global__ __launch_bounds__(512, 2) void k(float* out, const u32x4* src, u32x4*
         }
         float s = 0;
         for (int g = 0; g < 2; ++g) for (int t = 0; t < 2; ++t) for (int r = 0; r < 16; ++r) s += acc[g][t][r];
-        out[(size_t)blockIdx.x * 256 + threadIdx.x] = s;
+        out[(size_t)blockIdx.x * 512 + threadIdx.x] = s;
     } else {
-        const int tid = threadIdx.x - 256;
+        const int tid = threadIdx.x - (NTHR - 256);
         u32x4 regs[6];
         for (int j = 0; j < 6; ++j) regs[j] = u32x4{(unsigned)tid, (unsigned)j, 0u, 0u};
         float v[8] = {1.f, 2.f, 3.f, 4.f, 5.f, 6.f, 7.f, 8.f};
@@ -87,18 +105,18 @@ __global__ __launch_bounds__(512, 2) void k(float* out, const u32x4* src, u32x4*
         float s = 0;
         for (int j = 0; j < 8; ++j) s += v[j];
         for (int j = 0; j < 6; ++j) s += (float)regs[j][0];
-        out[(size_t)blockIdx.x * 256 + tid + 65536] = s;
+        out[(size_t)blockIdx.x * 256 + tid + 131072] = s;
     }
 }
 
 template <class K>
-static void run(const char* name, K kernel, int iters, float* out, const u32x4* src, u32x4* dst, size_t n) {
+static void run(const char* name, K kernel, int iters, float* out, const u32x4* src, u32x4* dst, size_t n, int threads = 512) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
     hipEvent_t a, b;
     (void)hipEventCreate(&a); (void)hipEventCreate(&b);
     for (int rep = 0; rep < 3; ++rep) {
         (void)hipEventRecord(a, 0);
-        hipLaunchKernelGGL(kernel, dim3(256), dim3(512), 120 * 1024, 0, out, src, dst, iters, n);
+        hipLaunchKernelGGL(kernel, dim3(256), dim3(threads), 120 * 1024, 0, out, src, dst, iters, n);
         (void)hipEventRecord(b, 0);
         (void)hipEventSynchronize(b);
         float ms = 0;
@@ -111,7 +129,7 @@ static void run(const char* name, K kernel, int iters, float* out, const u32x4* 
 int main() {
     float* out; u32x4 *src, *dst;
     const size_t n = (size_t)64 << 20;   // 1 GiB of 16-byte elements to fetch from
-    (void)hipMalloc(&out, 4 * 131072 * 2); (void)hipMalloc(&src, n * 16); (void)hipMalloc(&dst, (size_t)256 * 64 * 2048 * 16);
+    (void)hipMalloc(&out, 4 * 131072 * 2); /* consumers' sums: 256 workgroups x 512; producers' behind them */ (void)hipMalloc(&src, n * 16); (void)hipMalloc(&dst, (size_t)256 * 64 * 2048 * 16);
     (void)hipMemset(src, 1, n * 16);
     const int iters = 2000;
     run("0 consumers + barrier per item only", k<0>, iters, out, src, dst, n);
@@ -125,5 +143,7 @@ int main() {
     run("6 as 0, ONE barrier per TWO items", k<6>, iters, out, src, dst, n);
     run("7 as 0, one barrier per three items", k<7>, iters, out, src, dst, n);
     run("8 as 0, one barrier per four items", k<8>, iters, out, src, dst, n);
+    run("12 two consumer teams taking turns: nest | four stores", k<12>, iters, out, src, dst, n, 768);
+    run("13 ... nest | ~150 VALU + four stores", k<13>, iters, out, src, dst, n, 768);
     return 0;
 }
