@@ -1256,6 +1256,30 @@ struct GeoS1 {
         }
 #endif
     }
+    // The 32 -> 32 layer (one reduction slab, one channel tile): its 18 filter fragments (9 taps x 2 k-steps, 72 VGPRs) are the same for
+    // every tile — read from LDS once per workgroup and kept in registers, the nest then reads the 24 pixel fragments of an item only
+    // (42 LDS reads per 36 MFMAs before: the phase ran at half the matrix rate on LDS bandwidth).
+    __device__ static void load_filter_regs(bf16x8 (&wreg)[18], const char* (&wb)[2]) {
+#pragma unroll
+        for (int tl = 0; tl < 9; ++tl)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) wreg[tl * 2 + ks] = lds_frag(wb[ks] + (tl * 32) * 64);
+    }
+    __device__ static void mfma_wreg(f32x16 (&acc)[ACC][1], const Bases& b, const bf16x8 (&wreg)[18]) {
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 xf[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xf[r] = lds_frag(b.x[kx][ks] + r * (PW * 64));
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) acc[g][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[(ky * 3 + kx) * 2 + ks], xf[g + ky], acc[g][0], 0, 0, 0);
+            }
+        }
+    }
     static constexpr bool TS_OK = true;   // a wave's group is 32 consecutive pixels of one output row: transposed stores apply
     __device__ static void row_origin(int g, const ConvArgs& a, int n, int ty, int tx, int wave, size_t& row_pix0, bool& row_valid, int& cols_valid) {
         const int oy = ty * TH + wave * 2 + g, ox0 = tx * TW;
@@ -1961,6 +1985,13 @@ __global__ __launch_bounds__(256 * (TEAMS + 1), (TEAMS == 2 ? 3 : 2)) void conv3
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) stat[nt][s2][e] = 0.f;
+        // filter fragments in registers (GeoS1, one channel tile, one reduction slab; wres_ bit 19 switches it off: ANH_WS_FILTER_REGS=0)
+#ifndef ANH_WS_FILTER_REGS_BUILD
+#define ANH_WS_FILTER_REGS_BUILD 1
+#endif
+        constexpr bool WREG = ANH_WS_FILTER_REGS_BUILD && std::is_same<G, GeoS1>::value && NT == 1 && !DMA && TEAMS == 1 && !CAN_DEFER;
+        const bool wreg_on = WREG && n_slabs == 1 && !((wres_ >> 19) & 1);
+        bf16x8 wreg[WREG ? 18 : 1];
         // TEAMS = 2: this team's tiles are those of its parity in the workgroup's walk; the epilogue of a finished tile runs in the NEXT interval
         // (the other team's MFMA phase); `pend_*`: that tile and the item index its epilogue belongs to
         int tord = 0, pend_tile = -1, pend_it = 0;
@@ -2068,6 +2099,12 @@ __global__ __launch_bounds__(256 * (TEAMS + 1), (TEAMS == 2 ? 3 : 2)) void conv3
             }
             // TEAMS = 2: the team in its MFMA phase outranks the team in its epilogue at the SIMD's issue arbiter (bit 18 of wres_ switches it off)
             if constexpr (TEAMS == 2) { if (!((wres_ >> 18) & 1)) __builtin_amdgcn_s_setprio(3); }
+            if constexpr (WREG) {
+                if (wreg_on) {
+                    if (it == 0) G::load_filter_regs(wreg, wb);   // (the filter block of a single-slab layer is in both patch buffers from items 0 / 1 on)
+                    G::mfma_wreg(acc, b, wreg);
+                } else G::template mfma<NT>(acc, b, wb);
+            } else
             if constexpr (CAN_DEFER) {
                 if (dpending) { G::template mfma<NT>(acc, b, wb, StoreHook<DS>{dst, out_rsrc}); dpending = false; }
                 else G::template mfma<NT>(acc, b, wb);
@@ -2280,7 +2317,8 @@ void launch_ws(const ConvArgs& a, int tiles_x, int tiles_y, int flip, hipStream_
     }
     const int e_off = lay.e_off | ((ts_off >> 4) << 18);
     static const int teams_prio_env = getenv("ANH_WS_TEAMS_PRIO") ? atoi(getenv("ANH_WS_TEAMS_PRIO")) : 1;
-    int extra_bits = ((lay.ipb == 2) << 17) | ((teams_prio_env ? 0 : 1) << 18);   // (bit 16: the DMA form's patch ring has three slots; bit 17: two items per barrier; bit 18: two teams without the MFMA phase's priority)
+    static const int filter_regs_env = getenv("ANH_WS_FILTER_REGS") ? atoi(getenv("ANH_WS_FILTER_REGS")) : 1;
+    int extra_bits = ((lay.ipb == 2) << 17) | ((teams_prio_env ? 0 : 1) << 18) | ((filter_regs_env ? 0 : 1) << 19);   // (bit 16: the DMA form's patch ring has three slots; bit 17: two items per barrier; bit 18: two teams without the MFMA phase's priority)
     const int ps = lay.ps;
     // ANH_WS_ROLE_MAP: 0 = one producer + one consumer per SIMD, 1 = consumers on SIMDs 0-1 / producers on SIMDs 2-3, 2 = map 1 for the
     // 32-output-channel kernels only (their MFMA phase is short; the 64-channel kernels need all four matrix cores)
