@@ -54,10 +54,22 @@ constexpr int PH = TH + 2, PW = TW + 2;   // input patch
 constexpr int PATCH_PIX = PH * PW;        // 340 pixel records of 64 B
 constexpr int X_BYTES = PATCH_PIX * 64;   // 21,760
 
+// two fp32 -> one packed bf16 pair, round to nearest even.  (Round 4: written as ONE vector conversion hipcc emits a single
+// v_cvt_pk_bf16_f32 per pair instead of two half-live ones and a v_perm_b32 in about 1,600 places of this file — bit-identical, and
+// MEASURED slower: inference 4,460 / 4,471 / 4,524 / 4,534 -> 4,375 / 4,296 / 4,401 / 4,425 Mpx/s, training unchanged.  -DANH_PACK2_VECTOR=1.)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#ifndef ANH_PACK2_VECTOR
+#define ANH_PACK2_VECTOR 0
+#endif
 __device__ __forceinline__ unsigned pack2(float lo, float hi) {
+#if ANH_PACK2_VECTOR
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+#else
     bf16x2 t;
     t[0] = (bf16)lo; t[1] = (bf16)hi;
     return __builtin_bit_cast(unsigned, t);
+#endif
 }
 __device__ __forceinline__ float lo_f(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float hi_f(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
@@ -415,6 +427,25 @@ __device__ __forceinline__ void store_pixel_tiles_head(const f32x16& acc, const 
         auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
         auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
         const unsigned w4[4] = {r0[0], r1[0], r0[1], r1[1]};   // channels 16 s + 8 half + 0 .. 7, two per word
+#ifndef ANH_HEAD_PK_FMA
+#define ANH_HEAD_PK_FMA 0
+#endif
+#if ANH_HEAD_PK_FMA
+        // two classes per instruction (v_pk_fma_f32; the activation broadcast to both halves): the same chain per class, half the VALU
+        // issue slots — on a SIMD they are what this epilogue costs
+        typedef f32x2 f32x2_t;
+#pragma unroll
+        for (int kp = 0; kp < 2; ++kp) {
+            f32x2_t sum = {0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float lo = lo_f(w4[i]), hi = hi_f(w4[i]);
+                sum = __builtin_elementwise_fma(f32x2_t{lo, lo}, f32x2_t{hw[s][2 * i][2 * kp], hw[s][2 * i][2 * kp + 1]}, sum);
+                sum = __builtin_elementwise_fma(f32x2_t{hi, hi}, f32x2_t{hw[s][2 * i + 1][2 * kp], hw[s][2 * i + 1][2 * kp + 1]}, sum);
+            }
+            part[s][2 * kp] = sum[0]; part[s][2 * kp + 1] = sum[1];
+        }
+#else
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             float sum = 0.f;
@@ -425,6 +456,7 @@ __device__ __forceinline__ void store_pixel_tiles_head(const f32x16& acc, const 
             }
             part[s][k] = sum;
         }
+#endif
     }
     const size_t plane = (size_t)a.h_out * a.w_out;
 #pragma unroll
