@@ -1071,43 +1071,82 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_ws_kernel(WgParams a, int til
         struct Regs { RawChunk<KP> p[NP]; RawChunk<KT> t[NT_]; unsigned pok, tok; };
         Regs ra, rb;
         const size_t p_plane = (size_t)a.patch.h * a.patch.w * a.patch.c, t_plane = (size_t)a.tile.h * a.tile.w * a.tile.c;  // < 2^31 elements (host check)
+        // Buffer loads, as the conv kernels' producers (round 4: a SIMD's issue port is what these kernels spend): one descriptor per
+        // image and operand, a 32-bit byte offset per chunk, positions outside the image at an offset outside the descriptor (zeros
+        // by themselves: the plain-copy kinds need neither clamps nor masks).  -DANH_WS_BUFFER_LOADS=0: clamped 64-bit pointers.
+#ifndef ANH_WS_BUFFER_LOADS
+#define ANH_WS_BUFFER_LOADS 1
+#endif
+        constexpr bool BUFL = ANH_WS_BUFFER_LOADS != 0;
+        constexpr bool P_MASK = !BUFL || KP == SRC_ACT || KP == SRC_ACT2, T_MASK = !BUFL || KT == SRC_ACT || KT == SRC_ACT2;   // bn kinds: relu(shift) is not zero
+        auto buffer_side = [&](const __amdgpu_buffer_rsrc_t& ra_, const __amdgpu_buffer_rsrc_t& rb_, int off, auto& dst, auto kind_tag) __attribute__((always_inline)) {
+            constexpr int K = decltype(kind_tag)::value;
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ra_, off, 0, 0);
+            dst.a = make_uint4(v[0], v[1], v[2], v[3]);
+            if constexpr (K == SRC_ACT2 || K == SRC_SUM2) {
+                const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(rb_, off, 0, 0);
+                dst.b = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+        };
         auto fetch = [&](Regs& R, int tile_) __attribute__((always_inline)) {
             const int tx = tile_ % tiles_x, ty = (tile_ / tiles_x) % tiles_y, n = tile_ / (tiles_x * tiles_y);
             const int x0 = tx * TW, y0 = ty * TH;
             const bf16* pa = a.patch.a + (size_t)n * p_plane;
             const bf16* pb = KP == SRC_ACT2 ? a.patch.b + (size_t)n * p_plane : nullptr;
             const int yb = STRIDE * y0 + ORIGIN, xb = STRIDE * x0 + ORIGIN;
-            R.pok = 0;
-#pragma unroll
-            for (int jj = 0; jj < NP; ++jj) {
-                const int iy = yb + (pgeo[jj] & 255), ix = xb + (pgeo[jj] >> 8);
-                const int cy = min(max(iy, 0), a.patch.h - 1), cx = min(max(ix, 0), a.patch.w - 1);
-                R.p[jj] = side_load_at<KP>(pa, pb, (cy * a.patch.w + cx) * a.patch.c + cc + c16 * 8);
-                R.pok |= ((iy == cy && ix == cx) ? 1u : 0u) << jj;
-            }
             const bf16* ta = a.tile.a + (size_t)n * t_plane;
             const bf16* tb = KT == SRC_ACT2 ? a.tile.b + (size_t)n * t_plane : nullptr;
-            const int ox = x0 + t_x, cx = min(ox, a.tile.w - 1);
+            R.pok = 0;
             R.tok = 0;
+            if constexpr (BUFL) {
+                const __amdgpu_buffer_rsrc_t rpa = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(pa), 0, (int)(unsigned)(p_plane * 2), 0x00020000);
+                const __amdgpu_buffer_rsrc_t rpb = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(KP == SRC_ACT2 ? pb : pa), 0, (int)(unsigned)(p_plane * 2), 0x00020000);
 #pragma unroll
-            for (int jj = 0; jj < NT_; ++jj) {
-                const int oy = y0 + t_row0 + 2 * (jj % JPN), cy = min(oy, a.tile.h - 1);
-                R.t[jj] = side_load_at<KT>(ta, tb, (cy * a.tile.w + cx) * a.tile.c + tch0 + (jj / JPN) * 32 + c16 * 8);
-                R.tok |= ((oy == cy && ox == cx) ? 1u : 0u) << jj;
+                for (int jj = 0; jj < NP; ++jj) {
+                    const int iy = yb + (pgeo[jj] & 255), ix = xb + (pgeo[jj] >> 8);
+                    const bool ok = (unsigned)iy < (unsigned)a.patch.h && (unsigned)ix < (unsigned)a.patch.w;
+                    buffer_side(rpa, rpb, ok ? ((iy * a.patch.w + ix) * a.patch.c + cc + c16 * 8) * 2 : (int)0xFFFFF000u, R.p[jj], std::integral_constant<int, KP>{});
+                    if constexpr (P_MASK) R.pok |= (ok ? 1u : 0u) << jj;
+                }
+                const __amdgpu_buffer_rsrc_t rta = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(ta), 0, (int)(unsigned)(t_plane * 2), 0x00020000);
+                const __amdgpu_buffer_rsrc_t rtb = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(KT == SRC_ACT2 ? tb : ta), 0, (int)(unsigned)(t_plane * 2), 0x00020000);
+                const int ox = x0 + t_x;
+#pragma unroll
+                for (int jj = 0; jj < NT_; ++jj) {
+                    const int oy = y0 + t_row0 + 2 * (jj % JPN);
+                    const bool ok = oy < a.tile.h && ox < a.tile.w;
+                    buffer_side(rta, rtb, ok ? ((oy * a.tile.w + ox) * a.tile.c + tch0 + (jj / JPN) * 32 + c16 * 8) * 2 : (int)0xFFFFF000u, R.t[jj], std::integral_constant<int, KT>{});
+                    if constexpr (T_MASK) R.tok |= (ok ? 1u : 0u) << jj;
+                }
+            } else {
+#pragma unroll
+                for (int jj = 0; jj < NP; ++jj) {
+                    const int iy = yb + (pgeo[jj] & 255), ix = xb + (pgeo[jj] >> 8);
+                    const int cy = min(max(iy, 0), a.patch.h - 1), cx = min(max(ix, 0), a.patch.w - 1);
+                    R.p[jj] = side_load_at<KP>(pa, pb, (cy * a.patch.w + cx) * a.patch.c + cc + c16 * 8);
+                    R.pok |= ((iy == cy && ix == cx) ? 1u : 0u) << jj;
+                }
+                const int ox = x0 + t_x, cx = min(ox, a.tile.w - 1);
+#pragma unroll
+                for (int jj = 0; jj < NT_; ++jj) {
+                    const int oy = y0 + t_row0 + 2 * (jj % JPN), cy = min(oy, a.tile.h - 1);
+                    R.t[jj] = side_load_at<KT>(ta, tb, (cy * a.tile.w + cx) * a.tile.c + tch0 + (jj / JPN) * 32 + c16 * 8);
+                    R.tok |= ((oy == cy && ox == cx) ? 1u : 0u) << jj;
+                }
             }
         };
         auto commit = [&](const Regs& R, char* lbuf) __attribute__((always_inline)) {
 #pragma unroll
             for (int jj = 0; jj < NP; ++jj) {
                 uint4 v = chunk_convert<KP>(R.p[jj], psa, pta, psb, ptb);
-                if (!((R.pok >> jj) & 1u)) v = make_uint4(0u, 0u, 0u, 0u);
+                if constexpr (P_MASK) { if (!((R.pok >> jj) & 1u)) v = make_uint4(0u, 0u, 0u, 0u); }
                 if ((tid >> 2) + 64 * jj < RECS) *reinterpret_cast<uint4*>(lbuf + pdst[jj]) = v;
             }
 #pragma unroll
             for (int jj = 0; jj < NT_; ++jj) {
                 const float* t0 = tab + (jj / JPN) * 32 + c16 * 8;
                 uint4 v = chunk_convert<KT>(R.t[jj], t0, t0 + NTC * 32, t0 + 2 * NTC * 32, t0 + 3 * NTC * 32);
-                if (!((R.tok >> jj) & 1u)) v = make_uint4(0u, 0u, 0u, 0u);
+                if constexpr (T_MASK) { if (!((R.tok >> jj) & 1u)) v = make_uint4(0u, 0u, 0u, 0u); }
                 *reinterpret_cast<uint4*>(lbuf + tdst0 + ((jj / JPN) * TILE_PIX + 2 * (jj % JPN) * 32) * 64) = v;
             }
         };
@@ -3256,7 +3295,7 @@ bool mfma_wgrad_supported(const WgradArgs& a) {
     if (!s1 && !s2) return false;
     const int c_tile = a.gather == 1 ? a.c_in : a.c_out, c_patch = a.gather == 1 ? a.c_out : a.c_in;
     const int64_t plane_in = (int64_t)a.h_in * a.w_in * a.c_in, plane_out = (int64_t)a.h_out * a.w_out * a.c_out;
-    if (plane_in >= (1ll << 31) || plane_out >= (1ll << 31)) return false;  // the kernel indexes within one image with 32-bit offsets
+    if (plane_in * 2 >= 0xFFFFF000ll || plane_out * 2 >= 0xFFFFF000ll) return false;  // the kernel addresses within one image through a buffer descriptor (32-bit byte offsets; 0xFFFFF000 marks padding)
     static const int ws_on = getenv("ANH_WGRAD_WS") ? atoi(getenv("ANH_WGRAD_WS")) : 1;
     return c_patch % 32 == 0 && (c_tile == 32 || c_tile == 64 || c_tile == 128 || (c_tile == 256 && ws_on));
 }
