@@ -135,6 +135,9 @@ Engine::~Engine() {
     if (stream) (void)hipStreamSynchronize(stream);
     if (early_stream) (void)hipStreamSynchronize(early_stream);
     if (aux_stream) { (void)hipStreamSynchronize(aux_stream); (void)hipStreamDestroy(aux_stream); }
+    if (blend_stream) { (void)hipStreamSynchronize(blend_stream); (void)hipStreamDestroy(blend_stream); }
+    if (ev_logits) (void)hipEventDestroy(ev_logits);
+    for (hipEvent_t e : ev_blend) if (e) (void)hipEventDestroy(e);
     if (ev_dy_ready) (void)hipEventDestroy(ev_dy_ready);
     if (ev_aux_done) (void)hipEventDestroy(ev_aux_done);
     if (ev_early_grads) (void)hipEventDestroy(ev_early_grads);
@@ -153,6 +156,7 @@ void Engine::set_stream(hipStream_t s) {
 void Engine::synchronize() {
     HIP_CHECK(hipStreamSynchronize(stream));
     if (aux_stream) HIP_CHECK(hipStreamSynchronize(aux_stream));
+    if (blend_stream) HIP_CHECK(hipStreamSynchronize(blend_stream));
     if (prof.enabled) prof.collect();
 }
 
@@ -896,6 +900,11 @@ void Engine::infer_tiles(const anh_tile* ts, int count, const uint8_t* d_image, 
     hb.src = layer_source((int)spec.layers.size() - 1, image); hb.c_in = head.cin; hb.k = head.cout;
     const bool fuse_head = !training && head.k == 1 && head.has_bias && head.in_a >= 0 && head_blend_supported(hb);
     bool head_epi = false;   // the head rides in the epilogue of the last hidden layer's conv: its logits, not its activation, go to memory
+    // asynchronous blends (infer_device): this batch's logits go to the buffer of its parity; the blends of the batch before the last
+    // one, which read that buffer on the blend stream, must be done before this batch's net writes it
+    const bool async = async_batch >= 0 && blend_stream != nullptr;
+    DevBuf& tout = (async && (async_batch & 1)) ? tile_out_b : tile_out;
+    if (async && async_batch >= 2) HIP_CHECK(hipStreamWaitEvent(stream, ev_blend[async_batch & 1], 0));
     if (fuse_head) {
         prof.start_pass();
         plan_dims(count, win.height, win.width);
@@ -909,21 +918,29 @@ void Engine::infer_tiles(const anh_tile* ts, int count, const uint8_t* d_image, 
             head_epi = readers == 1 && conv_head_in_epilogue_ok(probe);
         }
         if (head_epi) {
-            tile_out.reserve((size_t)count * K * win.height * win.width * 4);
-            head_epi_layer = hl; head_epi_out = tile_out.as<float>();
+            tout.reserve((size_t)count * K * win.height * win.width * 4);
+            head_epi_layer = hl; head_epi_out = tout.as<float>();
         }
         for (size_t li = 0; li + 1 < spec.layers.size(); ++li) run_conv_forward((int)li, image, false, nullptr);
         head_epi_layer = -1; head_epi_out = nullptr;
     } else {
-        tile_out.reserve((size_t)count * K * win.height * win.width * 4);
-        forward_inference(image, count, win.height, win.width, tile_out.as<float>());
+        tout.reserve((size_t)count * K * win.height * win.width * 4);
+        forward_inference(image, count, win.height, win.width, tout.as<float>());
     }
     const size_t es = elem_size(dtype);
+    // the blends read the logits buffer only (not a layer tensor the next batch's net overwrites) in every form but the fused head + blend kernel
+    const bool blend_async = async && !(fuse_head && !head_epi);
+    hipStream_t bs = stream;
+    if (blend_async) {
+        HIP_CHECK(hipEventRecord(ev_logits, stream));
+        HIP_CHECK(hipStreamWaitEvent(blend_stream, ev_logits, 0));
+        bs = blend_stream;
+    }
     for (int i = 0; i < count; ++i) {
         const anh_tile& t = ts[i];
         const TileWindow wi = tile_window(t, spec.cfg.levels);
         BlendArgs b;
-        b.logits_nchw = (fuse_head && !head_epi) ? nullptr : tile_out.as<float>() + (size_t)i * K * win.height * win.width; b.blended = d_blended;
+        b.logits_nchw = (fuse_head && !head_epi) ? nullptr : tout.as<float>() + (size_t)i * K * win.height * win.width; b.blended = d_blended;
         b.k = K; b.tile_h = wi.height; b.tile_w = wi.width; b.tile_left = wi.left; b.tile_top = wi.top;
         b.img_h = H; b.img_w = W;
         b.full[0] = t.full_rect.left; b.full[1] = t.full_rect.top; b.full[2] = t.full_rect.right; b.full[3] = t.full_rect.bottom;
@@ -941,10 +958,12 @@ void Engine::infer_tiles(const anh_tile* ts, int count, const uint8_t* d_image, 
             prof.end(stream, tok);
             continue;
         }
-        const int tok = prof.begin(stream, "blend_accumulate", 0, (double)K * win.height * win.width * 12);
-        launch_blend(b, stream);
-        prof.end(stream, tok);
+        const int tok = prof.begin(bs, "blend_accumulate", 0, (double)K * win.height * win.width * 12);
+        launch_blend(b, bs);
+        prof.end(bs, tok);
     }
+    // (recorded on the blend stream even when this batch's blends ran on `stream`: the stream is in order, the event then marks the blends before it)
+    if (async) HIP_CHECK(hipEventRecord(ev_blend[async_batch & 1], blend_async ? blend_stream : stream));
 }
 
 // how many tiles with a window of h x w run as one batch: ANH_INFER_TILE_BATCH, or as many (at most kMaxTileBatch) as keep the
@@ -978,6 +997,17 @@ void Engine::infer_device(const uint8_t* d_image, int H, int W, const double* ga
     const int K = spec.cfg.classes;
     const int64_t pixels = (int64_t)H * W;
     prof.start_image();
+    // MEASURED (four same-box rounds, 4096^2: 4,343 -> 4,327 Mpx/s; 16384^2: 4,475 -> 4,461): no gain — the persistent conv kernels hold
+    // every CU, the blend workgroups run between them as before.  Off by default, kept as a tested form (labels and planes bit-identical).
+    static const int async_env = getenv("ANH_INFER_ASYNC_BLEND") ? atoi(getenv("ANH_INFER_ASYNC_BLEND")) : 0;
+    const bool async = async_env != 0 && !training;
+    if (async && !blend_stream) {
+        HIP_CHECK(hipStreamCreateWithFlags(&blend_stream, hipStreamNonBlocking));
+        HIP_CHECK(hipEventCreateWithFlags(&ev_logits, hipEventDisableTiming));
+        for (hipEvent_t& e : ev_blend) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    int n_async = 0;
+    struct Reset { int& v; ~Reset() { v = -1; } } reset{async_batch};   // (also when a launch throws)
     launch_fill_zero(d_blended, (size_t)K * pixels * 4, stream);
     // consecutive tiles with equal input windows (all of them, on a regular tiling) run as batches
     // — as FEW batches as the cap allows, of equal size (25 tiles at a cap of 8 used to run as 8 + 8 + 8 + 1: every launch has a fixed
@@ -992,9 +1022,14 @@ void Engine::infer_device(const uint8_t* d_image, int H, int W, const double* ga
             ++run;
         }
         const size_t n_batches = (run + batch - 1) / batch, per = (run + n_batches - 1) / n_batches;
-        for (size_t done = 0; done < run; done += per) infer_tiles(&tiles[i + done], (int)std::min(per, run - done), d_image, H, W, d_blended);
+        for (size_t done = 0; done < run; done += per) {
+            async_batch = async ? n_async++ : -1;
+            infer_tiles(&tiles[i + done], (int)std::min(per, run - done), d_image, H, W, d_blended);
+        }
         i += run;
     }
+    async_batch = -1;
+    if (n_async > 0) HIP_CHECK(hipStreamWaitEvent(stream, ev_blend[(n_async - 1) & 1], 0));   // the planes are complete on `stream` from here on
     if (d_labels) argmax_rows(d_blended, H, W, 0, H, gains_host, d_labels);
 }
 
