@@ -408,7 +408,7 @@ __device__ __forceinline__ void pack_pixel_tiles_act(const f32x16 (&acc)[NT], co
 // head_blend_kernel's four lanes: chunk sums chained over ascending channels from 0, (chunk 0 + chunk 1) + (chunk 2 + chunk 3), + bias.
 // hw[s][j][k] = head weight of channel 16 s + 8 half + j, class k (zero beyond head_k).  Half 0 stores classes 0 and 2, half 1 classes 1 and 3.
 __device__ __forceinline__ void store_pixel_tiles_head(const f32x16& acc, const ConvArgs& a, size_t pix, int n, bool valid, int half, const float* act, int cw,
-                                                       const float (&hw)[2][8][4], const float (&hbias)[4]) {
+                                                       const float (&hw)[2][8][4], const float (&hbias)[4], const float* hwl = nullptr) {
     float v[16];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -430,7 +430,30 @@ __device__ __forceinline__ void store_pixel_tiles_head(const f32x16& acc, const 
 #ifndef ANH_HEAD_PK_FMA
 #define ANH_HEAD_PK_FMA 0
 #endif
-#if ANH_HEAD_PK_FMA
+// (ANH_HEAD_LDS_PK=1, MEASURED: hipcc hoists the 32 loop-invariant table reads out of the tile loop — 256 VGPRs, 6 spilled, as the
+// register form; inference 4,537 / 4,522 / 4,519 / 4,531 -> 4,291 / 4,271 / 4,211 / 4,238 Mpx/s.  Off.)
+#ifndef ANH_HEAD_LDS_PK
+#define ANH_HEAD_LDS_PK 0
+#endif
+#if ANH_HEAD_LDS_PK
+        // The head weights read from an LDS table [channel][4 classes] (one broadcast ds_read_b128 per channel: no VALU, and 64 VGPRs
+        // fewer than the register copy — with the filter fragments in registers the packed form spilled), the FMAs packed by class pairs
+        // (v_pk_fma_f32, the activation broadcast by op_sel): the same chain per class, half the issue slots.
+        {
+            f32x2 s01 = {0.f, 0.f}, s23 = {0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float4 wl = *reinterpret_cast<const float4*>(hwl + (16 * s + 8 * half + 2 * i) * 4);
+                const float4 wh = *reinterpret_cast<const float4*>(hwl + (16 * s + 8 * half + 2 * i + 1) * 4);
+                const float lo = lo_f(w4[i]), hi = hi_f(w4[i]);
+                s01 = __builtin_elementwise_fma(f32x2{lo, lo}, f32x2{wl.x, wl.y}, s01);
+                s23 = __builtin_elementwise_fma(f32x2{lo, lo}, f32x2{wl.z, wl.w}, s23);
+                s01 = __builtin_elementwise_fma(f32x2{hi, hi}, f32x2{wh.x, wh.y}, s01);
+                s23 = __builtin_elementwise_fma(f32x2{hi, hi}, f32x2{wh.z, wh.w}, s23);
+            }
+            part[s][0] = s01[0]; part[s][1] = s01[1]; part[s][2] = s23[0]; part[s][3] = s23[1];
+        }
+#elif ANH_HEAD_PK_FMA
         // two classes per instruction (v_pk_fma_f32; the activation broadcast to both halves): the same chain per class, half the VALU
         // issue slots — on a SIMD they are what this epilogue costs
         typedef f32x2 f32x2_t;
@@ -1623,6 +1646,9 @@ __global__ __launch_bounds__(256 * (TEAMS + 1), (TEAMS == 2 ? 3 : 2)) void conv3
                 bnc[C_OUT + i] = a.out_shift[co_base + i];
             }
         }
+        if constexpr (HEAD) {   // the 1x1 head's weights behind the tables: [channel][4 classes], zero beyond head_k (launch_ws adds the 512 bytes)
+            for (int i = threadIdx.x; i < 32 * 4; i += NTHR) bnc[4 * C_OUT + i] = (i & 3) < a.head_k ? a.head_w[(i >> 2) * a.head_k + (i & 3)] : 0.f;
+        }
         if (fuse_bnred) {
             for (int i = threadIdx.x; i < C_OUT; i += NTHR) {
                 bnc[i] = a.bnred_scale[co_base + i];
@@ -2002,7 +2028,7 @@ __global__ __launch_bounds__(256 * (TEAMS + 1), (TEAMS == 2 ? 3 : 2)) void conv3
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) hw[s2][j][k] = k < a.head_k ? a.head_w[(16 * s2 + 8 * half + j) * a.head_k + k] : 0.f;
+                    for (int j = 0; j < 8; ++j) hw[s2][j][k] = (!ANH_HEAD_LDS_PK && k < a.head_k) ? a.head_w[(16 * s2 + 8 * half + j) * a.head_k + k] : 0.f;
             }
         }
         u32x4 old[FWD ? 1 : G::ACC][NT][2];   // prefetched old values of a read-modify-write destination (GeoUp)
@@ -2088,7 +2114,7 @@ __global__ __launch_bounds__(256 * (TEAMS + 1), (TEAMS == 2 ? 3 : 2)) void conv3
 #endif
                         }
                     }
-                    if constexpr (HEAD) store_pixel_tiles_head(acc[g][0], a, pix, n, valid, half, bnc, C_OUT, hw, hbias);
+                    if constexpr (HEAD) store_pixel_tiles_head(acc[g][0], a, pix, n, valid, half, bnc, C_OUT, hw, hbias, bnc + 4 * C_OUT);
                     else if constexpr (ACT) {
                         bool packed = false;
                         if constexpr (CAN_DEFER) { if (defer) { pack_pixel_tiles_act<NT, DS>(acc[g], a, pix, valid, half, co_base, bnc, C_OUT, dst, g * NT * 2); packed = true; } }
@@ -2452,6 +2478,7 @@ void launch_ws(const ConvArgs& a, int tiles_x, int tiles_y, int flip, hipStream_
     if (a.out_scale) {   // inference: activation-storing epilogue, plain-copy (or skip-add) staging
         ANH_REQUIRE(a.out_shift && !a.stat_partials && !a.bnred_partials && !a.stat_acc && !a.bnred_acc && !a.out_accumulate && !a.out2, "conv_ws: the activation-storing form takes no training epilogue");
         if (a.head_out) {   // the layer under the 1x1 head: logits instead of the activation
+            lds += 512;     // the head's weight table behind the bn tables (kernel: bnc + 4 C_OUT)
             if constexpr (std::is_same<G, GeoS1>::value && NT == 1) {
                 ANH_REQUIRE(conv_head_in_epilogue_ok(a) && a.head_w && a.head_bias, "conv_ws: this layer cannot take the head in its epilogue");
                 if (lay.teams == 2) {
