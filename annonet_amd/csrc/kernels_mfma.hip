@@ -1389,6 +1389,59 @@ struct GeoS1 {
     }
 };
 
+// GeoS1T (round 4): the stride-1 geometry on a 16 x 32 tile — a wave owns FOUR output rows (four accumulator groups), so a filter
+// fragment read from LDS feeds four MFMAs instead of two and six patch rows serve twelve (kx, k-step, ky) uses: 6 + 3 NT LDS reads per
+// 12 NT MFMAs (NT = 2: 12 per 24, GeoS1: 10 per 12), half the hand-over barriers per MFMA, a 1.19 x instead of a 1.33 x patch.  128
+// accumulator registers at NT = 2: the inference forms only (no statistics registers).  LDS: 2 x 39,168-byte patches + 73,728 bytes of
+// resident filter at 64 reduction channels = 153 KB.
+struct GeoS1T {
+    static constexpr int TTH = 16, TPH = TTH + 2;
+    static constexpr int RECS = TPH * PW, ACC = 4;
+    static constexpr bool RMW_PREFETCH = false;
+    __device__ static void decode(int rec, int& py, int& px, int& key) { py = rec / PW; px = rec - py * PW; key = (px >> 2) & 3; }
+    __device__ static int in_y0(int ty) { return ty * TTH - 1; }
+    __device__ static int in_x0(int tx) { return tx * TW - 1; }
+    static constexpr int NB = 3;
+    struct Bases { const char* x[3][2]; };
+    __device__ static void init(Bases& b, const char* lds_x, int wave, int col, int half) {
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) b.x[kx][ks] = swz_addr(lds_x, wave * 4 * PW + col + kx, (col + kx) >> 2, ks, half);
+    }
+    template <int NT, class H = NoHook>
+    __device__ static void mfma(f32x16 (&acc)[ACC][NT], const Bases& b, const char* (&wb)[2], const H& hook = H()) {
+        constexpr int C_OUT = NT * 32;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 xf[6];
+#pragma unroll
+                for (int r = 0; r < 6; ++r) xf[r] = lds_frag(b.x[kx][ks] + r * (PW * 64));
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int tl = ky * 3 + kx;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const bf16x8 wf = lds_frag(wb[ks] + (tl * C_OUT + nt * 32) * 64);
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) acc[g][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf[g + ky], acc[g][nt], 0, 0, 0);
+                    }
+                    hook((kx * 2 + ks) * 3 + ky);
+                }
+            }
+        }
+    }
+    static constexpr bool TS_OK = false;
+    __device__ static void row_origin(int, const ConvArgs&, int, int, int, int, size_t& row_pix0, bool& row_valid, int& cols_valid) { row_pix0 = 0; row_valid = false; cols_valid = 0; }
+    __device__ static void out_pixel(int g, const ConvArgs& a, int n, int ty, int tx, int wave, int col, size_t& pix, bool& valid) {
+        const int oy = ty * TTH + wave * 4 + g, ox = tx * TW + col;
+        valid = oy < a.h_out && ox < a.w_out;
+        pix = ((size_t)n * a.h_out + (valid ? oy : 0)) * a.w_out + (valid ? ox : 0);
+    }
+};
+
 struct GeoDown {
     static constexpr int RECS = 9 * 66, ACC = 1;
     static constexpr bool RMW_PREFETCH = false;
@@ -3293,7 +3346,19 @@ void launch_conv_mfma(const ConvArgs& a, hipStream_t s) {
     ANH_REQUIRE(!a.src.a_tab.acc || conv_folds_bn_tables(a), "conv_mfma: this layer's kernel does not fold bn accumulator tables");
     ANH_REQUIRE(!a.bnred_partials || (conv_fused_bnred_blocks(a) > 0 && !a.stat_partials), "conv_mfma: this layer's kernel does not fuse the bn backward reduction");
     if (p.geo == 0) {
-        if (p.form == 2) { if (p.nt == 1) launch_ws<GeoS1, 1>(a, p.tiles_x, p.tiles_y, p.flip, s); else launch_ws<GeoS1, 2>(a, p.tiles_x, p.tiles_y, p.flip, s); }
+        if (p.form == 2) {
+            // ANH_WS_TALL: the 64-output-channel inference forms on 16 x 32 tiles (GeoS1T) where two tall patches and the filter fit:
+            // 1 = at 128 reduction channels and more, 2 = wherever it fits, 0 = never
+            // MEASURED (five same-box rounds): 4,483 (0) / 4,483 (1) / 4,371 Mpx/s (2: -2.5 %; per image the 128->128 conv 332 -> 313 us,
+            // the 64->64 convs 350 -> 356 and 416 -> 432) — a third fewer LDS reads per MFMA and half the barriers buy nothing.  Off.
+            static const int tall_env = getenv("ANH_WS_TALL") ? atoi(getenv("ANH_WS_TALL")) : 0;
+            const size_t tall_x = (size_t)GeoS1T::RECS * 64, tall_w = (size_t)9 * 64 * 64, tall_tab = (size_t)a.c_red * 16 + 2 * 32 * 16;
+            const size_t n_sl = (size_t)(a.c_red >> 5);
+            const bool tall_fits = 2 * tall_x + n_sl * tall_w + tall_tab <= 160 * 1024 || 2 * (tall_x + tall_w) + tall_tab <= 160 * 1024;
+            if (p.nt == 1) launch_ws<GeoS1, 1>(a, p.tiles_x, p.tiles_y, p.flip, s);
+            else if (tall_env && (tall_env == 2 || a.c_red >= 128) && a.out_scale && !a.head_out && tall_fits && (a.src.kind == SRC_RAW || a.src.kind == SRC_SUM2)) launch_ws<GeoS1T, 2>(a, p.tiles_x, (a.h_out + GeoS1T::TTH - 1) / GeoS1T::TTH, p.flip, s);
+            else launch_ws<GeoS1, 2>(a, p.tiles_x, p.tiles_y, p.flip, s);
+        }
         else if (a.c_out == 32) launch_s1<1, 9>(a, s);
         else launch_s1<2, 9>(a, s);
     } else if (p.geo == 1) {
