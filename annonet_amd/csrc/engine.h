@@ -45,6 +45,7 @@ class Profiler {
 struct LayerState {
     DevBuf raw;    // raw conv output y (storage dtype), [n][h][w][cout]
     DevBuf dact;   // gradient w.r.t. this layer's post-activation output; becomes dy in place on the unfused path
+    DevBuf act_in; bool act_in_valid = false;   // ANH_ACT_MATERIALIZE: this layer's activated input as its forward conv staged it (ConvArgs::act_out); its filter gradient reads it plain
     DevBuf bn;     // mean, invstd, scale, shift (4*C floats) then var (C doubles)
     float* mean = nullptr; float* invstd = nullptr; float* scale = nullptr; float* shift = nullptr; double* var = nullptr;
     float* coef = nullptr;  // bn backward coefficients [3][C] of this layer (its own slot: two streams read them)

@@ -1305,6 +1305,8 @@ struct GeoS1 {
     __device__ static void decode(int rec, int& py, int& px, int& key) { py = rec / PW; px = rec - py * PW; key = (px >> 2) & 3; }
     __device__ static int in_y0(int ty) { return ty * TH - 1; }
     __device__ static int in_x0(int tx) { return tx * TW - 1; }
+    static constexpr bool CAN_MATERIALIZE = true;   // every input pixel is the interior of exactly one tile's patch
+    __device__ static bool interior(int py, int px) { return py >= 1 && py <= TH && px >= 1 && px <= TW; }
     static constexpr int NB = 3;  // one lane base per kx
     struct Bases { const char* x[3][2]; };
     __device__ static void init(Bases& b, const char* lds_x, int wave, int col, int half) {
@@ -1401,6 +1403,8 @@ struct GeoS1T {
     __device__ static void decode(int rec, int& py, int& px, int& key) { py = rec / PW; px = rec - py * PW; key = (px >> 2) & 3; }
     __device__ static int in_y0(int ty) { return ty * TTH - 1; }
     __device__ static int in_x0(int tx) { return tx * TW - 1; }
+    static constexpr bool CAN_MATERIALIZE = false;
+    __device__ static bool interior(int, int) { return false; }
     static constexpr int NB = 3;
     struct Bases { const char* x[3][2]; };
     __device__ static void init(Bases& b, const char* lds_x, int wave, int col, int half) {
@@ -1450,6 +1454,8 @@ struct GeoDown {
         const int rem = rec - py * 66, par = rem >= 33, u = rem - 33 * par;
         px = 2 * u + par; key = (u >> 2) & 3;
     }
+    static constexpr bool CAN_MATERIALIZE = false;
+    __device__ static bool interior(int, int) { return false; }
     __device__ static int in_y0(int ty) { return ty * 8; }
     __device__ static int in_x0(int tx) { return tx * 64; }
     static constexpr int NB = 2;
@@ -1496,6 +1502,8 @@ struct GeoUp {
     static constexpr int RECS = 5 * 33, ACC = 4;
     static constexpr bool RMW_PREFETCH = true;   // the skip-gradient accumulation of this net lands in stride-2 con backward-data
     __device__ static void decode(int rec, int& py, int& px, int& key) { py = rec / 33; px = rec - py * 33; key = (px >> 2) & 3; }
+    static constexpr bool CAN_MATERIALIZE = false;
+    __device__ static bool interior(int, int) { return false; }
     __device__ static int in_y0(int ty) { return ty * 4 - 1; }
     __device__ static int in_x0(int tx) { return tx * 32 - 1; }
     static constexpr int NB = 2;
@@ -1808,6 +1816,7 @@ __global__ __launch_bounds__(256 * (TEAMS + 1), (TEAMS == 2 ? 3 : 2)) void conv3
         const size_t plane = (size_t)H * W * c_red;  // < 2^31 elements (host check)
         // ---- staging geometry, fixed per thread: patch chunk jj = record (tid >> 2) + 64 jj ----
         int pgeo[NP], pdst[NP];
+        unsigned imask = 0;   // materialised input (ConvArgs::act_out): the chunks of this thread that lie in the tile's interior
     #pragma unroll
         for (int jj = 0; jj < NP; ++jj) {
             const int rec = min((tid >> 2) + 64 * jj, G::RECS - 1);
@@ -1815,6 +1824,7 @@ __global__ __launch_bounds__(256 * (TEAMS + 1), (TEAMS == 2 ? 3 : 2)) void conv3
             G::decode(rec, py, px, key);
             pgeo[jj] = py | (px << 8);
             pdst[jj] = rec * 64 + ((c16 ^ key) << 4);
+            imask |= ((G::interior(py, px) && (tid >> 2) + 64 * jj < G::RECS) ? 1u : 0u) << jj;
         }
         // filter chunk j = record (tid >> 2) + 64 j = (tap slot, co); slot t holds tap t, or 8 - t for mirrored taps
         int wsrc_off[NW], wdst[NW];
@@ -1837,9 +1847,12 @@ __global__ __launch_bounds__(256 * (TEAMS + 1), (TEAMS == 2 ? 3 : 2)) void conv3
     #endif
         constexpr bool DEEP2 = ANH_WS_DEEP2 && !(KIND == SRC_ACT2 && NP > 6);
         u32x4 wraw[NW];  // a native vector type: hipcc keeps a HIP uint4 that is only copied (never unpacked) in scratch
+        // MAT: the training-forward bn kinds of a geometry whose tiles partition the input also store what they stage (ConvArgs::act_out)
+        constexpr bool MAT = ANH_WS_BUFFER_LOADS != 0 && FWD && !ACT && G::CAN_MATERIALIZE && (KIND == SRC_ACT || KIND == SRC_ACT2);
         struct Fetched {
             RawChunk<KIND> praw[NP];
             unsigned pok;
+            int poff[MAT ? NP : 1], n;   // MAT: the chunks' byte offsets within their image, and the image
         };
         Fetched R0, R1;
         // the fetch cursor runs two items ahead of the commits.  Its tile coordinates advance incrementally (no division per item)
@@ -1883,6 +1896,13 @@ __global__ __launch_bounds__(256 * (TEAMS + 1), (TEAMS == 2 ? 3 : 2)) void conv3
             const bf16* pb = (KIND == SRC_ACT2 || KIND == SRC_SUM2) ? xb + (size_t)fn * plane : nullptr;
             const int cc = fslab * 32;
             R.pok = fpok;
+            if constexpr (MAT) {
+                if (a.act_out) {   // (uniform: nothing of this runs in the default schedule)
+                    R.n = fn;
+    #pragma unroll
+                    for (int jj = 0; jj < NP; ++jj) R.poff[jj] = foff[jj];
+                }
+            }
             if constexpr (BUFL) {
                 const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(pa), 0, plane_bytes, 0x00020000);
     #pragma unroll
@@ -1921,6 +1941,9 @@ __global__ __launch_bounds__(256 * (TEAMS + 1), (TEAMS == 2 ? 3 : 2)) void conv3
         auto commit = [&](Fetched& R) __attribute__((always_inline)) {
             char* lbuf = smem + (it & nbuf_mask) * x_stride;
             char* wbuf = lbuf + X_BYTES_;     // streaming form only
+            const bool mat_on = MAT && a.act_out != nullptr && blockIdx.y == 0;   // (one workgroup group stores: the groups stage the same input)
+            const __amdgpu_buffer_rsrc_t mat_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                reinterpret_cast<bf16*>(a.act_out) + (size_t)(MAT ? R.n : 0) * plane, 0, mat_on ? plane_bytes : 0, 0x00020000);
             // a single-slab layer's filter block goes into both buffers once (its registers are not refetched)
             const bool stage_w = !wres && (it < 2 || n_slabs > 1);
             float sa[8], ta[8], sb[8], tb[8];
@@ -1938,6 +1961,10 @@ __global__ __launch_bounds__(256 * (TEAMS + 1), (TEAMS == 2 ? 3 : 2)) void conv3
                 uint4 v = chunk_convert<KIND>(R.praw[jj], sa, ta, sb, tb);
                 if constexpr (NEED_MASK) { if (!((R.pok >> jj) & 1u)) v = make_uint4(0u, 0u, 0u, 0u); }
                 if ((tid >> 2) + 64 * jj < G::RECS) *reinterpret_cast<uint4*>(lbuf + pdst[jj]) = v;
+                if constexpr (MAT) {   // the activated input, once per pixel and channel: interior chunks only (padding offsets are dropped by the descriptor)
+                    if (mat_on && ((imask >> jj) & 1u))
+                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{v.x, v.y, v.z, v.w}, mat_rsrc, R.poff[jj], slab * 64, 0);
+                }
             }
             if (stage_w) {
     #pragma unroll
@@ -3320,6 +3347,19 @@ bool conv_head_in_epilogue_ok(const ConvArgs& a) {
     if (!on || !mfma_conv_supported(a) || stem_mfma_ok(a) || !ws_form_ok(a)) return false;
     return a.k == 3 && a.stride == 1 && a.c_out == 32 && a.out_scale && a.out_dtype == DT_BF16 && a.head_k >= 1 && a.head_k <= 4 &&
            (a.src.kind == SRC_RAW || a.src.kind == SRC_SUM2);
+}
+
+// Will the launch of `a` (every field set as for the launch) store its staged input through ConvArgs::act_out?  The warp-specialised
+// stride-1 forward form with a bn kind on its input (the MAT forms of conv3x3_ws).
+bool conv_materializes_input(const ConvArgs& a) {
+#if defined(ANH_WS_BUFFER_LOADS) && !ANH_WS_BUFFER_LOADS
+    return false;
+#else
+    if (!mfma_conv_supported(a) || stem_mfma_ok(a) || a.k != 3) return false;
+    const ConvPlan p = conv_plan(a);
+    const bool fwd_form = (a.stat_partials || a.stat_acc) && !a.bnred_partials && !a.bnred_acc && !a.out_accumulate && !a.out2 && !a.out_scale;
+    return p.geo == 0 && p.form == 2 && fwd_form && (a.src.kind == SRC_ACT || a.src.kind == SRC_ACT2);
+#endif
 }
 
 int conv_fused_bnred_blocks(const ConvArgs& a) {
