@@ -1848,7 +1848,12 @@ __global__ __launch_bounds__(256 * (TEAMS + 1), (TEAMS == 2 ? 3 : 2)) void conv3
         constexpr bool DEEP2 = ANH_WS_DEEP2 && !(KIND == SRC_ACT2 && NP > 6);
         u32x4 wraw[NW];  // a native vector type: hipcc keeps a HIP uint4 that is only copied (never unpacked) in scratch
         // MAT: the training-forward bn kinds of a geometry whose tiles partition the input also store what they stage (ConvArgs::act_out)
-        constexpr bool MAT = ANH_WS_BUFFER_LOADS != 0 && FWD && !ACT && G::CAN_MATERIALIZE && (KIND == SRC_ACT || KIND == SRC_ACT2);
+        // (compiled out by default, -DANH_ACT_MATERIALIZE_BUILD=1: measured +2.2 % per step when used, and +1.1 % when merely present —
+        // the forward forms' register allocation changes)
+#ifndef ANH_ACT_MATERIALIZE_BUILD
+#define ANH_ACT_MATERIALIZE_BUILD 0
+#endif
+        constexpr bool MAT = ANH_ACT_MATERIALIZE_BUILD != 0 && ANH_WS_BUFFER_LOADS != 0 && FWD && !ACT && G::CAN_MATERIALIZE && (KIND == SRC_ACT || KIND == SRC_ACT2);
         struct Fetched {
             RawChunk<KIND> praw[NP];
             unsigned pok;
@@ -3352,8 +3357,9 @@ bool conv_head_in_epilogue_ok(const ConvArgs& a) {
 // Will the launch of `a` (every field set as for the launch) store its staged input through ConvArgs::act_out?  The warp-specialised
 // stride-1 forward form with a bn kind on its input (the MAT forms of conv3x3_ws).
 bool conv_materializes_input(const ConvArgs& a) {
-#if defined(ANH_WS_BUFFER_LOADS) && !ANH_WS_BUFFER_LOADS
-    return false;
+#if (defined(ANH_WS_BUFFER_LOADS) && !ANH_WS_BUFFER_LOADS) || !defined(ANH_ACT_MATERIALIZE_BUILD) || !ANH_ACT_MATERIALIZE_BUILD
+    (void)a;
+    return false;   // the storing forms are compiled out (see MAT in conv3x3_ws_kernel)
 #else
     if (!mfma_conv_supported(a) || stem_mfma_ok(a) || a.k != 3) return false;
     const ConvPlan p = conv_plan(a);

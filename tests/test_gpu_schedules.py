@@ -47,7 +47,6 @@ def default_run(tmp_path_factory):
     ("backward_data_stores_issued_by_the_consumer_waves", {"ANH_WS_PSTAT": "1"}),     # round 3's form; the default (7) lets the producer waves issue them
     ("backward_data_stores_by_the_producers_for_stride_1_and_down_only", {"ANH_WS_PSTAT": "8"}),
     ("filter_fragments_of_the_32_channel_conv_read_from_lds_every_item", {"ANH_WS_FILTER_REGS": "0"}),
-    ("filter_gradients_read_the_activated_input_their_forward_conv_stored", {"ANH_ACT_MATERIALIZE": "1"}),
 ])
 def test_schedule_is_bit_identical(tmp_path, default_run, name, env):
     got = run_variant(tmp_path, name, env)
