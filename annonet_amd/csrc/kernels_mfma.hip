@@ -1037,7 +1037,7 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_mfma_kernel(WgParams a, int t
 // per tile.  128 tile channels (NTC = 4) at stride 1 use 4x32 pixel tiles so that two buffers fit in LDS.
 // ---------------------------------------------------------------------------------------------------------------
 template <int NTC, int KP, int KT, int STRIDE, bool TRANS>
-__global__ __launch_bounds__(512, 2) void wgrad3x3_ws_kernel(WgParams a, int tiles_x, int tiles_y, int total_tiles, int splits) {
+__global__ __launch_bounds__(512, 2) void wgrad3x3_ws_kernel(WgParams a, int tiles_x, int tiles_y, int total_tiles_all, int splits_all) {
     constexpr int TH = STRIDE == 1 ? (NTC == 4 ? 4 : 8) : 4, TW = 32, TILE_PIX = TH * TW, KS = TILE_PIX / 16;
     constexpr int RECS = STRIDE == 1 ? (TH + 2) * 34 : 9 * 66, ORIGIN = STRIDE == 1 ? -1 : 0;
     constexpr int P_ITEMS = RECS * 4, NP = (P_ITEMS + 255) / 256;   // patch chunks per producer thread
@@ -1064,7 +1064,15 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_ws_kernel(WgParams a, int til
     }
     __syncthreads();
 
-    int tile = split, it = 0;
+    // XCD bands (splits_all bit 30; ANH_WGRAD_XCD_BANDS): as conv3x3_ws — the workgroups of one XCD (split & 7: gridDim.x is a multiple of
+    // 8, so every slab / channel group of a split sits on that XCD too) walk one contiguous eighth of the tile list together, so the halo
+    // rows and columns neighbouring patches share are re-read from that XCD's L2.  Which tiles a split sums changes with it (fp32 partials
+    // in another — still fixed — order).
+    const int wbands = (splits_all >> 30) & 1, n_splits = splits_all & 0x3fffffff;
+    const int band_len = (total_tiles_all + 7) >> 3;
+    const int splits = wbands ? n_splits >> 3 : n_splits;                                                  // this split's step through the list
+    const int total_tiles = wbands ? min(total_tiles_all, ((split & 7) + 1) * band_len) : total_tiles_all;   // ... and its end
+    int tile = wbands ? (split & 7) * band_len + (split >> 3) : split, it = 0;
     if (producer) {
         // per-channel bn constants of the patch side: this thread's 8 channels, in registers
         float psa[8], pta[8], psb[8], ptb[8];
@@ -2878,7 +2886,10 @@ void launch_wg(const WgParams& prm, const WgPlan& p, hipStream_t s) {
     if (p.ws) {
         auto launch = [&](auto kernel) {
             ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), p.lds);
-            hipLaunchKernelGGL(kernel, dim3(p.splits, p.slabs, p.zgroups), dim3(512), p.lds, s, prm, p.tiles_x, p.tiles_y, p.total, p.splits);
+            // MEASURED (13 same-box rounds in two calls): 1.7314 -> 1.7217 and 1.7026 -> 1.6960 ms per step (-0.4 ... -0.6 %).  Default 1.
+            static const int wbands_env = getenv("ANH_WGRAD_XCD_BANDS") ? atoi(getenv("ANH_WGRAD_XCD_BANDS")) : 1;
+            const int wbands = wbands_env && p.splits % 8 == 0 && p.splits >= 8 ? 1 : 0;
+            hipLaunchKernelGGL(kernel, dim3(p.splits, p.slabs, p.zgroups), dim3(512), p.lds, s, prm, p.tiles_x, p.tiles_y, p.total, p.splits | (wbands << 30));
         };
         constexpr bool can_be_cont = STRIDE == 2 && KP == SRC_RAW;   // cont: the patch is dy (raw), its channels are the output channels
         if constexpr (can_be_cont) {

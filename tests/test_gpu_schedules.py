@@ -63,6 +63,8 @@ def test_schedule_is_bit_identical(tmp_path, default_run, name, env):
     ("bn_backward_sums_split_between_the_roles_every_geometry_that_can", {"ANH_WS_PSTAT": "4"}),
     ("conv_tiles_walked_with_the_grid_stride", {"ANH_WS_XCD_BANDS": "0"}),
     ("conv_roles_meet_after_every_second_item", {"ANH_WS_IPB": "2"}),
+    ("filter_gradient_tiles_walked_in_xcd_bands", {"ANH_WGRAD_XCD_BANDS": "1"}),
+    ("filter_gradient_tiles_walked_with_the_grid_stride", {"ANH_WGRAD_XCD_BANDS": "0"}),
     ("one_consumer_team_in_every_conv", {"ANH_WS_TEAMS": "0"}),
     ("two_consumer_teams_take_turns_where_the_form_exists", {"ANH_WS_TEAMS": "1"}),
     ("bn_backward_y_operands_staged_through_lds_by_the_producer_waves", {"ANH_WS_PSTAT": "5"}),
