@@ -153,6 +153,7 @@ _SIGNATURES = {  # ConvDesc / OpInput are defined above
     "anh_runtime_stores_activations": (C.c_int, [_P, C.POINTER(C.c_int)]),
     "anh_trainer_early_grads": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "anh_trainer_wait_early_grads": (C.c_int, [_P, _P]),
+    "anh_trainer_step_graph_stats": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "anh_trainer_synchronize": (C.c_int, [_P]),
     "anh_trainer_layer_tensor": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int64, C.POINTER(C.c_int)]),
     "anh_profile_enable": (C.c_int, [_P, C.c_int, C.c_int]),

@@ -41,7 +41,40 @@ struct BlobHeader {
 };
 }  // namespace
 
-namespace anh { void set_last_error(const std::string& message) { g_error = message; } }
+namespace anh {
+void set_last_error(const std::string& message) { g_error = message; }
+
+int replica_timeout_seconds() {
+    static const int s = getenv("ANH_REPLICA_TIMEOUT_S") && atoi(getenv("ANH_REPLICA_TIMEOUT_S")) > 0 ? atoi(getenv("ANH_REPLICA_TIMEOUT_S")) : 180;
+    return s;
+}
+namespace {
+template <class Query>
+void poll_until_done(Query&& query, const char* what) {
+    hipError_t e = query();
+    if (e == hipSuccess) return;   // the common case (the staging set of step k - 2): no clock read
+    const auto t0 = std::chrono::steady_clock::now();
+    const auto deadline = t0 + std::chrono::seconds(replica_timeout_seconds());
+    for (int spins = 0; e == hipErrorNotReady; ++spins) {
+        if (spins < 2000) std::this_thread::yield();
+        else std::this_thread::sleep_for(std::chrono::microseconds(50));
+        if ((spins & 63) == 63 && std::chrono::steady_clock::now() > deadline)
+            fail(ANH_ERR_DEVICE, std::string(what) + ": the device did not finish within " + std::to_string(replica_timeout_seconds()) +
+                                     " s (ANH_REPLICA_TIMEOUT_S) — a collective between the replicas of this handle did not complete");
+        e = query();
+    }
+    HIP_CHECK(e);
+}
+}  // namespace
+void wait_event(hipEvent_t ev, bool bounded) {
+    if (!bounded) { HIP_CHECK(hipEventSynchronize(ev)); return; }
+    poll_until_done([&] { return hipEventQuery(ev); }, "wait for an event");
+}
+void wait_stream(hipStream_t st, bool bounded) {
+    if (!bounded) { HIP_CHECK(hipStreamSynchronize(st)); return; }
+    poll_until_done([&] { return hipStreamQuery(st); }, "wait for a stream");
+}
+}  // namespace anh
 
 // ANH_REPLICA_WORKERS=0: round 3's form (threads created and joined on every call) for the before / after figure of DESIGN.md §6
 static bool persistent_workers() { static const bool on = !(getenv("ANH_REPLICA_WORKERS") && atoi(getenv("ANH_REPLICA_WORKERS")) == 0); return on; }
@@ -68,6 +101,7 @@ struct anh_runtime {
         { DeviceScope scope(device_of(0)); eng = std::make_unique<Engine>(cfg, false); }
         for (size_t r = 1; r < devices.size(); ++r) { DeviceScope scope(devices[r]); extra.push_back(Replica{std::make_unique<Engine>(cfg, false)}); }
         if (devices.size() > 1) { coll = std::make_unique<Collective>(devices); workers = std::make_unique<ReplicaWorkers>(devices); }
+        for (size_t r = 0; r < replicas(); ++r) replica(r).bounded_waits = replicas() > 1;   // host waits with a deadline (common.h)
         exchange.resize(replicas());
     }
     void set_params_all(const float* params, const float* running) {
@@ -187,6 +221,7 @@ struct anh_trainer {
             }
             if (replicas() > 1 && !coll) coll = std::make_unique<Collective>(devices);
             if (replicas() > 1 && !workers) workers = std::make_unique<ReplicaWorkers>(devices);
+            for (size_t r = 0; r < replicas(); ++r) replica(r).bounded_waits = replicas() > 1;   // host waits with a deadline (common.h)
             dirty = false;
         }
         if (resume_pending) {   // the reference names the file BEFORE SetClassCount (annonet_train_main.cpp:400-405): resume on first use
@@ -903,11 +938,11 @@ anh_trainer::StageSet& stage_and_run(anh_trainer* h, Engine& e, anh_trainer::Sta
     }
     if (st.in_flight) {   // the pinned block is free again once the upload of step k-2 is done: the one place a call blocks on the GPU
         const auto w0 = std::chrono::steady_clock::now();
-        HIP_CHECK(hipEventSynchronize(st.uploaded));
+        wait_event(st.uploaded, h->replicas() > 1);
         st.wait_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - w0).count();
     } else st.wait_us = 0;
     if (total > st.pinned_bytes) {
-        if (st.in_flight) HIP_CHECK(hipEventSynchronize(st.consumed));
+        if (st.in_flight) wait_event(st.consumed, h->replicas() > 1);
         if (st.pinned) HIP_CHECK(hipHostFree(st.pinned));
         st.pinned = nullptr; st.pinned_bytes = 0;
         HIP_CHECK(hipHostMalloc(&st.pinned, total, hipHostMallocDefault));
@@ -1045,7 +1080,7 @@ int anh_trainer_exchange_stats(anh_trainer* h, anh_exchange_stats* out) {
         out->allreduce_tail_us_last = xs.tail_us_last;
         out->allreduce_head_us_last = xs.head_us_last;
         out->early_reduce = xs.split ? 1 : 0;
-        out->uses_rccl = h->coll && h->coll->uses_rccl() ? 1 : 0;
+        out->uses_rccl = h->coll ? h->coll->transport() : 0;
         out->rccl_version = Collective::rccl_version();
         out->worker_calls = h->workers ? (int64_t)(h->workers->calls() - xs.worker_calls_base) : 0;
         out->bucket_bytes = h->eng ? ((int64_t)h->eng->spec.n_params + 1) * 4 : 0;
@@ -1220,6 +1255,13 @@ int anh_trainer_early_grads(anh_trainer* h, int64_t* first) {
         *first = h->replicas() > 1 ? (int64_t)e.spec.n_params + 1 : e.early_grad_first();   // (several replicas: the library reduces the buckets itself)
     });
 }
+int anh_trainer_step_graph_stats(anh_trainer* h, int64_t* captures, int64_t* launches) {
+    return guarded([&] {
+        ANH_REQUIRE(h && captures && launches, "null argument");
+        Engine& e = h->engine();
+        *captures = (int64_t)e.step_graph_captures; *launches = (int64_t)e.step_graph_launches;
+    });
+}
 int anh_trainer_wait_early_grads(anh_trainer* h, void* hip_stream) {
     return guarded([&] {
         ANH_REQUIRE(h && hip_stream, "null argument");
@@ -1387,7 +1429,7 @@ int anh_trainer_step_crops(anh_trainer* h, anh_dataset* d, const anh_crop_spec* 
             HIP_CHECK(hipEventCreateWithFlags(&st.consumed, hipEventDisableTiming));
         }
         if (total > st.dev.bytes) {
-            if (st.in_flight) HIP_CHECK(hipEventSynchronize(st.consumed));
+            if (st.in_flight) wait_event(st.consumed, h->replicas() > 1);
             st.dev.reserve(total);
         }
         // the crops of step k are cut on the dataset's stream while the trainer's stream still runs step k-1

@@ -32,6 +32,15 @@ inline void hip_check(hipError_t e, const char* what, const char* file, int line
 }
 #define HIP_CHECK(expr) ::anh::hip_check((expr), #expr, __FILE__, __LINE__)
 
+// Host-side waits of a handle that drives SEVERAL devices are bounded (host B of DESIGN.md §6): a collective that never completes —
+// a replica that did not join, a failed link — would otherwise leave StartTraining / synchronize blocked for ever, where the
+// one-process-per-GPU host has torch.distributed's collective timeout.  Deadline: ANH_REPLICA_TIMEOUT_S (default 180 s); a wait that
+// passes it throws ANH_ERR_DEVICE, which the C++ shim rethrows and the reference's mains turn into a positive exit code
+// (annonet_train_main.cpp:616-620,640-644).  bounded = false is the plain blocking call (single-device handles: no collective).
+int replica_timeout_seconds();                       // api.cpp
+void wait_event(hipEvent_t e, bool bounded);         // api.cpp
+void wait_stream(hipStream_t s, bool bounded);       // api.cpp
+
 // RAII device buffer (grow-only scratch)
 struct DevBuf {
     void* p = nullptr;

@@ -135,7 +135,13 @@ class Engine {
     void infer_device(const uint8_t* d_image, int H, int W, const double* gains_host, const std::vector<anh_tile>& tiles,
                       uint16_t* d_labels, float* d_blended);
 
+    // ANH_STEP_GRAPH=1: the backward pass behind the head replayed as a captured HIP graph (Engine::backward)
+    struct StepGraph { uint64_t key; int eager_runs; hipGraphExec_t exec; };
+    std::vector<StepGraph> step_graphs;
+    long step_graph_captures = 0, step_graph_launches = 0;
+    static bool step_graph_enabled();
     void synchronize();
+    bool bounded_waits = false;   // one of several replicas behind a handle: host waits take the deadline of common.h (wait_stream)
     void set_stream(hipStream_t s);
 
     // scratch exposed to the C ABI layer (host-pointer entry points stage through these)

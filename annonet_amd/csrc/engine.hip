@@ -136,6 +136,7 @@ Engine::~Engine() {
     if (early_stream) (void)hipStreamSynchronize(early_stream);
     if (aux_stream) { (void)hipStreamSynchronize(aux_stream); (void)hipStreamDestroy(aux_stream); }
     if (blend_stream) { (void)hipStreamSynchronize(blend_stream); (void)hipStreamDestroy(blend_stream); }
+    for (StepGraph& c : step_graphs) if (c.exec) (void)hipGraphExecDestroy(c.exec);
     if (ev_logits) (void)hipEventDestroy(ev_logits);
     for (hipEvent_t e : ev_blend) if (e) (void)hipEventDestroy(e);
     if (ev_dy_ready) (void)hipEventDestroy(ev_dy_ready);
@@ -154,9 +155,10 @@ void Engine::set_stream(hipStream_t s) {
 }
 
 void Engine::synchronize() {
-    HIP_CHECK(hipStreamSynchronize(stream));
-    if (aux_stream) HIP_CHECK(hipStreamSynchronize(aux_stream));
-    if (blend_stream) HIP_CHECK(hipStreamSynchronize(blend_stream));
+    const bool bounded = bounded_waits;
+    wait_stream(stream, bounded);
+    if (aux_stream) wait_stream(aux_stream, bounded);
+    if (blend_stream) wait_stream(blend_stream, bounded);
     if (prof.enabled) prof.collect();
 }
 
@@ -577,6 +579,7 @@ int64_t Engine::early_grad_first() const {
     // parameters are laid out in layer order, so "layers >= kEarlyLayer" is a suffix of the bucket; a net too shallow to have an
     // early part reports none
     if (!training || (int)spec.layers.size() <= kEarlyLayer + 1 || spec.layers[kEarlyLayer].in_a < 0) return spec.n_params + 1;
+    if (step_graph_enabled()) return spec.n_params + 1;   // (an event recorded inside a captured graph cannot gate a stream outside it: one all-reduce)
     return spec.layers[kEarlyLayer].w_off;
 }
 
@@ -685,6 +688,7 @@ void Engine::backward(const uint16_t* d_labels, const float* d_weights, double l
         launch_loss(a, stream);
         prof.end(stream, tok);
     }
+    auto run_layers = [&]() {   // everything behind the head: per layer bn backward, filter gradient (second stream), backward-data conv; the join
     for (int i = 0; i < nl; ++i) { ls[i].consumers = 0; ls[i].da_writes = 0; ls[i].fused_bwd_blocks = 0; }
     for (int i = 0; i < nl; ++i) {
         if (spec.layers[i].in_a >= 0) ++ls[spec.layers[i].in_a].consumers;
@@ -826,6 +830,46 @@ void Engine::backward(const uint16_t* d_labels, const float* d_weights, double l
         HIP_CHECK(hipEventRecord(ev_aux_done, aux_stream));
         HIP_CHECK(hipStreamWaitEvent(stream, ev_aux_done, 0));
     }
+    };
+    // ---- ANH_STEP_GRAPH=1 (round 5): the ~36 launches behind the head — both streams, the eight dy hand-overs and
+    // the join as graph edges — replayed as ONE hipGraphLaunch.  Nothing in them changes from step to step (the per-step values: the fold
+    // jobs' averaging factors ride in the head kernel, lr / loss tag / loss slot in the update kernel; both stay ordinary launches), so an
+    // instantiated graph is valid as long as the shapes, the buffers and the input image pointer (the stem's filter gradient reads it) are
+    // the same: they are the cache key.  A key runs eagerly twice (allocations, LDS attributes) before it is captured. ----
+    if (!step_graph_enabled() || prof.enabled) { run_layers(); return; }
+    uint64_t key = 1469598103934665603ull;
+    auto mix = [&key](uint64_t v) { key = (key ^ v) * 1099511628211ull; };
+    mix((uint64_t)last_n); mix((uint64_t)last_h); mix((uint64_t)last_w); mix((uint64_t)(uintptr_t)last_image.img); mix((uint64_t)last_image.img_sample_stride);
+    mix((uint64_t)last_image.img_left); mix((uint64_t)last_image.img_top); mix((uint64_t)last_image.img_h); mix((uint64_t)last_image.img_w); mix((uint64_t)last_image.img_nwin);
+    for (const LayerState& s : ls) { mix((uint64_t)(uintptr_t)s.raw.p); mix((uint64_t)(uintptr_t)s.dact.p); mix((uint64_t)(uintptr_t)s.bwd_partials.p); }
+    mix((uint64_t)(uintptr_t)dlogits.p); mix((uint64_t)(uintptr_t)wgrad_partials.p); mix((uint64_t)(uintptr_t)wgrad_partials_main.p); mix((uint64_t)(uintptr_t)bn_partials.p);
+    mix((uint64_t)(uintptr_t)stream); mix((uint64_t)(uintptr_t)aux_stream); mix((uint64_t)tables); mix((uint64_t)concurrent_wgrad); mix((uint64_t)head_da_virtual); mix((uint64_t)head_bnred_blocks_);
+    StepGraph* g = nullptr;
+    for (StepGraph& c : step_graphs) if (c.key == key) g = &c;
+    if (!g) {
+        if (step_graphs.size() >= 4) { for (StepGraph& c : step_graphs) if (c.exec) (void)hipGraphExecDestroy(c.exec); step_graphs.clear(); }
+        step_graphs.push_back(StepGraph{key, 0, nullptr});
+        g = &step_graphs.back();
+    }
+    if (!g->exec && g->eager_runs < 2) { ++g->eager_runs; run_layers(); return; }
+    if (!g->exec) {
+        hipGraph_t graph = nullptr;
+        HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeRelaxed));
+        try { run_layers(); }
+        catch (...) { (void)hipStreamEndCapture(stream, &graph); if (graph) (void)hipGraphDestroy(graph); throw; }
+        HIP_CHECK(hipStreamEndCapture(stream, &graph));
+        const hipError_t e = hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        HIP_CHECK(e);
+        ++step_graph_captures;
+    }
+    HIP_CHECK(hipGraphLaunch(g->exec, stream));
+    ++step_graph_launches;
+}
+
+bool Engine::step_graph_enabled() {
+    static const bool on = getenv("ANH_STEP_GRAPH") && atoi(getenv("ANH_STEP_GRAPH")) != 0;
+    return on;
 }
 
 void Engine::apply_update(double lr, double weight_decay, double momentum_coef, double grad_scale, unsigned long bn_window_arg, unsigned long long* loss_post, unsigned int loss_tag) {

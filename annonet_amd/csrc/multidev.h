@@ -7,7 +7,13 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <unistd.h>
+
+#include <atomic>
+#include <chrono>
 #include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
 #include <exception>
 #include <functional>
 #include <memory>
@@ -53,6 +59,7 @@ class Collective {
     ~Collective();
     void all_reduce_sum(const std::vector<float*>& bufs, size_t count, const std::vector<hipStream_t>& streams);
     bool uses_rccl() const { return !comms_.empty(); }
+    int transport() const { return uses_rccl() ? 1 : peer_copies_ ? 2 : 0; }   // 0 repeated-device rehearsal, 1 RCCL, 2 peer copies between distinct devices
     static int rccl_version();   // ncclGetVersion (e.g. 22203), 0 if the call fails
     int world() const { return (int)devices_.size(); }
 
@@ -62,6 +69,7 @@ class Collective {
     std::vector<hipEvent_t> ready_;
     hipEvent_t done_ = nullptr;
     DevBuf scratch_;
+    bool peer_copies_ = false;
 };
 
 // gather / scatter of plane pixels inside a list of rectangles: packed[k][offset_j + (y - top_j) * w_j + (x - left_j)] <-> planes[k][y][x]
@@ -98,12 +106,19 @@ class ReplicaWorkers {
     ReplicaWorkers(const ReplicaWorkers&) = delete;
     ReplicaWorkers& operator=(const ReplicaWorkers&) = delete;
     size_t replicas() const { return devices_.size(); }
-    uint64_t calls() const { return calls_; }   // (tests: the pool was used, and how often)
+    uint64_t calls() const { return calls_.load(std::memory_order_relaxed); }   // (tests: the pool was used, and how often)
 
+    // One call at a time per pool: `call_mu_` is held for the whole call, so a second host thread on the same handle (or a nested
+    // each_replica) waits instead of overwriting job_ / pending_ — the contract stays "one thread per handle" (annonet_hip.h), this only
+    // makes a violation safe.  The wait for the stragglers has a DEADLINE (ANH_REPLICA_TIMEOUT_S, default 180 s — the collective
+    // timeout of the one-process-per-GPU host, bench.py --collective-timeout): a worker that never comes back is a replica stuck in
+    // a HIP / RCCL call; its job references this frame, so the call cannot unwind — the process ends with a message and exit code 3
+    // (positive, as find_max_mini-batch_size.cmd:49-53 expects of a failure that is not a crash).
     template <class F>
     void run(F&& fn) {
         const size_t R = devices_.size();
         if (R <= 1) { if (R == 1) fn((size_t)0); return; }
+        std::lock_guard<std::mutex> one_call(call_mu_);
         std::function<void(size_t)> job = [&fn](size_t r) { fn(r); };
         {
             std::lock_guard<std::mutex> lock(mu_);
@@ -111,17 +126,23 @@ class ReplicaWorkers {
             pending_ = R - 1;
             for (auto& e : failed_) e = nullptr;
             ++generation_;
-            ++calls_;
         }
+        calls_.fetch_add(1, std::memory_order_relaxed);
         go_.notify_all();
         try { fn((size_t)0); } catch (...) { failed_[0] = std::current_exception(); }
         {
             std::unique_lock<std::mutex> lock(mu_);
-            done_.wait(lock, [this] { return pending_ == 0; });
+            if (!done_.wait_for(lock, std::chrono::seconds(replica_timeout_s()), [this] { return pending_ == 0; })) {
+                fprintf(stderr, "annonet_hip: %zu of %zu replica worker(s) did not finish within %d s (ANH_REPLICA_TIMEOUT_S): a replica is stuck "
+                                "in a device or collective call; ending the process\n", pending_, R - 1, replica_timeout_s());
+                fflush(stderr);
+                _exit(3);
+            }
             job_ = nullptr;
         }
         for (const std::exception_ptr& e : failed_) if (e) std::rethrow_exception(e);
     }
+    static int replica_timeout_s() { return replica_timeout_seconds() + 30; }   // (the workers' own device waits are bounded: let them report first)
 
   private:
     void loop(size_t r) {
@@ -145,10 +166,11 @@ class ReplicaWorkers {
     std::vector<int> devices_;
     std::vector<std::exception_ptr> failed_;
     std::vector<std::thread> threads_;
-    std::mutex mu_;
+    std::mutex mu_, call_mu_;
     std::condition_variable go_, done_;
     const std::function<void(size_t)>* job_ = nullptr;
-    uint64_t generation_ = 0, calls_ = 0;
+    uint64_t generation_ = 0;
+    std::atomic<uint64_t> calls_{0};
     size_t pending_ = 0;
     bool stop_ = false;
 };

@@ -1,5 +1,7 @@
 // multidev.hip — see multidev.h.  RCCL is the collective library of the exchange steps; nothing here touches a tensor's values
 // except the three tiny kernels at the bottom (fixed-order add of the rehearsal backend, rectangle gather / scatter).
+#include <string>
+
 #include "multidev.h"
 
 #include <rccl/rccl.h>
@@ -107,11 +109,24 @@ Collective::Collective(const std::vector<int>& devices) : devices_(devices) {
     std::vector<int> sorted = devices;
     std::sort(sorted.begin(), sorted.end());
     const bool distinct = std::adjacent_find(sorted.begin(), sorted.end()) == sorted.end();
-    if (distinct && devices.size() > 1) {
+    // Transport.  Distinct devices take RCCL; if its communicators cannot be created (ncclCommInitAll fails: a driver / IPC problem, a
+    // device another process holds exclusively), or ANH_COLLECTIVE_TRANSPORT=peer asks for it, the SAME process goes on with the
+    // peer-copy transport below (events + hipMemcpyPeerAsync + a fixed-order sum on replica 0) — slower (everything funnels through
+    // one device's links) but a run that comes back with numbers and says which transport made them (anh_exchange_stats::uses_rccl).
+    const char* want = getenv("ANH_COLLECTIVE_TRANSPORT");
+    const bool force_peer = want && std::string(want) == "peer";
+    if (distinct && devices.size() > 1 && !force_peer) {
         std::vector<ncclComm_t> comms(devices.size());
-        NCCL_CHECK(ncclCommInitAll(comms.data(), (int)devices.size(), devices.data()));
-        for (ncclComm_t c : comms) comms_.push_back((void*)c);
-    } else {
+        const ncclResult_t r = ncclCommInitAll(comms.data(), (int)devices.size(), devices.data());
+        if (r == ncclSuccess) for (ncclComm_t c : comms) comms_.push_back((void*)c);
+        else {
+            fprintf(stderr, "annonet_hip: ncclCommInitAll over %zu devices failed (%s); the exchange steps of this handle use peer copies instead\n",
+                    devices.size(), ncclGetErrorString(r));
+            (void)hipGetLastError();
+        }
+    }
+    peer_copies_ = distinct && devices.size() > 1 && comms_.empty();
+    if (comms_.empty()) {
         for (size_t i = 0; i < devices.size(); ++i) {
             DeviceScope scope(devices[i]);
             hipEvent_t e;

@@ -302,6 +302,9 @@ def tile_cells(tiles, width, height):
     return cells
 
 
+_SEGMENTS_CREATED_HERE = set()   # names of the shared-memory segments this process created (HostLabelMap)
+
+
 class HostLabelMap:
     """ONE [H, W] u16 label map in HOST memory shared by every rank of a sharded annonet_infer() (POSIX shared memory; the reference's
     writer threads consume host label maps, annonet_infer_main.cpp:403-419).  Every rank copies the cells of ITS tiles (tile_cells)
@@ -316,10 +319,23 @@ class HostLabelMap:
         self.width, self.height, self.rank = width, height, rank
         nbytes = width * height * 2
         self.creator = name is None
-        self.shm = shared_memory.SharedMemory(create=True, size=nbytes) if self.creator else shared_memory.SharedMemory(name=name)
+        if self.creator:
+            self.shm = shared_memory.SharedMemory(create=True, size=nbytes)
+            _SEGMENTS_CREATED_HERE.add(self.shm.name)
+        else:
+            # An ATTACHING rank must not own the segment's lifetime: before Python 3.13 SharedMemory(name=...) registers it with this
+            # process's resource tracker, which unlinks it (and warns of a leak) when whichever rank exits first — the creator unlinks.
+            try:
+                self.shm = shared_memory.SharedMemory(name=name, track=False)          # Python >= 3.13
+            except TypeError:
+                self.shm = shared_memory.SharedMemory(name=name)
+                if name not in _SEGMENTS_CREATED_HERE:     # (several ranks rehearsed in ONE process share the creator's registration)
+                    from multiprocessing import resource_tracker
+                    resource_tracker.unregister(self.shm._name, "shared_memory")
         self.name = self.shm.name
         self.array = np.ndarray((height, width), dtype=np.uint16, buffer=self.shm.buf)
-        self.ptr = C.addressof(C.c_char.from_buffer(self.shm.buf))
+        self._cbuf = C.c_char.from_buffer(self.shm.buf)      # (an export of the mapping: dropped in close() before the mapping is)
+        self.ptr = C.addressof(self._cbuf)
         owner = tile_owner(len(tiles), world_size)
         cells = tile_cells(tiles, width, height)
         mine = [c for c, o in zip(cells, owner) if o == rank]
@@ -360,11 +376,9 @@ class HostLabelMap:
             from . import _lib
             _lib.lib().anh_host_unregister(self.ptr)
             self.pinned = False
-        self.array = None
-        try:
-            self.shm.close()
-        except BufferError:
-            pass
+        self.array = None       # the numpy view and the ctypes object are this object's only exports of the mapping; a caller that
+        self._cbuf = None       # still holds a view of `.array` keeps it mapped, and close() then says so (BufferError) instead of hiding it
+        self.shm.close()
         if self.creator:
             try:
                 self.shm.unlink()

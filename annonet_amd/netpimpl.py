@@ -555,6 +555,12 @@ class TrainingNet(_Profiled):
         check(self.L.anh_trainer_early_grads(self.h, C.byref(first)))
         return int(first.value)
 
+    def step_graph_stats(self):
+        """(captures, launches) of the captured backward graph (ANH_STEP_GRAPH=1); (0, 0) when off"""
+        c, l = C.c_int64(0), C.c_int64(0)
+        check(self.L.anh_trainer_step_graph_stats(self.h, C.byref(c), C.byref(l)))
+        return int(c.value), int(l.value)
+
     def wait_early_grads(self, stream_ptr):
         """makes the caller's HIP stream wait until the early part of the bucket is final"""
         check(self.L.anh_trainer_wait_early_grads(self.h, stream_ptr))

@@ -676,7 +676,7 @@ def bench_in_process(args):
            "host_note": "host_us: wall time the calling thread spends inside one StartTraining; host_busy_us: the same minus the time it is blocked on the GPU (a staging set is reused every second step: the call waits until the upload of step k-2 has left it) = what the host itself needs (packing 32 x replicas samples into pinned staging, uploads, the step's launches on every replica by persistent worker threads, the collectives, the update): the one-thread reference loop cannot step faster than this",
            "worker_wakeups_per_step": round(st["worker_calls"] / max(st["steps"], 1), 2),
            "exchange": {"allreduce_tail_us": round(st["allreduce_tail_us_mean"], 1), "allreduce_head_us": round(st["allreduce_head_us_mean"], 1), "sampled_steps": st["samples"],
-                        "early_reduce": bool(st["early_reduce"]), "transport": "rccl" if st["uses_rccl"] else "repeated-device rehearsal (fixed-order sum kernel + copies)",
+                        "early_reduce": bool(st["early_reduce"]), "transport": {1: "rccl", 2: "peer copies between distinct devices (RCCL communicators unavailable or ANH_COLLECTIVE_TRANSPORT=peer)"}.get(st["uses_rccl"], "repeated-device rehearsal (fixed-order sum kernel + copies)"),
                         "rccl_version": st["rccl_version"], "bucket_bytes": st["bucket_bytes"],
                         "note": "device time of the all-reduce's two parts on replica 0 (event pairs on every 8th step): tail = bucket[first:] on a side stream while backward still runs, head = bucket[:first] on the main stream"},
            "final_loss": t.get_last_loss()}

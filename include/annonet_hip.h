@@ -95,7 +95,11 @@ int anh_handle_replicas(void* handle, int is_trainer); /* number of replicas (de
  * call (the reference's loop is one thread: /root/reference/annonet_train_main.cpp:583-614 — what it spends inside StartTraining bounds
  * the step rate whatever the GPUs do), and, on every 8th step (ANH_EXCHANGE_SAMPLE), the device time of the all-reduce's two parts on
  * replica 0 (tail = the bulk of the bucket, reduced on a side stream while backward still runs; head = the first layers, on the main
- * stream).  The replicas of a handle are driven by persistent worker threads; worker_calls counts their wake-ups. */
+ * stream).  The replicas of a handle are driven by persistent worker threads; worker_calls counts their wake-ups.
+ * uses_rccl names the transport of the exchange: 1 = RCCL over xGMI; 2 = peer copies between distinct devices (taken by itself, in the
+ * same process, when the RCCL communicators cannot be created, or with ANH_COLLECTIVE_TRANSPORT=peer); 0 = a device list that repeats
+ * a device (rehearsal on fewer GPUs).  One host thread per handle; host-side waits of a handle with several replicas give up after
+ * ANH_REPLICA_TIMEOUT_S seconds (default 180) with ANH_ERR_DEVICE instead of blocking for ever. */
 typedef struct {
     int replicas, early_reduce, uses_rccl, rccl_version;
     int64_t steps, samples, worker_calls, bucket_bytes;
@@ -217,6 +221,11 @@ int anh_trainer_get_stream(anh_trainer* h, void** hip_stream);
  * backward-data convs still run.  wait_early_grads makes `hip_stream` (a stream of the caller's) wait for exactly that point;
  * the elements [0, *first) are final when the handle's own stream has drained.  *first > n_params: no early part. */
 int anh_trainer_early_grads(anh_trainer* h, int64_t* first);
+/* ANH_STEP_GRAPH=1 (off by default): the launches of a training step behind the fused head — bn backward passes, backward-data convs and,
+ * on the second stream, the filter gradients with their hand-over events — are captured once per (shape, buffers, input pointer) and
+ * replayed with one hipGraphLaunch per StartTraining (/root/reference/annonet_train_main.cpp:609).  captures / launches: how often
+ * replica 0 of the handle instantiated / replayed a graph (0 / 0 when the switch is off or the profiler is on). */
+int anh_trainer_step_graph_stats(anh_trainer* h, int64_t* captures, int64_t* launches);
 int anh_trainer_wait_early_grads(anh_trainer* h, void* hip_stream);
 int anh_trainer_synchronize(anh_trainer* h);
 /* debugging / parity taps: raw conv output (which=0) or gradient w.r.t. the layer's activation (which=1), as fp32 NHWC */

@@ -17,7 +17,7 @@ def pytest_configure(config):
 # Collection order (the driver runs the suite with -x): comparisons of the HIP path with the oracle / the golden fixtures run
 # first, the end-to-end tool runs after them, bench.py's line contract last — a failure in a harness test can then never hide a
 # parity test.  Files not named here keep their alphabetical place between the groups.
-_ORDER_FIRST = ["test_golden", "test_gpu_ops", "test_gpu_parity", "test_gpu_crops", "test_gpu_det_seed_order", "test_gpu_sharded_infer",
+_ORDER_FIRST = ["test_golden", "test_gpu_ops", "test_gpu_ops_regime", "test_gpu_parity", "test_gpu_crops", "test_gpu_det_seed_order", "test_gpu_sharded_infer",
                 "test_gpu_multidev", "test_gpu_trainer_state", "test_gpu_schedules", "test_gpu_trained_precision", "test_gpu_convergence",
                 "test_gpu_errors", "test_dnn_envelope", "test_cpp_shim"]
 _ORDER_LAST = ["test_gpu_infer_main", "test_gpu_train_main", "test_gpu_exit_order", "test_gpu_bench_contract"]
