@@ -45,7 +45,6 @@ class Profiler {
 struct LayerState {
     DevBuf raw;    // raw conv output y (storage dtype), [n][h][w][cout]
     DevBuf dact;   // gradient w.r.t. this layer's post-activation output; becomes dy in place on the unfused path
-    DevBuf act_in; bool act_in_valid = false;   // ANH_ACT_MATERIALIZE: this layer's activated input as its forward conv staged it (ConvArgs::act_out); its filter gradient reads it plain
     DevBuf bn;     // mean, invstd, scale, shift (4*C floats) then var (C doubles)
     float* mean = nullptr; float* invstd = nullptr; float* scale = nullptr; float* shift = nullptr; double* var = nullptr;
     float* coef = nullptr;  // bn backward coefficients [3][C] of this layer (its own slot: two streams read them)
@@ -116,13 +115,6 @@ class Engine {
 
     // ---- tiled inference: annonet_infer.cpp:42-214 with image, blended planes and labels resident in HBM ----
     int head_epi_layer = -1; float* head_epi_out = nullptr;   // set around the conv launches of one inference batch (infer_tiles)
-    // A batch's blends (25 launches of 8.5 us per 4096^2 image, 6 % of it) run on a second stream beside the NEXT batch's convs
-    // (infer_device; ANH_INFER_ASYNC_BLEND=1, default 0: measured, no gain): two logits buffers alternate, the blends stay in list order on that one stream
-    // (annonet_infer.cpp:116-164: the additive blended_output sees the same sequence), `stream` waits for the last of them at the end.
-    hipStream_t blend_stream = nullptr;
-    hipEvent_t ev_logits = nullptr, ev_blend[2] = {nullptr, nullptr};
-    DevBuf tile_out_b;
-    int async_batch = -1;   // >= 0 while infer_device launches batch number async_batch with asynchronous blends
     static constexpr int kMaxTileBatch = 16;   // Src::img_win holds 16 windows (4096^2 image, 25 tiles of 1024^2: batches of 8+8+8+1 / 7+6+6+6 / 9+8+8 / 13+12 / 25: 3,838 / 3,865 / 3,917 / 3,960 / 3,938 Mpx/s)
     void infer_tile(const anh_tile& t, const uint8_t* d_image, int H, int W, float* d_blended);
     void infer_tiles(const anh_tile* ts, int count, const uint8_t* d_image, int H, int W, float* d_blended);

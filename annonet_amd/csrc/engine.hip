@@ -95,7 +95,7 @@ Engine::Engine(const anh_net_config& cfg, bool training_) : spec(Spec::build(cfg
         HIP_CHECK(hipMemsetAsync(momentum.p, 0, np * 4, stream));
         HIP_CHECK(hipMemsetAsync(grad.p, 0, (np + 1) * 4, stream));
     }
-    scalars.reserve(256);   // [loss | error flag | ...] in the first 64 bytes; bytes 64..255 stay zero for ever (ConvArgs::zeros)
+    scalars.reserve(256);   // [loss | error flag | ...] in the first 64 bytes; bytes 64..255 stay zero
     HIP_CHECK(hipMemsetAsync(scalars.p, 0, 256, stream));
     loss_dev = scalars.as<double>();
     error_flag = reinterpret_cast<int*>(scalars.as<char>() + 16);
@@ -135,10 +135,7 @@ Engine::~Engine() {
     if (stream) (void)hipStreamSynchronize(stream);
     if (early_stream) (void)hipStreamSynchronize(early_stream);
     if (aux_stream) { (void)hipStreamSynchronize(aux_stream); (void)hipStreamDestroy(aux_stream); }
-    if (blend_stream) { (void)hipStreamSynchronize(blend_stream); (void)hipStreamDestroy(blend_stream); }
     for (StepGraph& c : step_graphs) if (c.exec) (void)hipGraphExecDestroy(c.exec);
-    if (ev_logits) (void)hipEventDestroy(ev_logits);
-    for (hipEvent_t e : ev_blend) if (e) (void)hipEventDestroy(e);
     if (ev_dy_ready) (void)hipEventDestroy(ev_dy_ready);
     if (ev_aux_done) (void)hipEventDestroy(ev_aux_done);
     if (ev_early_grads) (void)hipEventDestroy(ev_early_grads);
@@ -158,7 +155,6 @@ void Engine::synchronize() {
     const bool bounded = bounded_waits;
     wait_stream(stream, bounded);
     if (aux_stream) wait_stream(aux_stream, bounded);
-    if (blend_stream) wait_stream(blend_stream, bounded);
     if (prof.enabled) prof.collect();
 }
 
@@ -443,8 +439,7 @@ void Engine::build_fold_jobs() {
 }
 
 void Engine::conv_dispatch(const ConvArgs& a_in, const char* tag, double flops, double bytes) {
-    ConvArgs a = a_in;
-    a.zeros = scalars.p ? static_cast<const char*>(scalars.p) + 64 : nullptr;   // zeros for ever (Engine::scalars, bytes 64..255): what padding pixels read in the LDS-DMA staging form
+    const ConvArgs& a = a_in;
     const bool fast = conv_takes_mfma(a, dtype);
     // the entry names the kernel family that runs: bf16 MFMA, fp32 MFMA (the parity mode on v_mfma_f32_32x32x2_f32), or the VALU kernels
     std::string name = std::string(fast ? "conv_mfma_bf16:" : conv_f32_mfma_ok(a) ? "conv_mfma_f32:" : (dtype == DT_BF16 ? "conv_generic_bf16:" : "conv_generic_f32:")) + tag;
@@ -506,18 +501,6 @@ void Engine::run_conv_forward(int li, const Src& image, bool training_pass, floa
             bn_partials.reserve((size_t)fused_stat_blocks * 2 * L.cout * sizeof(double));
             a.stat_partials = bn_partials.as<double>();
         }
-    }
-    // ANH_ACT_MATERIALIZE (experiment, round 4): a stride-1 layer's forward conv also stores the activated input it stages (bn + relu
-    // (+ skip add) of the producing layers, bf16), and the layer's filter gradient — which otherwise repeats that conversion in its own
-    // staging waves, on SIMDs it shares with its MFMAs — reads it plain: the same bf16 values, bit-identical gradients.
-    // MEASURED (five same-box rounds): 1.6770 -> 1.7135 ms per step (+2.2 %) — the filter gradients of the four stride-1 layers get 8-18 us
-    // faster and the apply passes beside them 25 us, but the forward convs pay 47 us for the extra stores (32->32: 86 -> 108 us).  Off.
-    static const int mat_env = getenv("ANH_ACT_MATERIALIZE") ? atoi(getenv("ANH_ACT_MATERIALIZE")) : 0;
-    s.act_in_valid = false;
-    if (mat_env && training_pass && dtype == DT_BF16 && L.in_a >= 0 && conv_takes_mfma(a, dtype) && conv_materializes_input(a)) {
-        s.act_in.reserve((size_t)p_in * L.cin * 2);
-        a.act_out = s.act_in.p;
-        s.act_in_valid = true;
     }
     conv_dispatch(a, (std::string("fwd_") + layer_tag(li, L)).c_str(), flops, bytes);
     if (table_layer) {   // no finalize launch: only this step's running-statistics bookkeeping, applied by the fold job
@@ -775,7 +758,6 @@ void Engine::backward(const uint16_t* d_labels, const float* d_weights, double l
         auto run_wgrad = [&]() {   // filter gradient
             WgradArgs g;
             g.src = layer_source(li, last_image);
-            if (s.act_in_valid) { Src m; m.kind = SRC_RAW; m.dtype = DT_BF16; m.a = s.act_in.p; g.src = m; }   // the forward conv left the activated input behind
             g.dy = dy; g.dy_dtype = dy_dt;
             g.n = s.n; g.h_in = s.h_in; g.w_in = s.w_in; g.c_in = L.cin;
             g.h_out = s.h; g.w_out = s.w; g.c_out = L.cout;
@@ -957,11 +939,7 @@ void Engine::infer_tiles(const anh_tile* ts, int count, const uint8_t* d_image, 
     hb.src = layer_source((int)spec.layers.size() - 1, image); hb.c_in = head.cin; hb.k = head.cout;
     const bool fuse_head = !training && head.k == 1 && head.has_bias && head.in_a >= 0 && head_blend_supported(hb);
     bool head_epi = false;   // the head rides in the epilogue of the last hidden layer's conv: its logits, not its activation, go to memory
-    // asynchronous blends (infer_device): this batch's logits go to the buffer of its parity; the blends of the batch before the last
-    // one, which read that buffer on the blend stream, must be done before this batch's net writes it
-    const bool async = async_batch >= 0 && blend_stream != nullptr;
-    DevBuf& tout = (async && (async_batch & 1)) ? tile_out_b : tile_out;
-    if (async && async_batch >= 2) HIP_CHECK(hipStreamWaitEvent(stream, ev_blend[async_batch & 1], 0));
+    DevBuf& tout = tile_out;
     if (fuse_head) {
         prof.start_pass();
         plan_dims(count, win.height, win.width);
@@ -985,14 +963,7 @@ void Engine::infer_tiles(const anh_tile* ts, int count, const uint8_t* d_image, 
         forward_inference(image, count, win.height, win.width, tout.as<float>());
     }
     const size_t es = elem_size(dtype);
-    // the blends read the logits buffer only (not a layer tensor the next batch's net overwrites) in every form but the fused head + blend kernel
-    const bool blend_async = async && !(fuse_head && !head_epi);
-    hipStream_t bs = stream;
-    if (blend_async) {
-        HIP_CHECK(hipEventRecord(ev_logits, stream));
-        HIP_CHECK(hipStreamWaitEvent(blend_stream, ev_logits, 0));
-        bs = blend_stream;
-    }
+    const hipStream_t bs = stream;   // (a batch's blends on a second stream beside the next batch's convs measured no gain in round 4: the persistent conv kernels hold every CU)
     for (int i = 0; i < count; ++i) {
         const anh_tile& t = ts[i];
         const TileWindow wi = tile_window(t, spec.cfg.levels);
@@ -1019,8 +990,6 @@ void Engine::infer_tiles(const anh_tile* ts, int count, const uint8_t* d_image, 
         launch_blend(b, bs);
         prof.end(bs, tok);
     }
-    // (recorded on the blend stream even when this batch's blends ran on `stream`: the stream is in order, the event then marks the blends before it)
-    if (async) HIP_CHECK(hipEventRecord(ev_blend[async_batch & 1], blend_async ? blend_stream : stream));
 }
 
 // how many tiles with a window of h x w run as one batch: ANH_INFER_TILE_BATCH, or as many (at most kMaxTileBatch) as keep the
@@ -1054,17 +1023,6 @@ void Engine::infer_device(const uint8_t* d_image, int H, int W, const double* ga
     const int K = spec.cfg.classes;
     const int64_t pixels = (int64_t)H * W;
     prof.start_image();
-    // MEASURED (four same-box rounds, 4096^2: 4,343 -> 4,327 Mpx/s; 16384^2: 4,475 -> 4,461): no gain — the persistent conv kernels hold
-    // every CU, the blend workgroups run between them as before.  Off by default, kept as a tested form (labels and planes bit-identical).
-    static const int async_env = getenv("ANH_INFER_ASYNC_BLEND") ? atoi(getenv("ANH_INFER_ASYNC_BLEND")) : 0;
-    const bool async = async_env != 0 && !training;
-    if (async && !blend_stream) {
-        HIP_CHECK(hipStreamCreateWithFlags(&blend_stream, hipStreamNonBlocking));
-        HIP_CHECK(hipEventCreateWithFlags(&ev_logits, hipEventDisableTiming));
-        for (hipEvent_t& e : ev_blend) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    }
-    int n_async = 0;
-    struct Reset { int& v; ~Reset() { v = -1; } } reset{async_batch};   // (also when a launch throws)
     launch_fill_zero(d_blended, (size_t)K * pixels * 4, stream);
     // consecutive tiles with equal input windows (all of them, on a regular tiling) run as batches
     // — as FEW batches as the cap allows, of equal size (25 tiles at a cap of 8 used to run as 8 + 8 + 8 + 1: every launch has a fixed
@@ -1079,14 +1037,10 @@ void Engine::infer_device(const uint8_t* d_image, int H, int W, const double* ga
             ++run;
         }
         const size_t n_batches = (run + batch - 1) / batch, per = (run + n_batches - 1) / n_batches;
-        for (size_t done = 0; done < run; done += per) {
-            async_batch = async ? n_async++ : -1;
+        for (size_t done = 0; done < run; done += per)
             infer_tiles(&tiles[i + done], (int)std::min(per, run - done), d_image, H, W, d_blended);
-        }
         i += run;
     }
-    async_batch = -1;
-    if (n_async > 0) HIP_CHECK(hipStreamWaitEvent(stream, ev_blend[(n_async - 1) & 1], 0));   // the planes are complete on `stream` from here on
     if (d_labels) argmax_rows(d_blended, H, W, 0, H, gains_host, d_labels);
 }
 

@@ -65,10 +65,6 @@ struct ConvArgs {
     const void* w_bf16 = nullptr;     // [tap][c_out][c_red] bf16 (MFMA B operand, k contiguous)
     const float* bias = nullptr;
     void* out = nullptr; int out_dtype = DT_F32; int out_accumulate = 0;
-    void* act_out = nullptr;       // conv3x3_ws, training forward of a stride-1 layer whose producers apply bn + relu (+ skip add): they also STORE what they stage —
-                                   // the layer's activated input, bf16 [n][h_in][w_in][c_red] — so that the layer's filter gradient reads it plain (conv_materializes_input)
-    const void* zeros = nullptr;   // >= 64 bytes of zeros in device memory: what padding pixels read in the LDS-DMA staging form (conv3x3_ws, DMA)
-    unsigned out_bytes = 0;   // conv3x3_ws with deferred stores: size of `out` for the buffer descriptor (set by launch_ws)
     void* out2 = nullptr; int out2_accumulate = 0;  // optional second destination (skip-add gradient)
     int out_nchw = 0;                               // fp32 NCHW destination (boundary layout)
     double* stat_partials = nullptr;                // fused bn statistics (MFMA path), else nullptr
@@ -309,7 +305,6 @@ void launch_conv_mfma(const ConvArgs& a, hipStream_t s);
 // > 0: the MFMA kernel of this layer can also write the bn statistic partials (set ConvArgs::stat_partials; the
 // value is the number of partials per channel to pass to launch_bn_forward_finalize)
 int conv_fused_stat_blocks(const ConvArgs& a);
-bool conv_materializes_input(const ConvArgs& a);   // the launch of `a` would take ConvArgs::act_out (warp-specialised stride-1 forward form, bn kinds)
 int conv_fused_bnred_blocks(const ConvArgs& a);   // same for ConvArgs::bnred_partials (backward-data convs)
 bool conv_folds_bn_tables(const ConvArgs& a);     // the layer's kernel reads Src::a_tab / b_tab (the persistent kernels)
 bool conv_stores_activation(const ConvArgs& a);   // the layer's MFMA kernel honours ConvArgs::out_scale / out_shift (src.kind SRC_RAW, SRC_SUM2 or SRC_IMAGE)

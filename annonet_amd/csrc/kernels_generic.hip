@@ -1037,37 +1037,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(const T* da, T* o
         m[j] = mean[ch]; is[j] = invstd[ch]; sc[j] = scale[ch]; sf[j] = shift[ch];
         k0[j] = coef[ch]; k1[j] = coef[c + ch]; k2[j] = coef[2 * c + ch];
     }
-    // The same expression, element by element, written on PAIRS (round 4: on a SIMD every vector instruction of this pass queues behind the
-    // MFMAs of the filter-gradient waves it runs beside — DESIGN 7.R4; hipcc packs the multiplications by itself but leaves 24 scalar
-    // subtractions per chunk): v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32, same IEEE operations in the same order per element.
-    // MEASURED (six same-box rounds): 1.6408 -> 1.6582 ms per step (+1.1 %) — 12 v_pk_add_f32 replace 24 v_sub_f32 and 8 v_mov_b32 that
-    // form the pairs come with them; fewer instructions, slower pass.  Compiled out.
-#ifndef ANH_APPLY_PACKED
-#define ANH_APPLY_PACKED 0
-#endif
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    // (written on pairs with v_pk_* instructions this pass measured +1.1 % per step in round 4: profiles/r04_ab_log.txt)
     for (int64_t i = first; i < chunks; i += stride) {
         float yv[8], dv[8], r[8];
         load8<T>(y + (size_t)i * 8, yv);
         load8<T>(da + (size_t)i * 8, dv);
-#if ANH_APPLY_PACKED
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const f32x2 y2 = {yv[2 * j], yv[2 * j + 1]}, d2 = {dv[2 * j], dv[2 * j + 1]};
-            const f32x2 z2 = __builtin_elementwise_fma(y2, f32x2{sc[2 * j], sc[2 * j + 1]}, f32x2{sf[2 * j], sf[2 * j + 1]});
-            const f32x2 dz2 = {z2[0] > 0.f ? d2[0] : 0.f, z2[1] > 0.f ? d2[1] : 0.f};
-            const f32x2 xhat2 = (y2 - f32x2{m[2 * j], m[2 * j + 1]}) * f32x2{is[2 * j], is[2 * j + 1]};
-            const f32x2 r2 = f32x2{k0[2 * j], k0[2 * j + 1]} * (dz2 - f32x2{k1[2 * j], k1[2 * j + 1]} - xhat2 * f32x2{k2[2 * j], k2[2 * j + 1]});
-            r[2 * j] = r2[0]; r[2 * j + 1] = r2[1];
-        }
-#else
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float dz = fmaf(yv[j], sc[j], sf[j]) > 0.f ? dv[j] : 0.f;
             const float xhat = (yv[j] - m[j]) * is[j];
             r[j] = k0[j] * (dz - k1[j] - xhat * k2[j]);
         }
-#endif
         store8<T>(out + (size_t)i * 8, r);
     }
 }

@@ -54,51 +54,18 @@ constexpr int PH = TH + 2, PW = TW + 2;   // input patch
 constexpr int PATCH_PIX = PH * PW;        // 340 pixel records of 64 B
 constexpr int X_BYTES = PATCH_PIX * 64;   // 21,760
 
-// two fp32 -> one packed bf16 pair, round to nearest even.  (Round 4: written as ONE vector conversion hipcc emits a single
-// v_cvt_pk_bf16_f32 per pair instead of two half-live ones and a v_perm_b32 in about 1,600 places of this file — bit-identical, and
-// MEASURED slower: inference 4,460 / 4,471 / 4,524 / 4,534 -> 4,375 / 4,296 / 4,401 / 4,425 Mpx/s, training unchanged.  -DANH_PACK2_VECTOR=1.)
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-#ifndef ANH_PACK2_VECTOR
-#define ANH_PACK2_VECTOR 0
-#endif
+// two fp32 -> one packed bf16 pair, round to nearest even (element-wise conversions: the one-instruction vector conversion measured
+// slower in round 4, profiles/r04_ab_log.txt)
 __device__ __forceinline__ unsigned pack2(float lo, float hi) {
-#if ANH_PACK2_VECTOR
-    const f32x2 v = {lo, hi};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-#else
     bf16x2 t;
     t[0] = (bf16)lo; t[1] = (bf16)hi;
     return __builtin_bit_cast(unsigned, t);
-#endif
 }
 __device__ __forceinline__ float lo_f(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float hi_f(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
 
-// Experiment (build flags, round 4): -DANH_NT_LOADS=1 makes the staging loads of the persistent kernels non-temporal, -DANH_NT_STORES=1
-// the conv epilogues' 16-byte stores (a CU's vector-memory pipeline is shared by the producers' loads and the consumers' stores; what
-// the instrumented build shows as the consumers' "store" phase is mostly stores waiting in that pipeline: profiles/r04_phase_budget_*).
-#ifndef ANH_NT_LOADS
-#define ANH_NT_LOADS 0
-#endif
-#ifndef ANH_NT_STORES
-#define ANH_NT_STORES 0
-#endif
-typedef __attribute__((ext_vector_type(4))) unsigned nt_u32x4;
-__device__ __forceinline__ uint4 load16(const void* p) {
-#if ANH_NT_LOADS
-    const nt_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_u32x4*>(p));
-    return make_uint4(v[0], v[1], v[2], v[3]);
-#else
-    return *reinterpret_cast<const uint4*>(p);
-#endif
-}
-__device__ __forceinline__ void store16(void* p, const uint4& v) {
-#if ANH_NT_STORES
-    __builtin_nontemporal_store(nt_u32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<nt_u32x4*>(p));
-#else
-    *reinterpret_cast<uint4*>(p) = v;
-#endif
-}
+__device__ __forceinline__ uint4 load16(const void* p) { return *reinterpret_cast<const uint4*>(p); }
+__device__ __forceinline__ void store16(void* p, const uint4& v) { *reinterpret_cast<uint4*>(p) = v; }
 __device__ __forceinline__ float relu_affine(float y, float s, float t) {
     const float z = fmaf(y, s, t);
     return z > 0.f ? z : 0.f;
@@ -136,77 +103,9 @@ __device__ __forceinline__ uint4 add_bf16x8(const uint4& p, const uint4& q) {
                       pack2(lo_f(p.z) + lo_f(q.z), hi_f(p.z) + hi_f(q.z)), pack2(lo_f(p.w) + lo_f(q.w), hi_f(p.w) + hi_f(q.w)));
 }
 
-#ifndef ANH_WS_DEFER_STORES_BUILD
-#define ANH_WS_DEFER_STORES_BUILD 0
-#endif
-// ---- deferred stores (round 4; measured slower, compiled out by default: see CAN_DEFER in conv3x3_ws_kernel) ----
-// The consumers' epilogue used to end with a burst of 16-byte stores (ACC x NT x 2 per lane: 32-64 KB per workgroup and tile) that the
-// wave must ISSUE before it can meet the producers at the barrier and start the next MFMA phase; the write path of a CU takes them at its
-// own pace, so the matrix cores idled behind a full store queue.  Deferred form: the epilogue leaves the packed values and their byte
-// offsets in registers, and the NEXT item's MFMA nest issues them one at a time between its MFMA groups (18 hook points per item), as
-// buffer stores whose offset is 0xFFFFFFF0 for pixels outside the tensor — the buffer's bound check drops those, no branch in the nest.
-struct NoHook { __device__ __forceinline__ void operator()(int) const {} };
-template <int S> struct DeferredStores { u32x4 q[S]; unsigned off[S]; };
-template <int S>
-struct StoreHook {
-    const DeferredStores<S>& d;
-    __amdgpu_buffer_rsrc_t rsrc;
-    __device__ __forceinline__ void operator()(int i) const {
-        constexpr int STEP = 16 / S < 1 ? 1 : 16 / S;          // S = 4 / 8 / 16 stores over hook points 1 .. 16
-        if (i >= 1 && (i - 1) % STEP == 0 && (i - 1) / STEP < S) {
-            const int j = (i - 1) / STEP;
-            __builtin_amdgcn_raw_buffer_store_b128(d.q[j], rsrc, (int)d.off[j], 0, 0);
-        }
-    }
-};
-template <int S>
-__device__ __forceinline__ void flush_deferred(const DeferredStores<S>& d, __amdgpu_buffer_rsrc_t rsrc) {
-#pragma unroll
-    for (int j = 0; j < S; ++j) __builtin_amdgcn_raw_buffer_store_b128(d.q[j], rsrc, (int)d.off[j], 0, 0);
-}
-
 // Epilogue buffer (conv3x3_ws, producer-side bn backward sums): pixel slot q holds the stored values of its NT*32 channels as
 // 16-byte chunks k = channel / 8, chunk index XOR-ed so that the eight lanes of a ds_write_b128 group hit distinct banks.
 template <int NT> __device__ __forceinline__ int ebuf_swizzle(int q) { return NT == 1 ? (q >> 2) & 3 : (q >> 1) & 7; }
-
-#ifndef ANH_WS_TSTORE_BUILD
-#define ANH_WS_TSTORE_BUILD 0
-#endif
-// ---- transposed stores (round 4; MEASURED slower — training 1.685 / 1.679 / 1.665 -> 1.709 / 1.695 / 1.697 ms, inference unchanged, the
-// stride-1 kernels +3 ... +8 us each — and compiled out: -DANH_WS_TSTORE_BUILD=1 brings the form back, ANH_WS_TSTORE=0/1 then switches it) ----
-// After the permlane swap a lane holds 16 bytes of ITS pixel, so one store instruction of a wave is 64 pieces of 16 bytes, 64-256 bytes
-// apart: 64 requests in the CU's in-order texture-address / L1 pipeline where a contiguous kilobyte is 8 (full 128-byte lines).  The
-// instrumented build says the consumers' epilogue is mostly stores waiting to be issued behind the producers' loads in that pipeline
-// (profiles/r04_phase_budget_*), so the hypothesis was that the store's request count is what it pays for — it is not (see above; round 1's
-// address-pattern micro-benchmark had said the same: 5.0-5.4 vs 5.7 TB/s).  Transposed form: the wave writes the row's chunks to
-// a private LDS strip (32 pixels x 64 NT bytes, chunk index swizzled by the pixel), reads them back so that CONSECUTIVE LANES hold
-// CONSECUTIVE 16-byte chunks of memory (lane l: chunk l mod 4NT of pixel l / 4NT + (16 / NT) j), and stores whole lines.  Same wave, LDS
-// operations in program order: no barrier.  stage = nullptr: the direct form.
-struct RowStore {
-    char* stage;        // this wave's strip, or nullptr
-    size_t row_pix0;    // flat pixel index of the row's first pixel (column 32 tx), clamped into the tensor
-    int cols_valid;     // pixels of the row inside the image, counted from that column
-    bool row_valid;
-    int lane;
-};
-template <int NT>
-__device__ __forceinline__ void ts_store(const RowStore& ts, const ConvArgs& a, int co_base, const uint4 (&fin)[NT][2]) {
-    constexpr int CH = 4 * NT, PPI = 64 / CH;
-    const int col = ts.lane & 31, half = ts.lane >> 5;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-            *reinterpret_cast<uint4*>(ts.stage + col * (64 * NT) + (((nt * 4 + 2 * s + half) ^ ebuf_swizzle<NT>(col)) << 4)) = fin[nt][s];
-    bf16* out = reinterpret_cast<bf16*>(a.out);
-    const int k = ts.lane % CH, p0 = ts.lane / CH;
-#pragma unroll
-    for (int j = 0; j < NT * 2; ++j) {
-        const int p = p0 + PPI * j;
-        const uint4 v = *reinterpret_cast<const uint4*>(ts.stage + p * (64 * NT) + ((k ^ ebuf_swizzle<NT>(p)) << 4));
-        if (ts.row_valid && p < ts.cols_valid) store16(out + (ts.row_pix0 + p) * a.c_out + co_base + k * 8, v);
-    }
-}
 
 // NT 32-channel accumulator tiles of one pixel per lane -> NHWC bf16.  Lane = pixel x half; registers 4q..4q+3 of a tile
 // hold channels 8q + 4*half + 0..3, so two v_permlane32_swap per 16 channels leave 8 consecutive channels (16 bytes) in
@@ -221,7 +120,7 @@ __device__ __forceinline__ void store_pixel_tiles_rmw(const f32x16 (&acc)[NT], c
                                                       const u32x4 (&prefetched)[NT][2], bool use_prefetched,
                                                       float (*stat)[2][16] = nullptr, int stat_mode = 0,
                                                       const u32x4 (*yraw)[2] = nullptr, const float* bnc = nullptr,
-                                                      char* ebuf = nullptr, int eq = 0, const RowStore& ts = RowStore{nullptr, 0, 0, false, 0}, bool store_global = true) {
+                                                      char* ebuf = nullptr, int eq = 0, bool store_global = true) {
     const int C_OUT = a.c_out;  // a workgroup may own only NT*32 of the layer's output channels, starting at co_base
     uint4 q[NT][2];
 #pragma unroll
@@ -255,8 +154,7 @@ __device__ __forceinline__ void store_pixel_tiles_rmw(const f32x16 (&acc)[NT], c
 #pragma unroll
             for (int s = 0; s < 2; ++s) fin[nt][s] = q[nt][s];
     }
-    if (ts.stage) ts_store<NT>(ts, a, co_base, fin);
-    else if (valid && store_global) {
+    if (valid && store_global) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -334,8 +232,7 @@ __device__ __forceinline__ void store_pixel_tiles_rmw(const f32x16 (&acc)[NT], c
 // Register r of a tile holds channel 8 (r >> 2) + 4 half + (r & 3) BEFORE the permlane swap; act = [scale | shift][cw] of the
 // workgroup's channels (LDS table or global memory).
 template <int NT>
-__device__ __forceinline__ void store_pixel_tiles_act(const f32x16 (&acc)[NT], const ConvArgs& a, size_t pix, bool valid, int half, int co_base, const float* act, int cw,
-                                                      const RowStore& ts = RowStore{nullptr, 0, 0, false, 0}, char* ebuf = nullptr, int eq = 0) {
+__device__ __forceinline__ void store_pixel_tiles_act(const f32x16 (&acc)[NT], const ConvArgs& a, size_t pix, bool valid, int half, int co_base, const float* act, int cw) {
     bf16* out = reinterpret_cast<bf16*>(a.out);
     const size_t base = pix * a.c_out + co_base + 8 * half;
     uint4 fin[NT][2];
@@ -360,46 +257,11 @@ __device__ __forceinline__ void store_pixel_tiles_act(const f32x16 (&acc)[NT], c
             fin[nt][s] = make_uint4(r0[0], r1[0], r0[1], r1[1]);
         }
     }
-    if (ebuf) {   // producer-issued stores (PS = 4): the values go to the workgroup's epilogue buffer only
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) *reinterpret_cast<uint4*>(ebuf + eq * (64 * NT) + (((nt * 4 + 2 * s + half) ^ ebuf_swizzle<NT>(eq)) << 4)) = fin[nt][s];
-    } else if (ts.stage) ts_store<NT>(ts, a, co_base, fin);
-    else if (valid) {
+    if (valid) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int s = 0; s < 2; ++s) store16(out + base + nt * 32 + 16 * s, fin[nt][s]);
-    }
-}
-
-// The same epilogue with the stores deferred: packed values and byte offsets into `d` (slots s0 .. s0 + 2 NT - 1).
-template <int NT, int S>
-__device__ __forceinline__ void pack_pixel_tiles_act(const f32x16 (&acc)[NT], const ConvArgs& a, size_t pix, bool valid, int half, int co_base, const float* act, int cw,
-                                                     DeferredStores<S>& d, int s0) {
-    const size_t base = pix * a.c_out + co_base + 8 * half;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        float v[16];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 sc = *reinterpret_cast<const float4*>(act + nt * 32 + 8 * q + 4 * half);
-            const float4 sh = *reinterpret_cast<const float4*>(act + cw + nt * 32 + 8 * q + 4 * half);
-            v[4 * q + 0] = fmaf(acc[nt][4 * q + 0], sc.x, sh.x);
-            v[4 * q + 1] = fmaf(acc[nt][4 * q + 1], sc.y, sh.y);
-            v[4 * q + 2] = fmaf(acc[nt][4 * q + 2], sc.z, sh.z);
-            v[4 * q + 3] = fmaf(acc[nt][4 * q + 3], sc.w, sh.w);
-        }
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const unsigned a0 = relu_bf16x2(pack2(v[8 * s + 0], v[8 * s + 1])), a1 = relu_bf16x2(pack2(v[8 * s + 2], v[8 * s + 3]));
-            const unsigned b0 = relu_bf16x2(pack2(v[8 * s + 4], v[8 * s + 5])), b1 = relu_bf16x2(pack2(v[8 * s + 6], v[8 * s + 7]));
-            auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
-            auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
-            d.q[s0 + nt * 2 + s] = u32x4{r0[0], r1[0], r0[1], r1[1]};
-            d.off[s0 + nt * 2 + s] = valid ? (unsigned)((base + nt * 32 + 16 * s) * 2) : 0xFFFFFFF0u;
-        }
     }
 }
 
@@ -408,7 +270,7 @@ __device__ __forceinline__ void pack_pixel_tiles_act(const f32x16 (&acc)[NT], co
 // head_blend_kernel's four lanes: chunk sums chained over ascending channels from 0, (chunk 0 + chunk 1) + (chunk 2 + chunk 3), + bias.
 // hw[s][j][k] = head weight of channel 16 s + 8 half + j, class k (zero beyond head_k).  Half 0 stores classes 0 and 2, half 1 classes 1 and 3.
 __device__ __forceinline__ void store_pixel_tiles_head(const f32x16& acc, const ConvArgs& a, size_t pix, int n, bool valid, int half, const float* act, int cw,
-                                                       const float (&hw)[2][8][4], const float (&hbias)[4], const float* hwl = nullptr) {
+                                                       const float (&hw)[2][8][4], const float (&hbias)[4]) {
     float v[16];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -427,48 +289,6 @@ __device__ __forceinline__ void store_pixel_tiles_head(const f32x16& acc, const 
         auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
         auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
         const unsigned w4[4] = {r0[0], r1[0], r0[1], r1[1]};   // channels 16 s + 8 half + 0 .. 7, two per word
-#ifndef ANH_HEAD_PK_FMA
-#define ANH_HEAD_PK_FMA 0
-#endif
-// (ANH_HEAD_LDS_PK=1, MEASURED: hipcc hoists the 32 loop-invariant table reads out of the tile loop — 256 VGPRs, 6 spilled, as the
-// register form; inference 4,537 / 4,522 / 4,519 / 4,531 -> 4,291 / 4,271 / 4,211 / 4,238 Mpx/s.  Off.)
-#ifndef ANH_HEAD_LDS_PK
-#define ANH_HEAD_LDS_PK 0
-#endif
-#if ANH_HEAD_LDS_PK
-        // The head weights read from an LDS table [channel][4 classes] (one broadcast ds_read_b128 per channel: no VALU, and 64 VGPRs
-        // fewer than the register copy — with the filter fragments in registers the packed form spilled), the FMAs packed by class pairs
-        // (v_pk_fma_f32, the activation broadcast by op_sel): the same chain per class, half the issue slots.
-        {
-            f32x2 s01 = {0.f, 0.f}, s23 = {0.f, 0.f};
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float4 wl = *reinterpret_cast<const float4*>(hwl + (16 * s + 8 * half + 2 * i) * 4);
-                const float4 wh = *reinterpret_cast<const float4*>(hwl + (16 * s + 8 * half + 2 * i + 1) * 4);
-                const float lo = lo_f(w4[i]), hi = hi_f(w4[i]);
-                s01 = __builtin_elementwise_fma(f32x2{lo, lo}, f32x2{wl.x, wl.y}, s01);
-                s23 = __builtin_elementwise_fma(f32x2{lo, lo}, f32x2{wl.z, wl.w}, s23);
-                s01 = __builtin_elementwise_fma(f32x2{hi, hi}, f32x2{wh.x, wh.y}, s01);
-                s23 = __builtin_elementwise_fma(f32x2{hi, hi}, f32x2{wh.z, wh.w}, s23);
-            }
-            part[s][0] = s01[0]; part[s][1] = s01[1]; part[s][2] = s23[0]; part[s][3] = s23[1];
-        }
-#elif ANH_HEAD_PK_FMA
-        // two classes per instruction (v_pk_fma_f32; the activation broadcast to both halves): the same chain per class, half the VALU
-        // issue slots — on a SIMD they are what this epilogue costs
-        typedef f32x2 f32x2_t;
-#pragma unroll
-        for (int kp = 0; kp < 2; ++kp) {
-            f32x2_t sum = {0.f, 0.f};
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float lo = lo_f(w4[i]), hi = hi_f(w4[i]);
-                sum = __builtin_elementwise_fma(f32x2_t{lo, lo}, f32x2_t{hw[s][2 * i][2 * kp], hw[s][2 * i][2 * kp + 1]}, sum);
-                sum = __builtin_elementwise_fma(f32x2_t{hi, hi}, f32x2_t{hw[s][2 * i + 1][2 * kp], hw[s][2 * i + 1][2 * kp + 1]}, sum);
-            }
-            part[s][2 * kp] = sum[0]; part[s][2 * kp + 1] = sum[1];
-        }
-#else
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             float sum = 0.f;
@@ -479,7 +299,6 @@ __device__ __forceinline__ void store_pixel_tiles_head(const f32x16& acc, const 
             }
             part[s][k] = sum;
         }
-#endif
     }
     const size_t plane = (size_t)a.h_out * a.w_out;
 #pragma unroll
@@ -1104,12 +923,8 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_ws_kernel(WgParams a, int til
         const size_t p_plane = (size_t)a.patch.h * a.patch.w * a.patch.c, t_plane = (size_t)a.tile.h * a.tile.w * a.tile.c;  // < 2^31 elements (host check)
         // Buffer loads, as the conv kernels' producers (round 4: a SIMD's issue port is what these kernels spend): one descriptor per
         // image and operand, a 32-bit byte offset per chunk, positions outside the image at an offset outside the descriptor (zeros
-        // by themselves: the plain-copy kinds need neither clamps nor masks).  -DANH_WS_BUFFER_LOADS=0: clamped 64-bit pointers.
-#ifndef ANH_WS_BUFFER_LOADS
-#define ANH_WS_BUFFER_LOADS 1
-#endif
-        constexpr bool BUFL = ANH_WS_BUFFER_LOADS != 0;
-        constexpr bool P_MASK = !BUFL || KP == SRC_ACT || KP == SRC_ACT2, T_MASK = !BUFL || KT == SRC_ACT || KT == SRC_ACT2;   // bn kinds: relu(shift) is not zero
+        // by themselves: the plain-copy kinds need neither clamps nor masks).
+        constexpr bool P_MASK = KP == SRC_ACT || KP == SRC_ACT2, T_MASK = KT == SRC_ACT || KT == SRC_ACT2;   // bn kinds: relu(shift) is not zero
         auto buffer_side = [&](const __amdgpu_buffer_rsrc_t& ra_, const __amdgpu_buffer_rsrc_t& rb_, int off, auto& dst, auto kind_tag) __attribute__((always_inline)) {
             constexpr int K = decltype(kind_tag)::value;
             const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ra_, off, 0, 0);
@@ -1129,7 +944,7 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_ws_kernel(WgParams a, int til
             const bf16* tb = KT == SRC_ACT2 ? a.tile.b + (size_t)n * t_plane : nullptr;
             R.pok = 0;
             R.tok = 0;
-            if constexpr (BUFL) {
+            {
                 const __amdgpu_buffer_rsrc_t rpa = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(pa), 0, (int)(unsigned)(p_plane * 2), 0x00020000);
                 const __amdgpu_buffer_rsrc_t rpb = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(KP == SRC_ACT2 ? pb : pa), 0, (int)(unsigned)(p_plane * 2), 0x00020000);
 #pragma unroll
@@ -1148,21 +963,6 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_ws_kernel(WgParams a, int til
                     const bool ok = oy < a.tile.h && ox < a.tile.w;
                     buffer_side(rta, rtb, ok ? ((oy * a.tile.w + ox) * a.tile.c + tch0 + (jj / JPN) * 32 + c16 * 8) * 2 : (int)0xFFFFF000u, R.t[jj], std::integral_constant<int, KT>{});
                     if constexpr (T_MASK) R.tok |= (ok ? 1u : 0u) << jj;
-                }
-            } else {
-#pragma unroll
-                for (int jj = 0; jj < NP; ++jj) {
-                    const int iy = yb + (pgeo[jj] & 255), ix = xb + (pgeo[jj] >> 8);
-                    const int cy = min(max(iy, 0), a.patch.h - 1), cx = min(max(ix, 0), a.patch.w - 1);
-                    R.p[jj] = side_load_at<KP>(pa, pb, (cy * a.patch.w + cx) * a.patch.c + cc + c16 * 8);
-                    R.pok |= ((iy == cy && ix == cx) ? 1u : 0u) << jj;
-                }
-                const int ox = x0 + t_x, cx = min(ox, a.tile.w - 1);
-#pragma unroll
-                for (int jj = 0; jj < NT_; ++jj) {
-                    const int oy = y0 + t_row0 + 2 * (jj % JPN), cy = min(oy, a.tile.h - 1);
-                    R.t[jj] = side_load_at<KT>(ta, tb, (cy * a.tile.w + cx) * a.tile.c + tch0 + (jj / JPN) * 32 + c16 * 8);
-                    R.tok |= ((oy == cy && ox == cx) ? 1u : 0u) << jj;
                 }
             }
         };
@@ -1185,12 +985,9 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_ws_kernel(WgParams a, int til
         // VGPRs, and what this kernel's waves leave of a SIMD's register file decides how many waves of the bn backward apply pass —
         // which runs beside this kernel on the other stream and IS on the step's critical path — fit next to them: none beside 232,
         // one 82-VGPR wave beside 195, two beside <= 168.  Same-box A/B: 1.7405 -> 1.7217 ms per step; this
-        // kernel's own time does not change (it is not what the step waits for).  ANH_WGRAD_LEAN (build flag): 0 two sets everywhere,
-        // 1 skip-add forms lean, 2 every form lean, 3 (default) skip-add and 128-channel forms.
-#ifndef ANH_WGRAD_LEAN
-#define ANH_WGRAD_LEAN 3
-#endif
-        constexpr bool ONE_SET = ANH_WGRAD_LEAN == 2 || (ANH_WGRAD_LEAN == 1 && KP == SRC_ACT2) || (ANH_WGRAD_LEAN == 3 && (KP == SRC_ACT2 || NTC == 4));
+        // kernel's own time does not change (it is not what the step waits for).  (Every form lean / only the skip-add forms lean measured
+        // 1.725 / 1.726-1.733 against 1.721-1.723 for this choice: profiles/r03 notes.)
+        constexpr bool ONE_SET = KP == SRC_ACT2 || NTC == 4;
         if (tile < total_tiles) fetch(ra, tile);
         if constexpr (ONE_SET) {
             while (tile < total_tiles) {
@@ -1289,32 +1086,12 @@ __device__ __forceinline__ const char* swz_addr(const char* base, int rec, int k
 }
 __device__ __forceinline__ bf16x8 lds_frag(const char* p) { return *reinterpret_cast<const bf16x8*>(p); }
 
-// -DANH_WS_PIN_NEST=1 (experiment, round 4): the stride-1 nest's instruction order pinned with sched_group_barrier — the LDS reads of
-// (kx, k-step) group i + 1 are issued BETWEEN the MFMAs of group i (one group = 6 NT MFMAs and 4 + 3 NT reads), instead of wherever the
-// list scheduler leaves them (hipcc: one to two MFMAs ahead, 22 lgkmcnt(1) waits per 72 MFMAs).  ISA checked: the waits become
-// lgkmcnt(5..8).  MEASURED: training 1.7586 / 1.7773 / 1.7682 -> 1.7708 / 1.7781 / 1.7712 ms, inference 4,189 / 4,159 / 4,227 -> 4,176 /
-// 4,122 / 4,157 Mpx/s: as round 3's hand-pinned nest, a shorter MFMA phase shortens nothing.  Compiled out.
-#ifndef ANH_WS_PIN_NEST
-#define ANH_WS_PIN_NEST 0
-#endif
-template <int M_, int R_, int m>
-struct PinGroup {
-    __device__ __forceinline__ static void go() {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                       // one MFMA
-        constexpr int r = ((m + 1) * R_) / M_ - (m * R_) / M_;
-        if constexpr (r > 0) __builtin_amdgcn_sched_group_barrier(0x100, r, 0);   // r LDS reads of the next group
-        if constexpr (m + 1 < M_) PinGroup<M_, R_, m + 1>::go();
-    }
-};
-
 struct GeoS1 {
     static constexpr int RECS = PATCH_PIX, ACC = 2;
     static constexpr bool RMW_PREFETCH = false;  // read-modify-write destinations prefetched before the MFMA phase (register cost)
     __device__ static void decode(int rec, int& py, int& px, int& key) { py = rec / PW; px = rec - py * PW; key = (px >> 2) & 3; }
     __device__ static int in_y0(int ty) { return ty * TH - 1; }
     __device__ static int in_x0(int tx) { return tx * TW - 1; }
-    static constexpr bool CAN_MATERIALIZE = true;   // every input pixel is the interior of exactly one tile's patch
-    __device__ static bool interior(int py, int px) { return py >= 1 && py <= TH && px >= 1 && px <= TW; }
     static constexpr int NB = 3;  // one lane base per kx
     struct Bases { const char* x[3][2]; };
     __device__ static void init(Bases& b, const char* lds_x, int wave, int col, int half) {
@@ -1328,8 +1105,8 @@ struct GeoS1 {
     // (Round 3: a hand-pinned two-register-set form of this nest — all ten fragments of step i + 1 requested behind the second MFMA of
     // step i — shortens the instrumented MFMA phase by 17 % (27 -> 22.7 us on the 64->64 forward) and leaves the step where it was:
     // 1.741 vs 1.738 ms for this plain nest, same box.  What did pay is registers: see HAS_FWD_FORM in launch_ws.)
-    template <int NT, class H = NoHook>
-    __device__ static void mfma(f32x16 (&acc)[ACC][NT], const Bases& b, const char* (&wb)[2], const H& hook = H()) {
+    template <int NT>
+    __device__ static void mfma(f32x16 (&acc)[ACC][NT], const Bases& b, const char* (&wb)[2]) {
         constexpr int C_OUT = NT * 32;
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
@@ -1347,18 +1124,9 @@ struct GeoS1 {
 #pragma unroll
                         for (int g = 0; g < 2; ++g) acc[g][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf[g + ky], acc[g][nt], 0, 0, 0);
                     }
-                    hook((kx * 2 + ks) * 3 + ky);   // 18 hook points per item (deferred stores of the previous tile)
                 }
             }
         }
-#if ANH_WS_PIN_NEST
-        {
-            constexpr int R = 4 + 3 * NT, M = 6 * NT;
-            __builtin_amdgcn_sched_group_barrier(0x100, R, 0);
-            PinGroup<M, R, 0>::go(); PinGroup<M, R, 0>::go(); PinGroup<M, R, 0>::go(); PinGroup<M, R, 0>::go(); PinGroup<M, R, 0>::go();
-            __builtin_amdgcn_sched_group_barrier(0x008, M, 0);
-        }
-#endif
     }
     // The 32 -> 32 layer (one reduction slab, one channel tile): its 18 filter fragments (9 taps x 2 k-steps, 72 VGPRs) are the same for
     // every tile — read from LDS once per workgroup and kept in registers, the nest then reads the 24 pixel fragments of an item only
@@ -1384,71 +1152,9 @@ struct GeoS1 {
             }
         }
     }
-    static constexpr bool TS_OK = true;   // a wave's group is 32 consecutive pixels of one output row: transposed stores apply
-    __device__ static void row_origin(int g, const ConvArgs& a, int n, int ty, int tx, int wave, size_t& row_pix0, bool& row_valid, int& cols_valid) {
-        const int oy = ty * TH + wave * 2 + g, ox0 = tx * TW;
-        row_valid = oy < a.h_out && ox0 < a.w_out;
-        cols_valid = a.w_out - ox0;
-        row_pix0 = ((size_t)n * a.h_out + (row_valid ? oy : 0)) * a.w_out + (row_valid ? ox0 : 0);
-    }
     // output pixel of accumulator group g (one lane = one pixel): row 2*wave + g of the tile
     __device__ static void out_pixel(int g, const ConvArgs& a, int n, int ty, int tx, int wave, int col, size_t& pix, bool& valid) {
         const int oy = ty * TH + wave * 2 + g, ox = tx * TW + col;
-        valid = oy < a.h_out && ox < a.w_out;
-        pix = ((size_t)n * a.h_out + (valid ? oy : 0)) * a.w_out + (valid ? ox : 0);
-    }
-};
-
-// GeoS1T (round 4): the stride-1 geometry on a 16 x 32 tile — a wave owns FOUR output rows (four accumulator groups), so a filter
-// fragment read from LDS feeds four MFMAs instead of two and six patch rows serve twelve (kx, k-step, ky) uses: 6 + 3 NT LDS reads per
-// 12 NT MFMAs (NT = 2: 12 per 24, GeoS1: 10 per 12), half the hand-over barriers per MFMA, a 1.19 x instead of a 1.33 x patch.  128
-// accumulator registers at NT = 2: the inference forms only (no statistics registers).  LDS: 2 x 39,168-byte patches + 73,728 bytes of
-// resident filter at 64 reduction channels = 153 KB.
-struct GeoS1T {
-    static constexpr int TTH = 16, TPH = TTH + 2;
-    static constexpr int RECS = TPH * PW, ACC = 4;
-    static constexpr bool RMW_PREFETCH = false;
-    __device__ static void decode(int rec, int& py, int& px, int& key) { py = rec / PW; px = rec - py * PW; key = (px >> 2) & 3; }
-    __device__ static int in_y0(int ty) { return ty * TTH - 1; }
-    __device__ static int in_x0(int tx) { return tx * TW - 1; }
-    static constexpr bool CAN_MATERIALIZE = false;
-    __device__ static bool interior(int, int) { return false; }
-    static constexpr int NB = 3;
-    struct Bases { const char* x[3][2]; };
-    __device__ static void init(Bases& b, const char* lds_x, int wave, int col, int half) {
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) b.x[kx][ks] = swz_addr(lds_x, wave * 4 * PW + col + kx, (col + kx) >> 2, ks, half);
-    }
-    template <int NT, class H = NoHook>
-    __device__ static void mfma(f32x16 (&acc)[ACC][NT], const Bases& b, const char* (&wb)[2], const H& hook = H()) {
-        constexpr int C_OUT = NT * 32;
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 xf[6];
-#pragma unroll
-                for (int r = 0; r < 6; ++r) xf[r] = lds_frag(b.x[kx][ks] + r * (PW * 64));
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky) {
-                    const int tl = ky * 3 + kx;
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        const bf16x8 wf = lds_frag(wb[ks] + (tl * C_OUT + nt * 32) * 64);
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) acc[g][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf[g + ky], acc[g][nt], 0, 0, 0);
-                    }
-                    hook((kx * 2 + ks) * 3 + ky);
-                }
-            }
-        }
-    }
-    static constexpr bool TS_OK = false;
-    __device__ static void row_origin(int, const ConvArgs&, int, int, int, int, size_t& row_pix0, bool& row_valid, int& cols_valid) { row_pix0 = 0; row_valid = false; cols_valid = 0; }
-    __device__ static void out_pixel(int g, const ConvArgs& a, int n, int ty, int tx, int wave, int col, size_t& pix, bool& valid) {
-        const int oy = ty * TTH + wave * 4 + g, ox = tx * TW + col;
         valid = oy < a.h_out && ox < a.w_out;
         pix = ((size_t)n * a.h_out + (valid ? oy : 0)) * a.w_out + (valid ? ox : 0);
     }
@@ -1462,8 +1168,6 @@ struct GeoDown {
         const int rem = rec - py * 66, par = rem >= 33, u = rem - 33 * par;
         px = 2 * u + par; key = (u >> 2) & 3;
     }
-    static constexpr bool CAN_MATERIALIZE = false;
-    __device__ static bool interior(int, int) { return false; }
     __device__ static int in_y0(int ty) { return ty * 8; }
     __device__ static int in_x0(int tx) { return tx * 64; }
     static constexpr int NB = 2;
@@ -1474,8 +1178,8 @@ struct GeoDown {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) b.x[kh][ks] = swz_addr(lds_x, wave * 4 * 33 + col + kh, (col + kh) >> 2, ks, half);
     }
-    template <int NT, class H = NoHook>
-    __device__ static void mfma(f32x16 (&acc)[ACC][NT], const Bases& b, const char* (&wb)[2], const H& hook = H()) {
+    template <int NT>
+    __device__ static void mfma(f32x16 (&acc)[ACC][NT], const Bases& b, const char* (&wb)[2]) {
         constexpr int C_OUT = NT * 32;
 #pragma unroll
         for (int tl = 0; tl < 9; ++tl) {
@@ -1488,16 +1192,8 @@ struct GeoDown {
                     const bf16x8 wf = lds_frag(wb[ks] + (tl * C_OUT + nt * 32) * 64);
                     acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc[0][nt], 0, 0, 0);
                 }
-                hook(tl * 2 + ks);
             }
         }
-    }
-    static constexpr bool TS_OK = true;
-    __device__ static void row_origin(int, const ConvArgs& a, int n, int ty, int tx, int wave, size_t& row_pix0, bool& row_valid, int& cols_valid) {
-        const int oy = ty * 4 + wave, ox0 = tx * 32;
-        row_valid = oy < a.h_out && ox0 < a.w_out;
-        cols_valid = a.w_out - ox0;
-        row_pix0 = ((size_t)n * a.h_out + (row_valid ? oy : 0)) * a.w_out + (row_valid ? ox0 : 0);
     }
     __device__ static void out_pixel(int, const ConvArgs& a, int n, int ty, int tx, int wave, int col, size_t& pix, bool& valid) {
         const int oy = ty * 4 + wave, ox = tx * 32 + col;
@@ -1510,8 +1206,6 @@ struct GeoUp {
     static constexpr int RECS = 5 * 33, ACC = 4;
     static constexpr bool RMW_PREFETCH = true;   // the skip-gradient accumulation of this net lands in stride-2 con backward-data
     __device__ static void decode(int rec, int& py, int& px, int& key) { py = rec / 33; px = rec - py * 33; key = (px >> 2) & 3; }
-    static constexpr bool CAN_MATERIALIZE = false;
-    __device__ static bool interior(int, int) { return false; }
     __device__ static int in_y0(int ty) { return ty * 4 - 1; }
     __device__ static int in_x0(int tx) { return tx * 32 - 1; }
     static constexpr int NB = 2;
@@ -1522,10 +1216,9 @@ struct GeoUp {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) b.x[ib][ks] = swz_addr(lds_x, wave * 33 + col + 1 - ib, (col + 1 - ib) >> 2, ks, half);
     }
-    template <int NT, class H = NoHook>
-    __device__ static void mfma(f32x16 (&acc)[ACC][NT], const Bases& b, const char* (&wb)[2], const H& hook = H()) {
+    template <int NT>
+    __device__ static void mfma(f32x16 (&acc)[ACC][NT], const Bases& b, const char* (&wb)[2]) {
         constexpr int C_OUT = NT * 32;
-        int hidx = 0;   // (a compile-time constant at every hook call once the nest is unrolled)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 xf[2][2];  // [ia][ib]: input (i - ia, j - ib)
@@ -1547,12 +1240,9 @@ struct GeoUp {
                                 const bf16x8 wf = lds_frag(wb[ks] + (tap * C_OUT + nt * 32) * 64);
                                 acc[py * 2 + px][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf[ia][ib], acc[py * 2 + px][nt], 0, 0, 0);
                             }
-                            hook(hidx++);
                         }
         }
     }
-    static constexpr bool TS_OK = false;  // a group's pixels are every second column of an output row
-    __device__ static void row_origin(int, const ConvArgs&, int, int, int, int, size_t& row_pix0, bool& row_valid, int& cols_valid) { row_pix0 = 0; row_valid = false; cols_valid = 0; }
     // accumulator group g = output parity class (py, px) = (g >> 1, g & 1) of low-res position (i, j)
     __device__ static void out_pixel(int g, const ConvArgs& a, int n, int ty, int tx, int wave, int col, size_t& pix, bool& valid) {
         const int oy = 2 * (ty * 4 + wave) + (g >> 1), ox = 2 * (tx * 32 + col) + (g & 1);
@@ -1573,37 +1263,20 @@ struct GeoUp {
 // FWD: the forward-only form — no prefetched epilogue operands (old values of an accumulating destination, y of the
 // layer behind `out`), whose registers the four-accumulator-group geometry at NT = 2 needs for its bn statistics sums.
 // ACT (inference, with FWD): the epilogue applies this layer's own folded bn + relu (ConvArgs::out_scale) and stores the activation.
-// PS (backward-data forms, with the bn backward sums fused): the sums are formed by the PRODUCER waves.  The consumers' epilogue
-// leaves the stored values of a tile in an LDS epilogue buffer (e_off); two items later a producer thread — which owns a fixed
-// 16-byte channel chunk, hence 16 running sums instead of the consumers' NT x 32 — reads them back beside the y it has fetched
-// meanwhile.  In the backward-data convs the producers (plain-copy staging) wait at the hand-over barrier for a third to half of
-// the kernel while the consumers' epilogue is as long as their MFMA phase: this moves that work to where the slack is.
-// PS = 2 (round 4): the sums are SPLIT between the roles — the consumer waves keep them for the accumulator groups g < ACC / 2 (their
-// own y prefetch, their own per-lane running sums), the producer waves for the groups g >= ACC / 2 through the epilogue buffer.  In the
-// plain-copy (backward-data) forms the consumers' epilogue is as long as their MFMA phase while the producers wait at the hand-over
-// barrier for a third to half of the kernel; moving ALL of the sums over (PS = 1) made the producers the long pole in every geometry but
-// one — half of them balances the two roles.
-// PS = 3 (round 4): the consumers keep ALL the sums, but their y operands arrive through LDS: the producer waves — idle at the hand-over
-// barrier for a third to half of a backward-data kernel — fetch the tile's y chunks beside the patch of the next item and leave them in
-// the epilogue buffer; the consumers read them there when the epilogue starts.  The consumers then carry no prefetched y registers
-// (ACC x NT x 8 VGPRs) through their MFMA phase — the register pressure that makes hipcc schedule the backward forms' MFMA nest with
-// three operand sets instead of seven (see HAS_FWD_FORM below) — and never wait on global memory in the epilogue.
-// DMA (round 4; plain-copy staging with every filter slab resident): the producer waves move the patches with LDS-DMA
-// (global_load_lds_dwordx4: the data goes from the memory pipeline straight into LDS — no staging registers, no commit phase, no VALU).
-// A lane's 16 bytes land at M0 + 16 x lane, so one wave instruction fills 16 consecutive 64-byte records; the column swizzle of the
-// record layout becomes a choice of WHICH chunk of its pixel a lane asks for (chunk (lane & 3) ^ key), padding pixels read a block of
-// zeros.  The patch buffers form a ring of `rd` (2 or 3, what LDS allows): item m's transfers are issued in the producers' iteration
-// m - (rd - 2) and must have landed (s_waitcnt vmcnt) before the barrier that hands item m over.
-// TEAMS = 2 (round 4, "ping-pong"): TWO consumer teams of four waves (768 threads: waves 0-3 team 0, 4-7 team 1, 8-11 the producers; three
-// waves per SIMD, <= 168 VGPRs).  A consumer wave's item is an MFMA phase followed by an epilogue that is mostly stores waiting to be
-// issued, during which its SIMD's matrix core idles — the producer wave beside it runs no MFMA.  With two teams the tiles
-// alternate between them: in the interval in which one team runs the MFMA phase of tile k, the other runs the epilogue of tile k - 1 on
-// the same four SIMDs.  Still ONE workgroup barrier per item and two patch buffers: the epilogue needs only the team's registers.
-// (tools/micro/conv_bytes.hip: a copy kernel with this kernel's addresses and roles and a 1.5 us sleep before every tile's stores takes
-// 55 us per launch with one workgroup per CU and 34 with two.)  Forms: PS = 0, no DMA staging; statistics / bn backward sums as TEAMS = 1
-// (per-lane running sums in each team's waves; the closing reduction takes eight waves' partials in a fixed order).
-template <class G, int NT, int KIND, bool FWD = false, bool ACT = false, int PS = 0, bool HEAD = false, bool DMA = false, int TEAMS = 1>
-__global__ __launch_bounds__(256 * (TEAMS + 1), (TEAMS == 2 ? 3 : 2)) void conv3x3_ws_kernel(ConvArgs a, int tiles_x, int tiles_y, int flip, long long* prof, int wres_, int e_off_) {
+// HEAD (with ACT; GeoS1, NT = 1): the epilogue forms the 1x1 head's logits instead of storing the activation.
+// PS (backward-data forms with the bn backward sums fused; plain-copy staging): what the PRODUCER waves take over from the consumers'
+// epilogue.  The consumers leave the final values of a tile in an LDS epilogue buffer (e_off); two items later a producer thread —
+// which owns a fixed 16-byte channel chunk — reads them back, consecutive lanes holding consecutive chunks:
+//   PS = 1  the producers form the bn backward sums (16 running sums per thread instead of the consumers' NT x 32; y fetched meanwhile);
+//   PS = 4  the producers issue the tile's global stores, the consumers keep the sums (stride-1 / down geometries);
+//   PS = 5  both (the four-accumulator-group geometry at 32 channels).
+// In the backward-data convs the producers wait at the hand-over barrier for a third to half of the kernel while the consumers'
+// epilogue — mostly stores waiting to be issued — is as long as their MFMA phase: this moves that work to where the slack is.
+// Forms measured and removed again (rounds 2-4; profiles/r04_ab_log.txt, DESIGN.md "Measured and rejected"): sums split between the roles,
+// y operands through LDS, LDS-DMA staging, two consumer teams, one barrier per two items, deferred / transposed / non-temporal stores,
+// a second staging register set, a pinned MFMA nest, 16 x 32 tiles, role-per-SIMD maps, wave priorities, staggered starts.
+template <class G, int NT, int KIND, bool FWD = false, bool ACT = false, int PS = 0, bool HEAD = false>
+__global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tiles_x, int tiles_y, int flip, long long* prof, int wres_, int e_off) {
     // per-phase wall-clock accounting, compiled in with -DANH_WS_PROFILE (ANH_WS_PROF=1 then prints one line per launch)
 #ifdef ANH_WS_PROFILE
     long long t_a = 0, t_b = 0, t_c = 0, t_d = 0, t0_;
@@ -1617,43 +1290,26 @@ __global__ __launch_bounds__(256 * (TEAMS + 1), (TEAMS == 2 ? 3 : 2)) void conv3
 #define TICK()
 #define TOCK(acc_)
 #endif
-    static_assert(TEAMS == 1 || (TEAMS == 2 && PS == 0 && !DMA), "conv3x3_ws: two consumer teams exist for the PS = 0, register-staged forms");
-    constexpr int NTHR = 256 * (TEAMS + 1);
+    static_assert(PS == 0 || PS == 1 || PS == 4 || PS == 5, "conv3x3_ws: producer-side forms 1 (sums), 4 (stores), 5 (both)");
+    constexpr int NTHR = 512;
     constexpr int C_OUT = NT * 32, NP = (G::RECS * 4 + 255) / 256, W_ITEMS = 9 * C_OUT * 4, NW = (W_ITEMS + 255) / 256;
     constexpr int X_BYTES_ = G::RECS * 64, W_BYTES = 9 * C_OUT * 64, BUF = X_BYTES_ + W_BYTES;
-    const int wres = wres_ & 1, role_map = (wres_ >> 1) & 1, prio = (wres_ >> 2) & 3, bands = (wres_ >> 4) & 1;
-    const bool defer = (wres_ >> 5) & 1;   // the epilogue's stores ride in the next item's MFMA nest (DeferredStores)
-    // ANH_WS_STAGGER (experiment): every second workgroup of an XCD starts 64 x n cycles late — persistent workgroups do identical work per
-    // item, so without it all 256 CUs issue their epilogue stores in the same short window of every item
-    {
-        const int stagger = (wres_ >> 8) & 0xff;
-        if (stagger && ((blockIdx.x >> 3) & 1)) for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(1);
-    }
-    const int ts_off = (int)((unsigned)e_off_ >> 18) << 4, e_off = e_off_ & 0x3ffff;   // transposed stores: offset of the four consumer strips (0 = off)   // (see the role map below; prio: experiment switch ANH_WS_PRIO)
+    const int wres = wres_ & 1, bands = (wres_ >> 4) & 1;   // wres_ bit 0: filter-resident form; bit 4: XCD-band tile walk; bit 19: filter fragments NOT kept in registers
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // LDS layout.  Streaming form: [X | W] [X | W] tables — the filter slab of every item travels with its patch.
     // Resident form (wres; the filter slabs of ALL reduction slabs fit beside two patches, i.e. 64 reduction channels):
     // [X] [X] [W slab 0] [W slab 1] ... tables — the producers stage the filter once and then move patches only.
     const int n_slabs_l = a.c_red >> 5;
-    constexpr int X_PAD = NP * 4096;                                              // DMA: a patch buffer holds whole wave instructions (64 records per round of the four waves)
-    const int rd = DMA ? 2 + ((wres_ >> 16) & 1) : 2;                             // DMA: depth of the patch ring
-    const int x_stride = DMA ? X_PAD : wres ? X_BYTES_ : BUF;                     // between the patch buffers
-    // Two items per barrier (round 4, `ipb` = wres_ bit 17; resident-filter forms whose LDS holds FOUR patch buffers): the roles meet
-    // after every second item; item `it` lives in patch buffer it & 3.  tools/micro/ws_interference.hip: the stride-1 nest alone, one
-    // workgroup barrier per 72 MFMAs, 1.65 us per item; one barrier per two items 1.43-1.55.
-    const int ipb = DMA ? 1 : 1 + ((wres_ >> 17) & 1);
-    const int nbuf_mask = wres && !DMA ? 2 * ipb - 1 : 1;                          // patch buffers - 1 (non-DMA forms)
-    const int w_base = DMA ? rd * X_PAD : (nbuf_mask + 1) * X_BYTES_;             // resident filter slabs
-    const int tab_off = DMA ? w_base + n_slabs_l * W_BYTES : wres ? w_base + n_slabs_l * W_BYTES : 2 * BUF;
+    const int x_stride = wres ? X_BYTES_ : BUF;                     // between the two patch buffers
+    const int w_base = 2 * X_BYTES_;                               // resident filter slabs
+    const int tab_off = wres ? w_base + n_slabs_l * W_BYTES : 2 * BUF;
     float* tab = reinterpret_cast<float*>(smem + tab_off);  // [a_scale | a_shift | b_scale | b_shift][c_red]
 
-    // wres_ bit 0: filter-resident form; bit 1: role map.  The hardware deals the eight waves of a workgroup round the four SIMDs
-    // (wave w -> SIMD w & 3).  Map 0 puts one producer and one consumer on every SIMD (all four matrix cores in use); map 1 puts
-    // the consumers on SIMDs 0-1 and the producers on SIMDs 2-3, so the staging VALU work never queues behind an MFMA.
+    // The hardware deals the eight waves of a workgroup round the four SIMDs (wave w -> SIMD w & 3): one producer and one consumer
+    // wave on every SIMD, all four matrix cores in use.
     const int hw_wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    const bool producer = TEAMS == 2 ? hw_wave >= 8 : role_map ? ((hw_wave >> 1) & 1) != 0 : hw_wave >= 4;
-    const int wave = TEAMS == 2 ? (hw_wave & 3) : role_map ? ((hw_wave & 1) | ((hw_wave >> 2) << 1)) : (hw_wave & 3);   // index within the role / team (0..3)
-    const int team = TEAMS == 2 && !producer ? hw_wave >> 2 : 0;
+    const bool producer = hw_wave >= 4;
+    const int wave = hw_wave & 3;   // index within the role (0..3)
     const int lane = threadIdx.x & 63, tid = wave * 64 + lane, c16 = tid & 3;
     const int half = lane >> 5, col = lane & 31;
     const int co_base = blockIdx.y * C_OUT;
@@ -1671,19 +1327,12 @@ __global__ __launch_bounds__(256 * (TEAMS + 1), (TEAMS == 2 ? 3 : 2)) void conv3
     constexpr bool CAN_STATS = G::ACC * NT <= 4 || FWD;  // register budget of the consumer waves
     const bool fuse_stats = !PS && !ACT && CAN_STATS && (a.stat_partials != nullptr || a.stat_acc != nullptr);   // forward: bn statistics of the output
     const bool fuse_bnred = !FWD && (PS || CAN_STATS) && (a.bnred_partials != nullptr || a.bnred_acc != nullptr);  // backward-data: dgamma / dbeta sums of the layer `out` belongs to
-    // PS = 4 / 5 (round 4): the PRODUCER waves issue the tile's global stores.  The consumers leave the final values in the epilogue
-    // buffer only (as PS = 1 does for the sums) and go straight back to the hand-over barrier; two items later a producer thread reads its
-    // chunks back — consecutive lanes hold consecutive 16-byte chunks, whole lines — and stores them.  4: the consumers keep the sums
-    // (as PS = 0); 5: the producers form them as well (as PS = 1).  In the plain-copy forms the producers wait at the barrier for a third
-    // to half of the kernel, and the instrumented build shows the consumers' epilogue as mostly stores waiting to be issued.
     constexpr bool PST = PS == 4 || PS == 5;
-    const int stat_mode = fuse_stats ? 1 : (fuse_bnred && PS != 1 && PS != 5) ? 2 : 0;   // sums kept by the CONSUMER waves (PS = 2: of the groups g < PS_G0)
-    const bool ps = (PS == 1 || PS == 2 || PS == 5) && fuse_bnred;         // sums kept by the producer waves (PS = 2: of the groups g >= PS_G0)
-    const bool pst = PST && (fuse_bnred || ACT);                           // global stores issued by the producer waves (also the plain-copy inference forms)
-    const bool pl = PS == 3 && fuse_bnred;                                 // y operands of the consumers' sums staged through LDS by the producer waves
-    constexpr int PS_G0 = PS == 2 ? G::ACC / 2 : 0, PS_GROUPS = G::ACC - PS_G0;   // the accumulator groups whose stored values go through the epilogue buffer
-    constexpr int E_BYTES = PS_GROUPS * 128 * 64 * NT;                     // epilogue buffer: PS_GROUPS x 128 pixel slots of NT x 64 bytes
-    constexpr int EK = 4 * NT, EQ_STEP = 256 / EK, ECH = PS_GROUPS * 128 / EQ_STEP;   // chunks per pixel; pixel slots between a thread's chunks; chunks per thread
+    const int stat_mode = fuse_stats ? 1 : (fuse_bnred && PS != 1 && PS != 5) ? 2 : 0;   // sums kept by the CONSUMER waves
+    const bool ps = (PS == 1 || PS == 5) && fuse_bnred;                    // sums kept by the producer waves
+    const bool pst = PST && fuse_bnred;                                    // global stores issued by the producer waves
+    constexpr int E_BYTES = G::ACC * 128 * 64 * NT;                        // epilogue buffer: ACC x 128 pixel slots of NT x 64 bytes
+    constexpr int EK = 4 * NT, EQ_STEP = 256 / EK, ECH = G::ACC * 128 / EQ_STEP;   // chunks per pixel; pixel slots between a thread's chunks; chunks per thread
     float est[16];   // PS: this producer thread's running sums (sum dz*y | sum dz of its 8 channels), reduced after the stat_mode reduction
     float* bnc = tab + c_red * 4;            // [scale | shift | mean | invstd][C_OUT] of this workgroup's channels
 
@@ -1715,9 +1364,6 @@ __global__ __launch_bounds__(256 * (TEAMS + 1), (TEAMS == 2 ? 3 : 2)) void conv3
                 bnc[C_OUT + i] = a.out_shift[co_base + i];
             }
         }
-        if constexpr (HEAD) {   // the 1x1 head's weights behind the tables: [channel][4 classes], zero beyond head_k (launch_ws adds the 512 bytes)
-            for (int i = threadIdx.x; i < 32 * 4; i += NTHR) bnc[4 * C_OUT + i] = (i & 3) < a.head_k ? a.head_w[(i >> 2) * a.head_k + (i & 3)] : 0.f;
-        }
         if (fuse_bnred) {
             for (int i = threadIdx.x; i < C_OUT; i += NTHR) {
                 bnc[i] = a.bnred_scale[co_base + i];
@@ -1728,94 +1374,7 @@ __global__ __launch_bounds__(256 * (TEAMS + 1), (TEAMS == 2 ? 3 : 2)) void conv3
         }
         __syncthreads();
     };
-    // ANH_WS_PRIO (experiment): 1 = the consumer (matrix) waves at s_setprio 1, 2 = the producer (staging) waves, 3 = consumers at 2 / producers at 1
-    if (prio == 1 && !producer) __builtin_amdgcn_s_setprio(1);
-    if (prio == 2 && producer) __builtin_amdgcn_s_setprio(1);
-    if (prio == 3) { if (producer) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2); }
-    if (producer && DMA) {
-      if constexpr (DMA) {
-        const bf16* wsrc = reinterpret_cast<const bf16*>(a.w_bf16);
-        const bf16* xa = reinterpret_cast<const bf16*>(a.src.a);
-        const bf16* zeros = reinterpret_cast<const bf16*>(a.zeros);
-        const size_t plane = (size_t)H * W * c_red;
-        // this lane's records: jj-th instruction of wave `wave` covers records (wave * 16 + 64 jj) .. + 15; the lane asks for chunk (lane & 3) ^ key
-        int pgeo[NP], pchunk[NP];
-#pragma unroll
-        for (int jj = 0; jj < NP; ++jj) {
-            const int rec = min((tid >> 2) + 64 * jj, G::RECS - 1);   // (records past the patch: any valid pixel, nobody reads them)
-            int py, px, key;
-            G::decode(rec, py, px, key);
-            pgeo[jj] = py | (px << 8);
-            pchunk[jj] = ((c16 ^ key) & 3) * 8;
-        }
-        const int per_img = tiles_x * tiles_y;
-        const int step_x = gstep % tiles_x, step_y = (gstep / tiles_x) % tiles_y, step_n = gstep / per_img;
-        int ftile = tile_first, fslab = 0;
-        int ftx = ftile % tiles_x, fty = (ftile / tiles_x) % tiles_y, fn = ftile / per_img;
-        int foff[NP];
-        unsigned fpok = 0;
-        auto enter_tile = [&]() __attribute__((always_inline)) {
-            const int x0 = G::in_x0(ftx), y0 = G::in_y0(fty);
-            fpok = 0;
-#pragma unroll
-            for (int jj = 0; jj < NP; ++jj) {
-                const int iy = y0 + (pgeo[jj] & 255), ix = x0 + (pgeo[jj] >> 8);
-                const int cy = min(max(iy, 0), H - 1), cx = min(max(ix, 0), W - 1);
-                foff[jj] = (cy * W + cx) * c_red + pchunk[jj];
-                fpok |= ((iy == cy && ix == cx) ? 1u : 0u) << jj;
-            }
-        };
-        int fit = 0;   // index of the item the cursor points at
-        auto issue = [&]() __attribute__((always_inline)) {   // the cursor's item -> ring slot fit % rd; advances the cursor
-            const bf16* pa = xa + (size_t)fn * plane + fslab * 32;
-            char* lbase = smem + (fit % rd) * X_PAD + wave * 1024;
-#pragma unroll
-            for (int jj = 0; jj < NP; ++jj) {
-                const bf16* g = ((fpok >> jj) & 1u) ? pa + foff[jj] : zeros + (lane & 3) * 8;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)(lbase + jj * 4096), 16, 0, 0);
-            }
-            ++fit;
-            if (++fslab == n_slabs) {
-                fslab = 0; ftile += gstep;
-                ftx += step_x; if (ftx >= tiles_x) { ftx -= tiles_x; ++fty; }
-                fty += step_y; if (fty >= tiles_y) { fty -= tiles_y; ++fn; }
-                fn += step_n;
-                if (ftile < n_tiles) enter_tile();
-            }
-        };
-        if (ftile < n_tiles) { enter_tile(); issue(); }                      // item 0
-        if (tile < n_tiles) {   // every filter slab to its own LDS block, once (through registers: a few KB from L2)
-            constexpr int NWd = (W_ITEMS + 255) / 256;
-            for (int sl = 0; sl < n_slabs; ++sl) {
-                u32x4 wr[NWd];
-#pragma unroll
-                for (int j = 0; j < NWd; ++j) {
-                    const int rec = min((tid >> 2) + 64 * j, 9 * C_OUT - 1);
-                    const int tl = rec / C_OUT, co = rec - tl * C_OUT;
-                    const int tap = flip ? 8 - tl : tl;
-                    wr[j] = *reinterpret_cast<const u32x4*>(wsrc + (tap * a.c_out + co_base + co) * c_red + c16 * 8 + sl * 32);
-                }
-#pragma unroll
-                for (int j = 0; j < NWd; ++j) {
-                    const int rec = (tid >> 2) + 64 * j;
-                    const int co = rec % C_OUT;
-                    if (rec < 9 * C_OUT) *reinterpret_cast<u32x4*>(smem + w_base + sl * W_BYTES + rec * 64 + ((c16 ^ ((co >> 2) & 3)) << 4)) = wr[j];
-                }
-            }
-        }
-        init_tables();
-        while (tile < n_tiles) {   // iteration `it`: hand item `it` over at its closing barrier
-            bool ahead = false;
-            if (rd == 3 && ftile < n_tiles) { issue(); ahead = true; }       // item it + 1 into the slot the consumers left at the last barrier
-            if (ahead) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");   // item it (issued one iteration ago) has landed; item it + 1 may still fly
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (rd == 2 && ftile < n_tiles) issue();                           // ring of two: item it + 1 goes into the slot item it - 1 just left
-            if (++slab == n_slabs) { slab = 0; tile += gstep; }
-            ++it;
-        }
-      }
-    } else if (producer) {
+    if (producer) {
         // The producers request their FIRST patch and the filter blocks before the tables are loaded and the workgroup meets:
         // those round trips overlap instead of adding up.
         const bf16* wsrc = reinterpret_cast<const bf16*>(a.w_bf16);
@@ -1824,7 +1383,6 @@ __global__ __launch_bounds__(256 * (TEAMS + 1), (TEAMS == 2 ? 3 : 2)) void conv3
         const size_t plane = (size_t)H * W * c_red;  // < 2^31 elements (host check)
         // ---- staging geometry, fixed per thread: patch chunk jj = record (tid >> 2) + 64 jj ----
         int pgeo[NP], pdst[NP];
-        unsigned imask = 0;   // materialised input (ConvArgs::act_out): the chunks of this thread that lie in the tile's interior
     #pragma unroll
         for (int jj = 0; jj < NP; ++jj) {
             const int rec = min((tid >> 2) + 64 * jj, G::RECS - 1);
@@ -1832,7 +1390,6 @@ __global__ __launch_bounds__(256 * (TEAMS + 1), (TEAMS == 2 ? 3 : 2)) void conv3
             G::decode(rec, py, px, key);
             pgeo[jj] = py | (px << 8);
             pdst[jj] = rec * 64 + ((c16 ^ key) << 4);
-            imask |= ((G::interior(py, px) && (tid >> 2) + 64 * jj < G::RECS) ? 1u : 0u) << jj;
         }
         // filter chunk j = record (tid >> 2) + 64 j = (tap slot, co); slot t holds tap t, or 8 - t for mirrored taps
         int wsrc_off[NW], wdst[NW];
@@ -1844,31 +1401,16 @@ __global__ __launch_bounds__(256 * (TEAMS + 1), (TEAMS == 2 ? 3 : 2)) void conv3
             wsrc_off[j] = (tap * a.c_out + co_base + co) * c_red + c16 * 8;
             wdst[j] = rec * 64 + ((c16 ^ ((co >> 2) & 3)) << 4);   // within a filter slab
         }
-        // ---- two items in flight.  Item k lives in register set k & 1; the loads of item k + 2 are issued right after item k is
-        // committed, so a load has a whole item period to arrive instead of the hand-over barrier alone (the producers used to
-        // spend their commit phase waiting for loads issued one barrier earlier: r02_sq_counters, SQ_WAIT_ANY 40-55 %) ----
-        // The filter slab of the NEXT item is fetched one item ahead into one shared register set: it comes from L2 (every workgroup
-        // reads the same filter), and a second set would cost 36 VGPRs at 64 output channels.  The skip-add kind on the 594-record
-        // patch keeps ONE patch set: two would spill.
-    #ifndef ANH_WS_DEEP2
-    #define ANH_WS_DEEP2 0
-    #endif
-        constexpr bool DEEP2 = ANH_WS_DEEP2 && !(KIND == SRC_ACT2 && NP > 6);
+        // ---- ONE item of loads in flight: the loads of item k + 1 are issued right after item k is committed, so a load has a whole
+        // item period to arrive (a second register set measured slower three times: rounds 2, 3, 4).  The filter slab of the NEXT item
+        // is fetched one item ahead into one shared register set: it comes from L2 (every workgroup reads the same filter). ----
         u32x4 wraw[NW];  // a native vector type: hipcc keeps a HIP uint4 that is only copied (never unpacked) in scratch
-        // MAT: the training-forward bn kinds of a geometry whose tiles partition the input also store what they stage (ConvArgs::act_out)
-        // (compiled out by default, -DANH_ACT_MATERIALIZE_BUILD=1: measured +2.2 % per step when used, and +1.1 % when merely present —
-        // the forward forms' register allocation changes)
-#ifndef ANH_ACT_MATERIALIZE_BUILD
-#define ANH_ACT_MATERIALIZE_BUILD 0
-#endif
-        constexpr bool MAT = ANH_ACT_MATERIALIZE_BUILD != 0 && ANH_WS_BUFFER_LOADS != 0 && FWD && !ACT && G::CAN_MATERIALIZE && (KIND == SRC_ACT || KIND == SRC_ACT2);
         struct Fetched {
             RawChunk<KIND> praw[NP];
             unsigned pok;
-            int poff[MAT ? NP : 1], n;   // MAT: the chunks' byte offsets within their image, and the image
         };
-        Fetched R0, R1;
-        // the fetch cursor runs two items ahead of the commits.  Its tile coordinates advance incrementally (no division per item)
+        Fetched R0;
+        // the fetch cursor runs ahead of the commits.  Its tile coordinates advance incrementally (no division per item)
         // and the chunk offsets / validity bits of its tile are computed once per tile, not once per (tile, slab) item.
         const int per_img = tiles_x * tiles_y;
         const int step_x = gstep % tiles_x, step_y = (gstep / tiles_x) % tiles_y, step_n = gstep / per_img;
@@ -1879,13 +1421,9 @@ __global__ __launch_bounds__(256 * (TEAMS + 1), (TEAMS == 2 ? 3 : 2)) void conv3
         // BUFFER loads — address = per-image descriptor (SGPRs) + a 32-bit byte offset computed once per tile (VGPR) + the slab's offset
         // (SGPR): no sign extension, no 64-bit add per load (3 VALU each before); a padding pixel's offset lies outside the descriptor, so
         // the load returns zeros by itself and the plain-copy kinds need neither clamped addresses nor a mask (5 VALU per chunk before).
-    #ifndef ANH_WS_BUFFER_LOADS
-    #define ANH_WS_BUFFER_LOADS 1
-    #endif
-        constexpr bool BUFL = ANH_WS_BUFFER_LOADS != 0;
-        constexpr bool NEED_MASK = !BUFL || KIND == SRC_ACT || KIND == SRC_ACT2;   // relu(0 * scale + shift) is not zero: the bn kinds zero their padding after the prologue
+        constexpr bool NEED_MASK = KIND == SRC_ACT || KIND == SRC_ACT2;   // relu(0 * scale + shift) is not zero: the bn kinds zero their padding after the prologue
         const int plane_bytes = (int)(unsigned)(plane * 2);   // (< 0xFFFFF000: host check, conv_plan)
-        int foff[NP];   // BUFL: byte offset within the image (0xFFFFF000 = padding); else element offset of the clamped pixel
+        int foff[NP];   // byte offset within the image (0xFFFFF000 = padding)
         unsigned fpok = 0;
         auto enter_tile = [&]() __attribute__((always_inline)) {
             const int x0 = G::in_x0(ftx), y0 = G::in_y0(fty);
@@ -1893,15 +1431,9 @@ __global__ __launch_bounds__(256 * (TEAMS + 1), (TEAMS == 2 ? 3 : 2)) void conv3
     #pragma unroll
             for (int jj = 0; jj < NP; ++jj) {
                 const int iy = y0 + (pgeo[jj] & 255), ix = x0 + (pgeo[jj] >> 8);
-                if constexpr (BUFL) {
-                    const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-                    foff[jj] = ok ? ((iy * W + ix) * c_red + c16 * 8) * 2 : (int)0xFFFFF000u;   // (+ the slab's offset: still outside the image)
-                    if constexpr (NEED_MASK) fpok |= (ok ? 1u : 0u) << jj;
-                } else {
-                    const int cy = min(max(iy, 0), H - 1), cx = min(max(ix, 0), W - 1);
-                    foff[jj] = (cy * W + cx) * c_red + c16 * 8;
-                    fpok |= ((iy == cy && ix == cx) ? 1u : 0u) << jj;
-                }
+                const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                foff[jj] = ok ? ((iy * W + ix) * c_red + c16 * 8) * 2 : (int)0xFFFFF000u;   // (+ the slab's offset: still outside the image)
+                if constexpr (NEED_MASK) fpok |= (ok ? 1u : 0u) << jj;
             }
         };
         auto fetch = [&](Fetched& R) __attribute__((always_inline)) {
@@ -1909,31 +1441,19 @@ __global__ __launch_bounds__(256 * (TEAMS + 1), (TEAMS == 2 ? 3 : 2)) void conv3
             const bf16* pb = (KIND == SRC_ACT2 || KIND == SRC_SUM2) ? xb + (size_t)fn * plane : nullptr;
             const int cc = fslab * 32;
             R.pok = fpok;
-            if constexpr (MAT) {
-                if (a.act_out) {   // (uniform: nothing of this runs in the default schedule)
-                    R.n = fn;
+            const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(pa), 0, plane_bytes, 0x00020000);
     #pragma unroll
-                    for (int jj = 0; jj < NP; ++jj) R.poff[jj] = foff[jj];
-                }
+            for (int jj = 0; jj < NP; ++jj) {
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ra, foff[jj], cc * 2, 0);
+                R.praw[jj].a = make_uint4(v[0], v[1], v[2], v[3]);
             }
-            if constexpr (BUFL) {
-                const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(pa), 0, plane_bytes, 0x00020000);
+            if constexpr (KIND == SRC_ACT2 || KIND == SRC_SUM2) {
+                const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(pb), 0, plane_bytes, 0x00020000);
     #pragma unroll
                 for (int jj = 0; jj < NP; ++jj) {
-                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ra, foff[jj], cc * 2, 0);
-                    R.praw[jj].a = make_uint4(v[0], v[1], v[2], v[3]);
+                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rb, foff[jj], cc * 2, 0);
+                    R.praw[jj].b = make_uint4(v[0], v[1], v[2], v[3]);
                 }
-                if constexpr (KIND == SRC_ACT2 || KIND == SRC_SUM2) {
-                    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(pb), 0, plane_bytes, 0x00020000);
-    #pragma unroll
-                    for (int jj = 0; jj < NP; ++jj) {
-                        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rb, foff[jj], cc * 2, 0);
-                        R.praw[jj].b = make_uint4(v[0], v[1], v[2], v[3]);
-                    }
-                }
-            } else {
-    #pragma unroll
-                for (int jj = 0; jj < NP; ++jj) R.praw[jj] = side_load_at<KIND>(pa, pb, foff[jj] + cc);
             }
             if (++fslab == n_slabs) {   // cursor -> the workgroup's next tile
                 fslab = 0; ftile += gstep;
@@ -1946,17 +1466,11 @@ __global__ __launch_bounds__(256 * (TEAMS + 1), (TEAMS == 2 ? 3 : 2)) void conv3
         const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(wsrc), 0, 9 * a.c_out * c_red * 2, 0x00020000);
         auto fetch_w = [&](int slab_) __attribute__((always_inline)) {
     #pragma unroll
-            for (int j = 0; j < NW; ++j) {
-                if constexpr (BUFL) wraw[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, wsrc_off[j] * 2, slab_ * 64, 0);
-                else wraw[j] = *reinterpret_cast<const u32x4*>(wsrc + wsrc_off[j] + slab_ * 32);
-            }
+            for (int j = 0; j < NW; ++j) wraw[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, wsrc_off[j] * 2, slab_ * 64, 0);
         };
         auto commit = [&](Fetched& R) __attribute__((always_inline)) {
-            char* lbuf = smem + (it & nbuf_mask) * x_stride;
+            char* lbuf = smem + (it & 1) * x_stride;
             char* wbuf = lbuf + X_BYTES_;     // streaming form only
-            const bool mat_on = MAT && a.act_out != nullptr && blockIdx.y == 0;   // (one workgroup group stores: the groups stage the same input)
-            const __amdgpu_buffer_rsrc_t mat_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-                reinterpret_cast<bf16*>(a.act_out) + (size_t)(MAT ? R.n : 0) * plane, 0, mat_on ? plane_bytes : 0, 0x00020000);
             // a single-slab layer's filter block goes into both buffers once (its registers are not refetched)
             const bool stage_w = !wres && (it < 2 || n_slabs > 1);
             float sa[8], ta[8], sb[8], tb[8];
@@ -1974,10 +1488,6 @@ __global__ __launch_bounds__(256 * (TEAMS + 1), (TEAMS == 2 ? 3 : 2)) void conv3
                 uint4 v = chunk_convert<KIND>(R.praw[jj], sa, ta, sb, tb);
                 if constexpr (NEED_MASK) { if (!((R.pok >> jj) & 1u)) v = make_uint4(0u, 0u, 0u, 0u); }
                 if ((tid >> 2) + 64 * jj < G::RECS) *reinterpret_cast<uint4*>(lbuf + pdst[jj]) = v;
-                if constexpr (MAT) {   // the activated input, once per pixel and channel: interior chunks only (padding offsets are dropped by the descriptor)
-                    if (mat_on && ((imask >> jj) & 1u))
-                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{v.x, v.y, v.z, v.w}, mat_rsrc, R.poff[jj], slab * 64, 0);
-                }
             }
             if (stage_w) {
     #pragma unroll
@@ -1995,12 +1505,11 @@ __global__ __launch_bounds__(256 * (TEAMS + 1), (TEAMS == 2 ? 3 : 2)) void conv3
             }
         }
         init_tables();
-        if (DEEP2 && ftile < n_tiles) fetch(R1);
-        // ---- PS: bn backward sums of the tile whose epilogue the consumers finished two items ago ----
+        // ---- PS: bn backward sums / global stores of the tile whose epilogue the consumers finished two items ago ----
         float esc[8], esh[8];
         const int ek = tid & (EK - 1), eq0 = tid / EK;   // this thread's chunk (channels 8 ek .. 8 ek + 7 of the workgroup's) and first pixel slot
         int hist1 = -1, hist2 = -1, hist1_it = 0, hist2_it = 0;   // tile (or -1) and item index of the last two items whose epilogue leaves a buffer
-        if (PS == 1 || PS == 2 || PS == 5) {
+        if (PS == 1 || PS == 5) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 esc[j] = bnc[ek * 8 + j]; esh[j] = bnc[C_OUT + ek * 8 + j];
@@ -2016,7 +1525,7 @@ __global__ __launch_bounds__(256 * (TEAMS + 1), (TEAMS == 2 ? 3 : 2)) void conv3
             for (int j = 0; j < ECH; ++j) {
                 const int q = eq0 + EQ_STEP * j;
                 size_t pix; bool valid;
-                G::out_pixel((q >> 7) + PS_G0, a, n, ty, tx, (q >> 5) & 3, q & 31, pix, valid);
+                G::out_pixel(q >> 7, a, n, ty, tx, (q >> 5) & 3, q & 31, pix, valid);
                 if (PS != 4) yv[j] = *reinterpret_cast<const u32x4*>(ylayer + pix * a.c_out + co_base + ek * 8);
                 if constexpr (PST) epix[j] = (unsigned)pix;   // (< 2^31 elements per tensor: host check) where this chunk's pixel is stored
                 evalid |= (valid ? 1u : 0u) << j;
@@ -2045,21 +1554,11 @@ __global__ __launch_bounds__(256 * (TEAMS + 1), (TEAMS == 2 ? 3 : 2)) void conv3
                 }
             }
         };
-        auto ystage = [&](int yit, const u32x4 (&yv)[ECH]) __attribute__((always_inline)) {   // PS = 3: this thread's y chunks of the item's tile -> epilogue buffer
-            char* eb = smem + e_off + (n_slabs == 1 ? (yit & 1) * E_BYTES : 0);
-#pragma unroll
-            for (int j = 0; j < ECH; ++j) {
-                const int q = eq0 + EQ_STEP * j;
-                *reinterpret_cast<u32x4*>(eb + q * (64 * NT) + ((ek ^ ebuf_swizzle<NT>(q)) << 4)) = yv[j];
-            }
-        };
         auto one_item = [&](Fetched& R) __attribute__((always_inline)) {
             u32x4 eyv[PS ? ECH : 1];
             unsigned evalid = 0;
             const int et = hist2, eit = hist2_it;
-            if constexpr (PS == 1 || PS == 2 || PST) { if ((ps || pst) && et >= 0) estat_begin(et, eyv, evalid); }
-            const bool ynow = PS == 3 && pl && slab == n_slabs - 1;   // the item the consumers' epilogue of `tile` follows
-            if constexpr (PS == 3) { if (ynow) estat_begin(tile, eyv, evalid); }
+            if constexpr (PS != 0) { if ((ps || pst) && et >= 0) estat_begin(et, eyv, evalid); }
             TICK();
             commit(R);
 #ifdef ANH_WS_PROFILE
@@ -2069,12 +1568,10 @@ __global__ __launch_bounds__(256 * (TEAMS + 1), (TEAMS == 2 ? 3 : 2)) void conv3
             TICK();
             if (ftile < n_tiles) fetch(R);
             if (!wres && n_slabs > 1 && (slab + 1 < n_slabs || tile + gstep < n_tiles)) fetch_w(slab + 1 < n_slabs ? slab + 1 : 0);
-            if constexpr (PS == 1 || PS == 2 || PST) { if ((ps || pst) && et >= 0) estat_end(eit, eyv, evalid); }
-            if constexpr (PS == 3) { if (ynow) ystage(it, eyv); }
+            if constexpr (PS != 0) { if ((ps || pst) && et >= 0) estat_end(eit, eyv, evalid); }
             TOCK(t_b);
             TICK();
-            // buffer `it` is full; the consumers are done with the buffer(s) the next item(s) go to.  ipb = 2: only behind odd items and the last one
-            if (ipb == 1 || (it & 1) || (slab == n_slabs - 1 && tile + gstep >= n_tiles)) __syncthreads();
+            __syncthreads();   // buffer `it` is full; the consumers are done with the buffer the next item goes to
             TOCK(t_c);
             hist2 = hist1; hist2_it = hist1_it;
             hist1 = slab == n_slabs - 1 ? tile : -1; hist1_it = it;
@@ -2085,18 +1582,12 @@ __global__ __launch_bounds__(256 * (TEAMS + 1), (TEAMS == 2 ? 3 : 2)) void conv3
         t_loop = wall_clock64();
         c_loop = clock64();
 #endif
-        while (tile < n_tiles) {
-            one_item(R0);
-            if (DEEP2) {
-                if (tile >= n_tiles) break;
-                one_item(R1);
-            }
-        }
+        while (tile < n_tiles) one_item(R0);
 #ifdef ANH_WS_PROFILE
         t_loop_end = wall_clock64();
         c_loop = clock64() - c_loop;
 #endif
-        if constexpr (PS == 1 || PS == 2 || PST) {
+        if constexpr (PS != 0) {
             if (ps || pst) {   // the last two items: the one before the last is ready, the last one after the consumers' closing barrier
                 u32x4 eyv[ECH];
                 unsigned evalid = 0;
@@ -2121,7 +1612,7 @@ __global__ __launch_bounds__(256 * (TEAMS + 1), (TEAMS == 2 ? 3 : 2)) void conv3
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) hw[s2][j][k] = (!ANH_HEAD_LDS_PK && k < a.head_k) ? a.head_w[(16 * s2 + 8 * half + j) * a.head_k + k] : 0.f;
+                    for (int j = 0; j < 8; ++j) hw[s2][j][k] = k < a.head_k ? a.head_w[(16 * s2 + 8 * half + j) * a.head_k + k] : 0.f;
             }
         }
         u32x4 old[FWD ? 1 : G::ACC][NT][2];   // prefetched old values of a read-modify-write destination (GeoUp)
@@ -2130,10 +1621,10 @@ __global__ __launch_bounds__(256 * (TEAMS + 1), (TEAMS == 2 ? 3 : 2)) void conv3
         // tile ahead: those of tile t + 1 are requested while tile t runs, so their latency is covered by a full item and
         // not by the MFMA phase alone (measured: 133 -> 120 us on the 32x64 stride-2 backward-data; the same depth for the
         // y operand of the stride-1 kernels measured slower, 93 -> 105 us, and is not compiled).
-        constexpr bool DEEP = !FWD && NT == 1 && G::RMW_PREFETCH, DEEP_Y = false;
-        u32x4 old_n[DEEP ? G::ACC : 1][NT][2], yraw_n[DEEP_Y ? G::ACC : 1][NT][2];
+        constexpr bool DEEP = !FWD && NT == 1 && G::RMW_PREFETCH;
+        u32x4 old_n[DEEP ? G::ACC : 1][NT][2];
         const bool rmw_any = !FWD && G::RMW_PREFETCH && a.out_accumulate;
-        const bool cons_bnred = fuse_bnred && PS != 1 && PS != 5;   // the consumers keep (some of) the bn backward sums (and fetch y for them, unless PS = 3)
+        const bool cons_bnred = fuse_bnred && PS != 1 && PS != 5;   // the consumers keep the bn backward sums (and fetch y for them)
         const bool pre_any = rmw_any || cons_bnred;
         auto prefetch_epilogue = [&](int t, auto& o, auto& y, bool want_old, bool want_y) __attribute__((always_inline)) {
             const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, n = t / (tiles_x * tiles_y);
@@ -2150,24 +1641,12 @@ __global__ __launch_bounds__(256 * (TEAMS + 1), (TEAMS == 2 ? 3 : 2)) void conv3
                     for (int s2 = 0; s2 < 2; ++s2) {
                         if constexpr (!FWD) {
                             if (want_old) o[g][nt][s2] = *reinterpret_cast<const u32x4*>(out + e0 + nt * 32 + 16 * s2);
-                            if (want_y && PS != 3 && (PS != 2 || g < PS_G0)) y[g][nt][s2] = *reinterpret_cast<const u32x4*>(yl + e0 + nt * 32 + 16 * s2);
+                            if (want_y) y[g][nt][s2] = *reinterpret_cast<const u32x4*>(yl + e0 + nt * 32 + 16 * s2);
                         }
                     }
             }
         };
-        if (DEEP && pre_any && tile < n_tiles) prefetch_epilogue(tile, old, yraw, rmw_any, cons_bnred && DEEP_Y);
-        // deferred stores (ACT forms without the head; `defer` = wres_ bit 5, a launch-time switch): see DeferredStores
-        // MEASURED (same-box A/B, three rounds): 4,320 -> 3,970 Mpx/s — the stores stall the in-order wave INSIDE its MFMA stream instead of
-        // behind it, and the second nest + 16-32 held registers take the stride-1 / up forms from 154-166 to 242 VGPRs.  Compiled out
-        // (-DANH_WS_DEFER_STORES_BUILD=1 brings it back, ANH_WS_DEFER_STORES=0/1 then switches it per process); labels bit-identical either way.
-#ifndef ANH_WS_DEFER_STORES_BUILD
-#define ANH_WS_DEFER_STORES_BUILD 0
-#endif
-        constexpr bool CAN_DEFER = ANH_WS_DEFER_STORES_BUILD && ACT && !HEAD && G::ACC * NT < 8;   // (eight accumulator tiles + sixteen deferred register sets do not fit: 336 spilled VGPRs)
-        constexpr int DS = CAN_DEFER ? G::ACC * NT * 2 : 1;
-        DeferredStores<DS> dst;
-        bool dpending = false;
-        const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)a.out_bytes, 0x00020000);
+        if (DEEP && pre_any && tile < n_tiles) prefetch_epilogue(tile, old, yraw, rmw_any, false);
         float stat[NT][2][16];      // per-lane running sums of this lane's 8 channels per (nt, s): see store_pixel_tiles_rmw
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
@@ -2176,17 +1655,11 @@ __global__ __launch_bounds__(256 * (TEAMS + 1), (TEAMS == 2 ? 3 : 2)) void conv3
 #pragma unroll
                 for (int e = 0; e < 16; ++e) stat[nt][s2][e] = 0.f;
         // filter fragments in registers (GeoS1, one channel tile, one reduction slab; wres_ bit 19 switches it off: ANH_WS_FILTER_REGS=0)
-#ifndef ANH_WS_FILTER_REGS_BUILD
-#define ANH_WS_FILTER_REGS_BUILD 1
-#endif
-        constexpr bool WREG = ANH_WS_FILTER_REGS_BUILD && std::is_same<G, GeoS1>::value && NT == 1 && !DMA && TEAMS == 1 && !CAN_DEFER;
+        constexpr bool WREG = std::is_same<G, GeoS1>::value && NT == 1;
         const bool wreg_on = WREG && n_slabs == 1 && !((wres_ >> 19) & 1);
         bf16x8 wreg[WREG ? 18 : 1];
-        // TEAMS = 2: this team's tiles are those of its parity in the workgroup's walk; the epilogue of a finished tile runs in the NEXT interval
-        // (the other team's MFMA phase); `pend_*`: that tile and the item index its epilogue belongs to
-        int tord = 0, pend_tile = -1, pend_it = 0;
         for (;;) {
-            // the epilogue of tile `et`, whose last item was `eit` (TEAMS = 1: right behind its MFMA phase)
+            // the epilogue of tile `et`, whose last item was `eit`: right behind its MFMA phase
             auto epilogue = [&](int et, int eit) __attribute__((always_inline)) {
                 const int tx = et % tiles_x, ty = (et / tiles_x) % tiles_y, n = et / (tiles_x * tiles_y);
                 const bool rmw = rmw_any;
@@ -2197,39 +1670,12 @@ __global__ __launch_bounds__(256 * (TEAMS + 1), (TEAMS == 2 ? 3 : 2)) void conv3
 #ifdef ANH_WS_PROFILE
                     if (prof_nostore) valid = false;
 #endif
-                    RowStore ts{nullptr, 0, 0, false, lane};
-                    if constexpr (ANH_WS_TSTORE_BUILD && G::TS_OK && !HEAD) {
-                        if (ts_off && !a.out_accumulate && !a.out2) {
-                            ts.stage = smem + ts_off + wave * (32 * 64 * NT);
-                            G::row_origin(g, a, n, ty, tx, wave, ts.row_pix0, ts.row_valid, ts.cols_valid);
-#ifdef ANH_WS_PROFILE
-                            if (prof_nostore) ts.row_valid = false;
-#endif
-                        }
-                    }
-                    if constexpr (HEAD) store_pixel_tiles_head(acc[g][0], a, pix, n, valid, half, bnc, C_OUT, hw, hbias, bnc + 4 * C_OUT);
-                    else if constexpr (ACT) {
-                        bool packed = false;
-                        if constexpr (CAN_DEFER) { if (defer) { pack_pixel_tiles_act<NT, DS>(acc[g], a, pix, valid, half, co_base, bnc, C_OUT, dst, g * NT * 2); packed = true; } }
-                        if (!packed) store_pixel_tiles_act<NT>(acc[g], a, pix, valid, half, co_base, bnc, C_OUT, ts,
-                                                                   pst ? smem + e_off + (n_slabs == 1 ? (eit & 1) * E_BYTES : 0) : nullptr, (g * 4 + wave) * 32 + col);
-                    }
+                    if constexpr (HEAD) store_pixel_tiles_head(acc[g][0], a, pix, n, valid, half, bnc, C_OUT, hw, hbias);
+                    else if constexpr (ACT) store_pixel_tiles_act<NT>(acc[g], a, pix, valid, half, co_base, bnc, C_OUT);
                     else {
-                        if constexpr (PS == 3) {   // the y operands of this group's sums: left in the epilogue buffer by the producer waves
-                            if (pl) {
-                                const char* eb = smem + e_off + (n_slabs == 1 ? (eit & 1) * E_BYTES : 0);
-                                const int q = (g * 4 + wave) * 32 + col;
-#pragma unroll
-                                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                                    for (int s2 = 0; s2 < 2; ++s2)
-                                        yraw[g][nt][s2] = *reinterpret_cast<const u32x4*>(eb + q * (64 * NT) + (((nt * 4 + 2 * s2 + half) ^ ebuf_swizzle<NT>(q)) << 4));
-                            }
-                        }
-                        const bool to_ebuf = (ps && g >= PS_G0) || pst;   // (compile-time per unrolled g) this group's sums are the producers' / its stores are
-                        store_pixel_tiles_rmw<NT>(acc[g], a, pix, valid, half, co_base, old[FWD ? 0 : g], rmw, stat, (PS == 2 && g >= PS_G0) ? 0 : stat_mode, yraw[FWD ? 0 : g], bnc,
-                                                  to_ebuf ? smem + e_off + (n_slabs == 1 ? (eit & 1) * E_BYTES : 0) : nullptr, ((g - PS_G0) * 4 + wave) * 32 + col,
-                                                  ts, !pst);
+                        const bool to_ebuf = ps || pst;   // this tile's sums are the producers' / its stores are
+                        store_pixel_tiles_rmw<NT>(acc[g], a, pix, valid, half, co_base, old[FWD ? 0 : g], rmw, stat, stat_mode, yraw[FWD ? 0 : g], bnc,
+                                                  to_ebuf ? smem + e_off + (n_slabs == 1 ? (eit & 1) * E_BYTES : 0) : nullptr, (g * 4 + wave) * 32 + col, !pst);
                     }
                 }
                 if constexpr (DEEP) {
@@ -2237,29 +1683,22 @@ __global__ __launch_bounds__(256 * (TEAMS + 1), (TEAMS == 2 ? 3 : 2)) void conv3
 #pragma unroll
                         for (int g = 0; g < G::ACC; ++g)
 #pragma unroll
-                            for (int s2 = 0; s2 < 2; ++s2) {
-                                old[g][0][s2] = old_n[g][0][s2];
-                                if constexpr (DEEP_Y) yraw[g][0][s2] = yraw_n[g][0][s2];
-                            }
+                            for (int s2 = 0; s2 < 2; ++s2) old[g][0][s2] = old_n[g][0][s2];
                     }
                 }
             };
-            if (tile >= n_tiles) {
-                if constexpr (TEAMS == 2) { if (pend_tile >= 0) epilogue(pend_tile, pend_it); }   // the tile this team finished in the workgroup's last interval(s)
-                break;
-            }
+            if (tile >= n_tiles) break;
             int ntile = tile, nslab = slab + 1;
             if (nslab == n_slabs) { nslab = 0; ntile += gstep; }
-            const bool mine = TEAMS == 1 || (tord & 1) == team;
-            const int boff = (DMA ? it % rd : (it & nbuf_mask)) * x_stride;
-            const int woff = (DMA || wres) ? w_base + slab * W_BYTES : boff + X_BYTES_;
+            const int boff = (it & 1) * x_stride;
+            const int woff = wres ? w_base + slab * W_BYTES : boff + X_BYTES_;
             typename G::Bases b;
 #pragma unroll
             for (int i = 0; i < G::NB; ++i)
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) b.x[i][ks] = b0.x[i][ks] + boff;
             const char* wb[2] = {wb0[0] + woff, wb0[1] + woff};
-            if (slab == 0 && mine) {
+            if (slab == 0) {
 #pragma unroll
                 for (int g = 0; g < G::ACC; ++g)
 #pragma unroll
@@ -2268,38 +1707,22 @@ __global__ __launch_bounds__(256 * (TEAMS + 1), (TEAMS == 2 ? 3 : 2)) void conv3
                         for (int r = 0; r < 16; ++r) acc[g][nt][r] = 0.f;
             }
             TICK();
-            if (ipb == 1 || !(it & 1)) __syncthreads();  // buffer `it` (ipb = 2: and it + 1) is full
+            __syncthreads();  // buffer `it` is full
             TOCK(t_c);
             TICK();
             const bool last_slab = slab == n_slabs - 1;
-            if constexpr (TEAMS == 2) {
-                if (!mine) {   // the other team's MFMA phase: this team's finished tile leaves now
-                    if (pend_tile >= 0) { epilogue(pend_tile, pend_it); pend_tile = -1; }
-                    TOCK(t_b);
-                    if (nslab == 0) ++tord;
-                    tile = ntile; slab = nslab; ++it;
-                    continue;
-                }
-            }
             if (pre_any && last_slab) {  // epilogue operands travel while the MFMAs run
                 if constexpr (DEEP) {
-                    if (tile + gstep < n_tiles) prefetch_epilogue(tile + gstep, old_n, yraw_n, rmw_any, cons_bnred && DEEP_Y);
-                    if constexpr (!DEEP_Y) prefetch_epilogue(tile, old, yraw, false, cons_bnred);
+                    if (tile + gstep < n_tiles) prefetch_epilogue(tile + gstep, old_n, yraw, rmw_any, false);
+                    prefetch_epilogue(tile, old, yraw, false, cons_bnred);
                 } else prefetch_epilogue(tile, old, yraw, rmw_any, cons_bnred);
             }
-            // TEAMS = 2: the team in its MFMA phase outranks the team in its epilogue at the SIMD's issue arbiter (bit 18 of wres_ switches it off)
-            if constexpr (TEAMS == 2) { if (!((wres_ >> 18) & 1)) __builtin_amdgcn_s_setprio(3); }
             if constexpr (WREG) {
                 if (wreg_on) {
                     if (it == 0) G::load_filter_regs(wreg, wb);   // (the filter block of a single-slab layer is in both patch buffers from items 0 / 1 on)
                     G::mfma_wreg(acc, b, wreg);
                 } else G::template mfma<NT>(acc, b, wb);
-            } else
-            if constexpr (CAN_DEFER) {
-                if (dpending) { G::template mfma<NT>(acc, b, wb, StoreHook<DS>{dst, out_rsrc}); dpending = false; }
-                else G::template mfma<NT>(acc, b, wb);
             } else G::template mfma<NT>(acc, b, wb);
-            if constexpr (TEAMS == 2) { if (!((wres_ >> 18) & 1)) __builtin_amdgcn_s_setprio(0); }
 #ifdef ANH_WS_PROFILE
             __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -2312,20 +1735,14 @@ __global__ __launch_bounds__(256 * (TEAMS + 1), (TEAMS == 2 ? 3 : 2)) void conv3
             TOCK(t_d);
 #endif
             TICK();
-            if (last_slab) {
-                if constexpr (TEAMS == 2) { pend_tile = tile; pend_it = it; }
-                else epilogue(tile, it);
-            }
-            if constexpr (CAN_DEFER) { if (defer && last_slab) dpending = true; }
+            if (last_slab) epilogue(tile, it);
             TOCK(t_b);
-            if (nslab == 0) ++tord;
             tile = ntile; slab = nslab; ++it;
         }
-        if constexpr (CAN_DEFER) { if (dpending) flush_deferred<DS>(dst, out_rsrc); }
-        if constexpr (PS == 1 || PS == 2 || PST) { if (ps || pst) __syncthreads(); }   // the consumers' closing barrier: the last tile's epilogue buffer is complete
+        if constexpr (PS != 0) { if (ps || pst) __syncthreads(); }   // the consumers' closing barrier: the last tile's epilogue buffer is complete
         if (stat_mode) {
             __syncthreads();  // (matched by the producers) every wave is done with the staging buffers
-            float* red = reinterpret_cast<float*>(smem) + (size_t)((team * 4 + wave) * 64 + lane) * (32 * NT);
+            float* red = reinterpret_cast<float*>(smem) + (size_t)(wave * 64 + lane) * (32 * NT);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -2341,33 +1758,31 @@ __global__ __launch_bounds__(256 * (TEAMS + 1), (TEAMS == 2 ? 3 : 2)) void conv3
         // 512 / (64 NT) adjacent threads shares one sum (strided columns, then an xor-shuffle tree)
         constexpr int GRP = 512 / (64 * NT);   // 8 or 4 threads per sum
         const int t = threadIdx.x / GRP, part = threadIdx.x % GRP;
-        if (TEAMS == 1 || threadIdx.x < 512) {   // (TEAMS = 2: eight consumer waves' partials, the first 512 threads fold them)
-            const int ch = t >> 1, which = t & 1;
-            const int nt = ch >> 5, s2 = (ch >> 4) & 1, hf = (ch >> 3) & 1, j = ch & 7;
-            const float* red = reinterpret_cast<const float*>(smem);
-            double sum = 0.0;
+        const int ch = t >> 1, which = t & 1;
+        const int nt = ch >> 5, s2 = (ch >> 4) & 1, hf = (ch >> 3) & 1, j = ch & 7;
+        const float* red = reinterpret_cast<const float*>(smem);
+        double sum = 0.0;
 #pragma unroll 4
-            for (int e = part; e < 128 * TEAMS; e += GRP) {
-                const int w = e >> 5, c = e & 31;
-                sum += (double)red[(size_t)(w * 64 + hf * 32 + c) * (32 * NT) + (nt * 2 + s2) * 16 + which * 8 + j];
-            }
+        for (int e = part; e < 128; e += GRP) {
+            const int w = e >> 5, c = e & 31;
+            sum += (double)red[(size_t)(w * 64 + hf * 32 + c) * (32 * NT) + (nt * 2 + s2) * 16 + which * 8 + j];
+        }
 #pragma unroll
-            for (int off = 1; off < GRP; off <<= 1) sum += __shfl_xor(sum, off, 64);
-            if (stat_mode == 2) {   // (sum dz*y, sum dz) of a channel sit in adjacent thread groups: -> (sum dz*xhat, sum dz)
-                const double sum_dz = __shfl_down(sum, GRP, 64);
-                if (which == 0) sum = (double)bnc[3 * C_OUT + ch] * (sum - (double)bnc[2 * C_OUT + ch] * sum_dz);
-            }
-            if (part == 0) {
-                long long* table = fuse_stats ? a.stat_acc : a.bnred_acc;
-                double* dst = fuse_stats ? a.stat_partials : a.bnred_partials;
-                if (table) bnacc_add(table, (fuse_stats ? BNACC_SUM_Y : BNACC_SUM_DZ_XHAT) + which, a.c_out, co_base + ch, sum);
-                else dst[((size_t)(co_base + ch) * 2 + which) * gridDim.x + blockIdx.x] = sum;
-            }
+        for (int off = 1; off < GRP; off <<= 1) sum += __shfl_xor(sum, off, 64);
+        if (stat_mode == 2) {   // (sum dz*y, sum dz) of a channel sit in adjacent thread groups: -> (sum dz*xhat, sum dz)
+            const double sum_dz = __shfl_down(sum, GRP, 64);
+            if (which == 0) sum = (double)bnc[3 * C_OUT + ch] * (sum - (double)bnc[2 * C_OUT + ch] * sum_dz);
+        }
+        if (part == 0) {
+            long long* table = fuse_stats ? a.stat_acc : a.bnred_acc;
+            double* dst = fuse_stats ? a.stat_partials : a.bnred_partials;
+            if (table) bnacc_add(table, (fuse_stats ? BNACC_SUM_Y : BNACC_SUM_DZ_XHAT) + which, a.c_out, co_base + ch, sum);
+            else dst[((size_t)(co_base + ch) * 2 + which) * gridDim.x + blockIdx.x] = sum;
         }
     }
-    if constexpr (PS == 1 || PS == 2 || PS == 5) {
+    if constexpr (PS == 1 || PS == 5) {
         if (ps) {   // the producers' 16 sums per thread -> (channel, which) = 64 NT sums, each over the 256 / EK threads that own the chunk, fixed order, in double
-            __syncthreads();   // every wave is done with the staging buffers (and with the consumers' reduction above, PS = 2)
+            __syncthreads();   // every wave is done with the staging buffers
             if (producer) {
                 float* redw = reinterpret_cast<float*>(smem) + (size_t)tid * 16;
 #pragma unroll
@@ -2397,7 +1812,7 @@ __global__ __launch_bounds__(256 * (TEAMS + 1), (TEAMS == 2 ? 3 : 2)) void conv3
     if (fuse_bnred && a.bnred_acc) bnacc_finish_backward(a.bnred_finish, (int)(gridDim.x * gridDim.y));
 #ifdef ANH_WS_PROFILE
     if (prof && lane == 0) {
-        long long* o = prof + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * (4 * TEAMS + 4) + (producer ? 4 * TEAMS : 4 * team) + wave) * 8;
+        long long* o = prof + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (producer ? 4 : 0) + wave) * 8;
         o[0] = t_a; o[1] = t_b; o[2] = t_c; o[3] = producer ? c_loop : it; o[4] = t_entry; o[5] = producer ? t_loop : t_d + (prof_sink == 12345.f ? 1 : 0); o[6] = t_loop_end; o[7] = wall_clock64();
     }
 #endif
@@ -2407,9 +1822,9 @@ __global__ __launch_bounds__(256 * (TEAMS + 1), (TEAMS == 2 ? 3 : 2)) void conv3
 
 int ws_target_wgs();
 
-// LDS layout of a persistent conv launch and whether it takes the producer-side form of the fused bn backward sums (PS).
+// LDS layout of a persistent conv launch and whether it takes a producer-side form of the fused bn backward sums / stores (PS).
 // with_bnred: the sums are wanted (conv_fused_bnred_blocks asks before ConvArgs::bnred_* are set).
-struct WsLayout { int wres; size_t lds; int ps /* 0 consumer-side sums, 1 producer-side, 2 split by accumulator group, ... */; int e_off; int ipb = 1; int teams = 1; };
+struct WsLayout { int wres; size_t lds; int ps /* 0, 1 (producer sums), 4 (producer stores), 5 (both) */; int e_off; };
 WsLayout ws_layout(const ConvArgs& a, int recs, int acc, int nt, bool with_bnred) {
     const size_t tables = (size_t)a.c_red * 16 + (size_t)nt * 32 * 16;
     const size_t x_bytes = (size_t)recs * 64, w_bytes = (size_t)9 * nt * 32 * 64;
@@ -2421,72 +1836,27 @@ WsLayout ws_layout(const ConvArgs& a, int recs, int acc, int nt, bool with_bnred
     WsLayout L{};
     L.wres = resident_on && n_slabs >= 2 && resident_lds <= 160 * 1024 && 2 * x_bytes + (size_t)n_slabs * w_bytes >= (size_t)32 * 1024 * nt;
     L.lds = L.wres ? resident_lds : 2 * (x_bytes + w_bytes) + tables;
-    // Two consumer teams (TEAMS = 2 in the kernel; ANH_WS_TEAMS: 0 off, 1 every form that has one, 2 inference forms only, 3 training forms
-    // only, 4 training forward forms only): the forms whose waves fit 168 VGPRs — inference: stride-1 at 32 and 64 output channels, the up conv at 32; training: the
-    // stride-1 conv at 32 channels, forward and backward-data.  They keep every sum in the consumer waves (PS = 0) and meet after every item;
-    // with sums, the closing reduction borrows 64 NT KiB from the start of the buffer.
-    {
-        static const int teams_env = getenv("ANH_WS_TEAMS") ? atoi(getenv("ANH_WS_TEAMS")) : 0;
-        const bool infer = a.out_scale != nullptr, s1 = recs == 340, up = recs == 165;
-        bool teams = false;
-        if (infer) teams = (teams_env == 1 || teams_env == 2) && (s1 || (up && nt == 1)) && (a.src.kind == SRC_RAW || a.src.kind == SRC_SUM2);
-        else {
-            const bool fwd = (a.stat_partials || a.stat_acc) && !with_bnred && !a.out_accumulate && !a.out2;
-            teams = (teams_env == 1 || teams_env == 3 || (teams_env == 4 && fwd)) && s1 && nt == 1 && L.lds - tables >= (size_t)64 * 1024 * nt &&
-                    (fwd ? (a.src.kind == SRC_RAW || a.src.kind == SRC_ACT || a.src.kind == SRC_ACT2) : a.src.kind == SRC_RAW);
-        }
-        if (teams) { L.teams = 2; return L; }
-    }
-    // Producer-side bn backward sums (the PS forms): plain-copy staging with the fused reduction, when the epilogue buffer fits —
-    // one buffer of ACC x 128 pixel slots, two (alternating by item) for single-slab layers whose every item ends a tile.  A
-    // single-slab layer may take the resident layout to make room (one filter block instead of a copy per patch buffer; whatever
-    // ANH_WS_WEIGHT_RESIDENT says — which waves keep the sums must not depend on a tuning switch, the summation order follows it).
-    // Measured (same-box A/B): a gain only where the consumers' epilogue is the long pole AND the producers' own work is
-    // small — the four-accumulator-group geometry (stride-2 con backward-data, 32 output channels: 119 -> 108 us); the stride-1 and
-    // down geometries get slower (32->32: 99 -> 117 us: their producers become the long pole).  ANH_WS_PSTAT: 0 off, 1 (default) the
-    // four-group geometry only, 2 every form that fits.
-    // Round 4: ANH_WS_PSTAT 3 / 4 = the SPLIT form (PS = 2 in the kernel: consumers keep the sums of half the accumulator groups, producers
-    // of the other half) for the stride-1 geometry (3), and for the four-group geometry at 32 channels as well (4); everything else as 1.
-    // Default 7 (round 4): the plain-copy forms' global stores are issued by the producer waves (PS = 4 / 5) — bit-identical to 1 (the same
-    // values, the same sums by the same waves), five same-box rounds 1.7356 / 1.7400 / 1.7374 / 1.7360 / 1.7383 -> 1.7264 / 1.7179 / 1.7178 /
-    // 1.7224 / 1.7187 ms per step (-1.0 %; the 64->32 stride-2 backward-data conv 66 -> 58 us, the 32->64 one 109 -> 105).
+    // Producer-side forms: plain-copy staging with the fused reduction, when the epilogue buffer fits — one buffer of ACC x 128 pixel
+    // slots, two (alternating by item) for single-slab layers whose every item ends a tile.  A single-slab layer may take the resident
+    // layout to make room (one filter block instead of a copy per patch buffer; whatever ANH_WS_WEIGHT_RESIDENT says — which waves keep
+    // the sums must not depend on a tuning switch, the summation order follows it).
+    // ANH_WS_PSTAT: 7 (default) = the producer waves issue the global stores: consumer sums (PS = 4) for the stride-1 / down geometries,
+    // producer sums + stores (PS = 5) for the four-group geometry at 32 channels (at 64 it spills: PS = 1, producer sums only);
+    // 8 = the same with the four-group geometry as in round 3 (PS = 1); 1 = round 3's default (PS = 1 for the four-group geometry, the
+    // consumers keep sums and stores elsewhere).  All three are bit-identical (tests/test_gpu_schedules.py).  Measured, same box:
+    // 1 -> 7: 1.7356 / 1.7400 / 1.7374 / 1.7360 / 1.7383 -> 1.7264 / 1.7179 / 1.7178 / 1.7224 / 1.7187 ms per step (-1.0 %).
     static const int ps_env = getenv("ANH_WS_PSTAT") ? atoi(getenv("ANH_WS_PSTAT")) : 7;
-    const bool can_split = acc >= 2 && acc * nt <= 4;   // the consumers must be able to hold per-lane sums (CAN_STATS in the kernel)
     int mode = 0;
-    if (ps_env == 2) mode = 1;
-    else if (ps_env == 1) mode = acc == 4 ? 1 : 0;
-    else if (ps_env == 3) mode = acc == 4 ? 1 : (can_split ? 2 : 0);
-    else if (ps_env == 4) mode = can_split ? 2 : (acc == 4 ? 1 : 0);
-    else if (ps_env == 5) mode = acc == 4 ? 1 : (acc * nt <= 4 ? 3 : 0);   // y through LDS (PS = 3) for the stride-1 and down geometries, the four-group geometry as 1
-    else if (ps_env == 6) mode = acc * nt <= 4 ? 3 : (acc == 4 ? 1 : 0);    // ... and for the four-group geometry at 32 channels
-    else if (ps_env == 7) mode = acc == 4 ? (nt == 1 ? 5 : 1) : (acc * nt <= 4 ? 4 : 0);   // producer-issued stores: consumer sums (4) for stride-1 / down, producer sums + stores (5) for the four-group geometry at 32 channels (at 64 it spills 18 VGPRs: stays 1)
-    else if (ps_env == 8) mode = acc == 4 ? 1 : (acc * nt <= 4 ? 4 : 0);    // ... the four-group geometry left as 1
-    const int e_groups = mode == 2 ? acc - acc / 2 : acc;
-    const size_t e_total = (size_t)e_groups * 128 * 64 * nt * (n_slabs == 1 ? 2 : 1);
-    // inference (activation-storing, plain-copy forms without the head): producer-issued stores too, where the epilogue buffer fits
-    // (ANH_WS_INFER_PSTORE, default 1)
-    // MEASURED: for every such form 4,245 -> 4,097 Mpx/s (-3.5 %: in inference the producers are the busier role); 0 = off (default),
-    // 1 = every form, 2 = the four-group geometry at 32 channels only, 3 = the stride-1 form at 64 -> 64 only, 4 = both of those
-    static const int infer_pstore = getenv("ANH_WS_INFER_PSTORE") ? atoi(getenv("ANH_WS_INFER_PSTORE")) : 0;
-    const bool up32 = acc == 4 && nt == 1, s1_64 = acc == 2 && nt == 2 && n_slabs == 2;
-    const bool pstore_here = infer_pstore == 1 || (infer_pstore == 2 && up32) || (infer_pstore == 3 && s1_64) || (infer_pstore == 4 && (up32 || s1_64));
-    if (pstore_here && a.out_scale && !a.head_out && a.src.kind == SRC_RAW && !a.out2 && !a.out_accumulate) {
-        const size_t e_inf = (size_t)acc * 128 * 64 * nt * (n_slabs == 1 ? 2 : 1);
-        if (L.lds + e_inf <= 160 * 1024) { L.ps = 4; L.e_off = (int)((L.lds + 15) / 16 * 16); L.lds = (size_t)L.e_off + e_inf; return L; }
-    }
+    if (ps_env == 1) mode = acc == 4 ? 1 : 0;
+    else if (ps_env == 8) mode = acc == 4 ? 1 : (acc * nt <= 4 ? 4 : 0);
+    else mode = acc == 4 ? (nt == 1 ? 5 : 1) : (acc * nt <= 4 ? 4 : 0);
+    const size_t e_total = (size_t)acc * 128 * 64 * nt * (n_slabs == 1 ? 2 : 1);
     if (mode && with_bnred && a.src.kind == SRC_RAW && !a.out_scale && !a.stat_partials && !a.stat_acc) {
         if (L.lds + e_total <= 160 * 1024) L.ps = mode;
         else if (n_slabs == 1 && resident_lds + e_total <= 160 * 1024 && resident_lds - tables >= 16 * 1024) { L.wres = 1; L.lds = resident_lds; L.ps = mode; }
     }
     L.e_off = L.ps ? (int)((L.lds + 15) / 16 * 16) : 0;
     if (L.ps) L.lds = (size_t)L.e_off + e_total;
-    // two items per barrier (ANH_WS_IPB=2; default 1): every filter slab resident beside FOUR patch buffers, no epilogue buffer in use.
-    // MEASURED (four rounds): training 1.7241 -> 1.7311 ms, inference 4,293 -> 4,164 Mpx/s (-3 %) — although the nest alone gains 5-13 % from
-    // it in tools/micro/ws_interference.hip: with real producers a hand-over every second item lets the roles drift two items apart and the
-    // consumers wait longer at each meeting than they save.  Off; kept as a tested form.
-    static const int ipb_env = getenv("ANH_WS_IPB") ? atoi(getenv("ANH_WS_IPB")) : 1;
-    const size_t four = 4 * x_bytes + (size_t)n_slabs * w_bytes + tables;
-    if (ipb_env == 2 && !L.ps && resident_on && four <= 160 * 1024) { L.wres = 1; L.ipb = 2; L.lds = four; }
     return L;
 }
 
@@ -2496,50 +1866,28 @@ void launch_ws(const ConvArgs& a, int tiles_x, int tiles_y, int flip, hipStream_
     const dim3 grid((unsigned)std::max(1, std::min(n_tiles, ws_target_wgs() / groups)), (unsigned)groups);
     const WsLayout lay = ws_layout(a, G::RECS, G::ACC, NT, a.bnred_partials != nullptr || a.bnred_acc != nullptr);
     const int wres = lay.wres;
-    size_t lds = lay.lds;
-    // ANH_WS_TSTORE (1): transposed stores (RowStore) — four wave-private LDS strips of 32 pixels x 64 NT bytes behind everything else,
-    // where they fit; the strips' offset rides in the upper bits of the kernel's e_off argument
-    static const int ts_env = getenv("ANH_WS_TSTORE") ? atoi(getenv("ANH_WS_TSTORE")) : 1;
-    int ts_off = 0;
-    if (ANH_WS_TSTORE_BUILD && ts_env && G::TS_OK && !a.head_out && !a.out_accumulate && !a.out2 && a.out_dtype == DT_BF16) {
-        const size_t at = (lds + 15) / 16 * 16, strips = (size_t)4 * 32 * 64 * NT;
-        if (at + strips <= 160 * 1024) { ts_off = (int)at; lds = at + strips; }
-    }
-    const int e_off = lay.e_off | ((ts_off >> 4) << 18);
-    static const int teams_prio_env = getenv("ANH_WS_TEAMS_PRIO") ? atoi(getenv("ANH_WS_TEAMS_PRIO")) : 1;
+    const size_t lds = lay.lds;
+    const int e_off = lay.e_off;
     static const int filter_regs_env = getenv("ANH_WS_FILTER_REGS") ? atoi(getenv("ANH_WS_FILTER_REGS")) : 1;
-    int extra_bits = ((lay.ipb == 2) << 17) | ((teams_prio_env ? 0 : 1) << 18) | ((filter_regs_env ? 0 : 1) << 19);   // (bit 16: the DMA form's patch ring has three slots; bit 17: two items per barrier; bit 18: two teams without the MFMA phase's priority)
     const int ps = lay.ps;
-    // ANH_WS_ROLE_MAP: 0 = one producer + one consumer per SIMD, 1 = consumers on SIMDs 0-1 / producers on SIMDs 2-3, 2 = map 1 for the
-    // 32-output-channel kernels only (their MFMA phase is short; the 64-channel kernels need all four matrix cores)
-    static const int role_env = getenv("ANH_WS_ROLE_MAP") ? atoi(getenv("ANH_WS_ROLE_MAP")) : 0;
-    static const int prio_env = getenv("ANH_WS_PRIO") ? atoi(getenv("ANH_WS_PRIO")) : 0;
     // ANH_WS_XCD_BANDS (1): the workgroups of one XCD walk one contiguous eighth of the tile list (see the kernel); 0 = strided walk
     static const int bands_env = getenv("ANH_WS_XCD_BANDS") ? atoi(getenv("ANH_WS_XCD_BANDS")) : 1;
     const int bands = bands_env && grid.x % 8 == 0 && grid.x >= 8 ? 1 : 0;
-    // ANH_WS_DEFER_STORES (1): the activation-storing (inference) forms issue a tile's stores inside the next item's MFMA nest; needs the
-    // output tensor below 4 GiB (32-bit buffer offsets; an offset of 0xFFFFFFF0 must lie outside it)
-    static const int defer_env = getenv("ANH_WS_DEFER_STORES") ? atoi(getenv("ANH_WS_DEFER_STORES")) : 1;
-    const unsigned long long out_bytes = (unsigned long long)a.n * a.h_out * a.w_out * a.c_out * 2ull;
-    const int defer = ANH_WS_DEFER_STORES_BUILD && defer_env && a.out_scale && !a.head_out && G::ACC * NT < 8 && out_bytes < 0xFFFFFF00ull ? 1 : 0;
-    ConvArgs a2 = a;
-    a2.out_bytes = (unsigned)std::min<unsigned long long>(out_bytes, 0xFFFFFF00ull);
-    static const int stagger_env = getenv("ANH_WS_STAGGER") ? atoi(getenv("ANH_WS_STAGGER")) & 0xff : 0;
-    const int role_map = (role_env == 1 || (role_env == 2 && NT == 1) ? 1 : 0) | ((prio_env & 3) << 1) | (bands << 3) | (defer << 4) | (stagger_env << 7);
-    auto launch = [&](auto kernel, unsigned threads = 512) {
-        const dim3 block(threads);
+    const int flags = wres | (bands << 4) | ((filter_regs_env ? 0 : 1) << 19);   // (bit 6: the profiling build's no-store run)
+    auto launch = [&](auto kernel) {
+        const dim3 block(512);
         ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), lds);
 #ifndef ANH_WS_PROFILE
-        hipLaunchKernelGGL(kernel, grid, block, lds, s, a2, tiles_x, tiles_y, flip, (long long*)nullptr, wres | (role_map << 1) | extra_bits, e_off);
+        hipLaunchKernelGGL(kernel, grid, block, lds, s, a, tiles_x, tiles_y, flip, (long long*)nullptr, flags, e_off);
 #else
         static const int prof_on = getenv("ANH_WS_PROF") ? atoi(getenv("ANH_WS_PROF")) : 0;
         static long long* prof = nullptr;
         if (prof_on && !prof) HIP_CHECK(hipMalloc(&prof, 1024 * 12 * 8 * sizeof(long long)));
         static const int nostore = getenv("ANH_WS_PROF_NOSTORE") ? atoi(getenv("ANH_WS_PROF_NOSTORE")) : 0;
-        hipLaunchKernelGGL(kernel, grid, block, lds, s, a2, tiles_x, tiles_y, flip, prof_on ? prof : nullptr, wres | (role_map << 1) | (nostore << 6) | extra_bits, e_off);
+        hipLaunchKernelGGL(kernel, grid, block, lds, s, a, tiles_x, tiles_y, flip, prof_on ? prof : nullptr, flags | (nostore << 6), e_off);
         if (prof_on) {
             HIP_CHECK(hipStreamSynchronize(s));
-            const int nwg = grid.x * grid.y, nw = (int)threads / 64, nc = nw - 4;   // waves per workgroup, consumer waves among them
+            const int nwg = grid.x * grid.y, nw = 8, nc = 4;   // waves per workgroup, consumer waves among them
             std::vector<long long> h((size_t)nwg * nw * 8);
             HIP_CHECK(hipMemcpy(h.data(), prof, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
             double pa = 0, pb = 0, pc = 0, ca = 0, cb = 0, cc = 0, cd = 0, items = 0;
@@ -2551,7 +1899,6 @@ void launch_ws(const ConvArgs& a, int tiles_x, int tiles_y, int flip, hipStream_
                 for (int v = nc; v < nw; ++v) { pa += h[(w * nw + v) * 8]; pb += h[(w * nw + v) * 8 + 1]; pc += h[(w * nw + v) * 8 + 2]; }
                 items += h[(w * nw) * 8 + 3];
             }
-            ca *= 4.0 / nc; cb *= 4.0 / nc; cc *= 4.0 / nc; cd *= 4.0 / nc;   // per consumer wave (two teams: each runs the MFMA phase of every second tile)
             for (int w = 0; w < nwg; ++w)
                 for (int v = nc; v < nw; ++v) {   // producer waves carry the loop stamps
                     const long long* o = &h[(w * nw + v) * 8];
@@ -2566,98 +1913,44 @@ void launch_ws(const ConvArgs& a, int tiles_x, int tiles_y, int flip, hipStream_
         }
 #endif
     };
-    // the forward-only form exists where it buys something: four accumulator groups at NT = 2 (cont forward), whose bn
-    // statistics sums take the registers the backward forms spend on prefetched epilogue operands
     if (a.out_scale) {   // inference: activation-storing epilogue, plain-copy (or skip-add) staging
         ANH_REQUIRE(a.out_shift && !a.stat_partials && !a.bnred_partials && !a.stat_acc && !a.bnred_acc && !a.out_accumulate && !a.out2, "conv_ws: the activation-storing form takes no training epilogue");
         if (a.head_out) {   // the layer under the 1x1 head: logits instead of the activation
-            lds += 512;     // the head's weight table behind the bn tables (kernel: bnc + 4 C_OUT)
             if constexpr (std::is_same<G, GeoS1>::value && NT == 1) {
                 ANH_REQUIRE(conv_head_in_epilogue_ok(a) && a.head_w && a.head_bias, "conv_ws: this layer cannot take the head in its epilogue");
-                if (lay.teams == 2) {
-                    if (a.src.kind == SRC_RAW) launch(conv3x3_ws_kernel<G, NT, SRC_RAW, true, true, 0, true, false, 2>, 768);
-                    else launch(conv3x3_ws_kernel<G, NT, SRC_SUM2, true, true, 0, true, false, 2>, 768);
-                    HIP_CHECK(hipGetLastError());
-                    return;
-                }
                 switch (a.src.kind) {
-                    case SRC_RAW: launch(conv3x3_ws_kernel<G, NT, SRC_RAW, true, true, false, true>); break;
-                    case SRC_SUM2: launch(conv3x3_ws_kernel<G, NT, SRC_SUM2, true, true, false, true>); break;
+                    case SRC_RAW: launch(conv3x3_ws_kernel<G, NT, SRC_RAW, true, true, 0, true>); break;
+                    case SRC_SUM2: launch(conv3x3_ws_kernel<G, NT, SRC_SUM2, true, true, 0, true>); break;
                     default: fail(ANH_ERR_INTERNAL, "conv_ws: the activation-storing form reads post-activation tensors");
                 }
             } else fail(ANH_ERR_INTERNAL, "conv_ws: the head-in-epilogue form exists for the stride-1 32-channel kernel only");
             HIP_CHECK(hipGetLastError());
             return;
         }
-        if constexpr (std::is_same<G, GeoS1>::value || (std::is_same<G, GeoUp>::value && NT == 1)) {
-            if (lay.teams == 2) {
-                if (a.src.kind == SRC_RAW) launch(conv3x3_ws_kernel<G, NT, SRC_RAW, true, true, 0, false, false, 2>, 768);
-                else launch(conv3x3_ws_kernel<G, NT, SRC_SUM2, true, true, 0, false, false, 2>, 768);
-                HIP_CHECK(hipGetLastError());
-                return;
-            }
-        }
         switch (a.src.kind) {
-            case SRC_RAW: {
-                // ANH_WS_DMA (0): patches by LDS-DMA where every filter slab fits beside a ring of 3 (else 2) padded patch buffers (2: rings of
-                // three only).  MEASURED, labels bit-identical: 4,379 / 4,363 / 4,347 -> 4,348 / 4,346 / 4,316 Mpx/s (1), 4,340 / 4,326 / 4,300 (2):
-                // with the producers' registers, commit phase and VALU work gone and two items in flight, nothing moves — in inference too
-                // the consumer waves are the long pole.  Off by default, kept as a tested form.
-                static const int dma_env = getenv("ANH_WS_DMA") ? atoi(getenv("ANH_WS_DMA")) : 0;
-                const size_t n_slabs = (size_t)(a.c_red >> 5), x_pad = (size_t)((G::RECS * 4 + 255) / 256) * 4096;
-                const size_t fixed = n_slabs * 9 * NT * 32 * 64 + (size_t)a.c_red * 16 + (size_t)NT * 32 * 16;
-                const int rd = 3 * x_pad + fixed <= 160 * 1024 ? 3 : 2 * x_pad + fixed <= 160 * 1024 ? 2 : 0;
-                if (dma_env && a.zeros && ps == 0 && rd && (dma_env < 2 || rd == 3)) {
-                    lds = (size_t)rd * x_pad + fixed;
-                    extra_bits = (rd == 3) << 16;   // (the DMA form meets after every item)
-                    launch(conv3x3_ws_kernel<G, NT, SRC_RAW, true, true, 0, false, true>);
-                } else if (ps == 4) launch(conv3x3_ws_kernel<G, NT, SRC_RAW, true, true, 4>);
-                else launch(conv3x3_ws_kernel<G, NT, SRC_RAW, true, true>);
-                break;
-            }
+            case SRC_RAW: launch(conv3x3_ws_kernel<G, NT, SRC_RAW, true, true>); break;
             case SRC_SUM2: launch(conv3x3_ws_kernel<G, NT, SRC_SUM2, true, true>); break;
             default: fail(ANH_ERR_INTERNAL, "conv_ws: the activation-storing form reads post-activation tensors");
         }
         HIP_CHECK(hipGetLastError());
         return;
     }
-    // (Round 3: EVERY geometry has one.  A training forward that runs the general form carries the registers of the backward epilogues
-    // (old values, y operands: 64 VGPRs at two accumulator groups x two channel tiles) through its MFMA phase, where hipcc then keeps
-    // three operand register sets and waits behind every LDS read; in the forward-only form the same nest is scheduled with seven.
-    // Same-box A/B: 1.757 -> 1.738 ms per step; the skip-add 64->64 forward 72.7 -> 63.1 us.)
-    constexpr bool HAS_FWD_FORM = true;
-    const bool fwd_form = HAS_FWD_FORM && (a.stat_partials || a.stat_acc) && !a.bnred_partials && !a.bnred_acc && !a.out_accumulate && !a.out2;
-    if constexpr (std::is_same<G, GeoS1>::value && NT == 1) {
-        if (lay.teams == 2) {
-            if (fwd_form) {
-                switch (a.src.kind) {
-                    case SRC_RAW: launch(conv3x3_ws_kernel<G, NT, SRC_RAW, true, false, 0, false, false, 2>, 768); break;
-                    case SRC_ACT: launch(conv3x3_ws_kernel<G, NT, SRC_ACT, true, false, 0, false, false, 2>, 768); break;
-                    default: launch(conv3x3_ws_kernel<G, NT, SRC_ACT2, true, false, 0, false, false, 2>, 768); break;
-                }
-            } else launch(conv3x3_ws_kernel<G, NT, SRC_RAW, false, false, 0, false, false, 2>, 768);
-            HIP_CHECK(hipGetLastError());
-            return;
+    // The forward-only form (every geometry has one): a training forward that runs the general form carries the registers of the
+    // backward epilogues (old values, y operands: 64 VGPRs at two accumulator groups x two channel tiles) through its MFMA phase.
+    // Same-box A/B (round 3): 1.757 -> 1.738 ms per step; the skip-add 64->64 forward 72.7 -> 63.1 us.
+    const bool fwd_form = (a.stat_partials || a.stat_acc) && !a.bnred_partials && !a.bnred_acc && !a.out_accumulate && !a.out2;
+    if (fwd_form) {
+        switch (a.src.kind) {
+            case SRC_RAW: launch(conv3x3_ws_kernel<G, NT, SRC_RAW, true>); break;
+            case SRC_ACT: launch(conv3x3_ws_kernel<G, NT, SRC_ACT, true>); break;
+            case SRC_ACT2: launch(conv3x3_ws_kernel<G, NT, SRC_ACT2, true>); break;
+            default: fail(ANH_ERR_INTERNAL, "conv_ws: no forward-only form for this source kind");
         }
-    }
-    if constexpr (HAS_FWD_FORM) {
-        if (fwd_form) {
-            switch (a.src.kind) {
-                case SRC_RAW: launch(conv3x3_ws_kernel<G, NT, SRC_RAW, true>); break;
-                case SRC_ACT: launch(conv3x3_ws_kernel<G, NT, SRC_ACT, true>); break;
-                case SRC_ACT2: launch(conv3x3_ws_kernel<G, NT, SRC_ACT2, true>); break;
-                default: fail(ANH_ERR_INTERNAL, "conv_ws: no forward-only form for this source kind");
-            }
-            HIP_CHECK(hipGetLastError());
-            return;
-        }
+        HIP_CHECK(hipGetLastError());
+        return;
     }
     if (ps == 1) { launch(conv3x3_ws_kernel<G, NT, SRC_RAW, false, false, 1>); HIP_CHECK(hipGetLastError()); return; }
-    if constexpr (G::ACC >= 2 && G::ACC * NT <= 4) {
-        if (ps == 2) { launch(conv3x3_ws_kernel<G, NT, SRC_RAW, false, false, 2>); HIP_CHECK(hipGetLastError()); return; }
-    }
-    if constexpr (G::ACC * NT <= 4) {
-        if (ps == 3) { launch(conv3x3_ws_kernel<G, NT, SRC_RAW, false, false, 3>); HIP_CHECK(hipGetLastError()); return; }
+    if constexpr (G::ACC < 4 && G::ACC * NT <= 4) {   // (ws_layout gives the four-group geometry 5 or 1, never 4)
         if (ps == 4 && !a.out2) { launch(conv3x3_ws_kernel<G, NT, SRC_RAW, false, false, 4>); HIP_CHECK(hipGetLastError()); return; }
     }
     if (ps == 5 && !a.out2) { launch(conv3x3_ws_kernel<G, NT, SRC_RAW, false, false, 5>); HIP_CHECK(hipGetLastError()); return; }
@@ -2725,10 +2018,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_stem_mfma_kernel(WgradArgs a, Wg
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;
 
-    // ---- software pipeline over this workgroup's tiles: loads of tile i+1 fly while the MFMAs of tile i run ----
-    unsigned char ipx[NI];
-    unsigned iok = 0, gok = 0;
-    uint4 graw[4], yraw[4];
+    // ---- software pipeline over this workgroup's tiles: the loads of tile i + 1 are issued behind the barrier of tile i and fly while
+    // its MFMAs run.  Round 5 measured two deeper forms, same box, four alternating rounds (profiles/r05_ab_log.txt): a second register
+    // set (loads of tile i + 2 in flight; does not fit 256 VGPRs: 70 spilled) 1.678 -> 1.846 ms per step; the one set refilled chunk by
+    // chunk as soon as a chunk has been converted 1.678 -> 1.686 (noise).  The kernel is not waiting for its loads: its waves issue
+    // VALU instructions for 27 % of their cycles at two waves per SIMD (profiles/r04_sq_counters.txt) — the staging arithmetic is the limit. ----
+    struct Regs {
+        unsigned char ipx[NI];
+        unsigned iok, gok;
+        uint4 graw[4], yraw[4];
+    };
+    Regs R0;
     // BNBWD: dy is computed from (da, y) while staging; this thread's 8 channels' constants stay in registers
     float bsc[8], bsf[8], bm[8], bis[8], bk0[8], bk1[8], bk2[8];
     if (BNBWD) {
@@ -2742,41 +2042,48 @@ __global__ __launch_bounds__(256, 2) void wgrad_stem_mfma_kernel(WgradArgs a, Wg
     const bf16* dyy = reinterpret_cast<const bf16*>(a.dy_y);
     const bf16* dyp = reinterpret_cast<const bf16*>(a.dy);
     const size_t dy_plane = (size_t)a.h_out * a.w_out * 32;
-    auto fetch = [&](int tile) {
+    struct TileAt { int x0, y0, n; };
+    auto tile_at = [&](int tile) __attribute__((always_inline)) {
         const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
-        const int x0 = tx * 32, y0 = ty * 8;
-        const uint8_t* img = a.src.img + (size_t)n * a.src.img_sample_stride;
-        iok = 0;
+        return TileAt{tx * 32, ty * 8, n};
+    };
+    auto fetch_img = [&](Regs& R, const TileAt& t, int jj) __attribute__((always_inline)) {
+        const uint8_t* img = a.src.img + (size_t)t.n * a.src.img_sample_stride;
+        const int c = igeo[jj] & 15, px = (igeo[jj] >> 4) & 255, py = igeo[jj] >> 12;
+        const int iy = t.y0 - 2 + py, ix = t.x0 - 2 + px;
+        const int sy = min(max(a.src.win_top(t.n) + iy, 0), a.src.img_h - 1), sx = min(max(a.src.win_left(t.n) + ix, 0), a.src.img_w - 1);
+        R.ipx[jj] = img[((size_t)sy * a.src.img_w + sx) * CIN + c];
+        const unsigned ok = (iy >= 0 && iy < a.h_in && ix >= 0 && ix < a.w_in) ? 1u : 0u;
+        R.iok = (R.iok & ~(1u << jj)) | (ok << jj);
+    };
+    auto fetch_dy = [&](Regs& R, const TileAt& t, int jj) __attribute__((always_inline)) {
+        const bf16* g = dyp + (size_t)t.n * dy_plane;
+        const int ox = t.x0 + t_x, cx = min(ox, a.w_out - 1);
+        const int oy = t.y0 + t_row0 + 2 * jj, cy = min(oy, a.h_out - 1);
+        R.graw[jj] = *reinterpret_cast<const uint4*>(g + (cy * a.w_out + cx) * 32 + c16 * 8);
+        if (BNBWD) R.yraw[jj] = *reinterpret_cast<const uint4*>(dyy + (size_t)t.n * dy_plane + (cy * a.w_out + cx) * 32 + c16 * 8);
+        const unsigned ok = (oy == cy && ox == cx) ? 1u : 0u;
+        R.gok = (R.gok & ~(1u << jj)) | (ok << jj);
+    };
+    auto fetch = [&](Regs& R, int tile) __attribute__((always_inline)) {
+        const TileAt t = tile_at(tile);
+        R.iok = 0; R.gok = 0;
 #pragma unroll
-        for (int jj = 0; jj < NI; ++jj) {
-            const int c = igeo[jj] & 15, px = (igeo[jj] >> 4) & 255, py = igeo[jj] >> 12;
-            const int iy = y0 - 2 + py, ix = x0 - 2 + px;
-            const int sy = min(max(a.src.win_top(n) + iy, 0), a.src.img_h - 1), sx = min(max(a.src.win_left(n) + ix, 0), a.src.img_w - 1);
-            ipx[jj] = img[((size_t)sy * a.src.img_w + sx) * CIN + c];
-            iok |= ((iy >= 0 && iy < a.h_in && ix >= 0 && ix < a.w_in) ? 1u : 0u) << jj;
-        }
-        const bf16* g = dyp + (size_t)n * dy_plane;
-        const int ox = x0 + t_x, cx = min(ox, a.w_out - 1);
-        gok = 0;
+        for (int jj = 0; jj < NI; ++jj) fetch_img(R, t, jj);
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            const int oy = y0 + t_row0 + 2 * jj, cy = min(oy, a.h_out - 1);
-            graw[jj] = *reinterpret_cast<const uint4*>(g + (cy * a.w_out + cx) * 32 + c16 * 8);
-            if (BNBWD) yraw[jj] = *reinterpret_cast<const uint4*>(dyy + (size_t)n * dy_plane + (cy * a.w_out + cx) * 32 + c16 * 8);
-            gok |= ((oy == cy && ox == cx) ? 1u : 0u) << jj;
-        }
+        for (int jj = 0; jj < 4; ++jj) fetch_dy(R, t, jj);
     };
 
     int tile = blockIdx.x;
-    if (tile < total_tiles) fetch(tile);
+    if (tile < total_tiles) fetch(R0, tile);
     int buf = 0;
-    for (; tile < total_tiles; tile += splits) {
+    auto one_tile = [&](Regs& R) __attribute__((always_inline)) {
         char* lbuf = smem + buf * BUF;
         // image patch (12 x 36 x CIN) -> five shifted bf16 copies per row; u8 / 256 is exact in bf16
 #pragma unroll
         for (int jj = 0; jj < NI; ++jj) {
             const int c = igeo[jj] & 15, px = (igeo[jj] >> 4) & 255, py = igeo[jj] >> 12;
-            const float v = ((iok >> jj) & 1u) ? (float)ipx[jj] * (1.0f / 256.0f) : 0.f;
+            const float v = ((R.iok >> jj) & 1u) ? (float)R.ipx[jj] * (1.0f / 256.0f) : 0.f;
             const bf16 b = (bf16)v;
             if (tid + 256 * jj < 12 * 36 * CIN) {
 #pragma unroll
@@ -2788,12 +2095,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_stem_mfma_kernel(WgradArgs a, Wg
         }
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
-            const uint4 dyv = BNBWD ? chunk_bnbwd(graw[jj], yraw[jj], bsc, bsf, bm, bis, bk0, bk1, bk2) : graw[jj];
-            const uint4 v = ((gok >> jj) & 1u) ? dyv : make_uint4(0u, 0u, 0u, 0u);
+            const uint4 dyv = BNBWD ? chunk_bnbwd(R.graw[jj], R.yraw[jj], bsc, bsf, bm, bis, bk0, bk1, bk2) : R.graw[jj];
+            const uint4 v = ((R.gok >> jj) & 1u) ? dyv : make_uint4(0u, 0u, 0u, 0u);
             *reinterpret_cast<uint4*>(lbuf + gdst0 + jj * (2 * 32 * 64)) = v;
         }
         __syncthreads();  // two buffers: the writes above cannot race with a slower wave still reading the other one
-        if (tile + splits < total_tiles) fetch(tile + splits);
+        if (tile + splits < total_tiles) fetch(R, tile + splits);
         const char* g0 = lbuf + g_off[0];
         const char* g1 = lbuf + g_off[1];
 #pragma unroll
@@ -2807,7 +2114,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_stem_mfma_kernel(WgradArgs a, Wg
             }
         }
         buf ^= 1;
-    }
+        tile += splits;
+    };
+    while (tile < total_tiles) one_tile(R0);
 
     // ---- sum the four waves' accumulators through LDS (fixed order) and write ONE partial per workgroup ----
     __syncthreads();
@@ -2857,10 +2166,9 @@ WgPlan wgrad_plan_mfma(const WgradArgs& a) {
     p.cont = a.gather == 1;
     static const int ws_on = getenv("ANH_WGRAD_WS") ? atoi(getenv("ANH_WGRAD_WS")) : 1;
     p.ws = ws_on != 0;
-    // tile channels per workgroup: 128 (ntc 4) leaves a consumer wave nine accumulator tiles (216-232 VGPRs: no wave of another kernel
-    // fits beside the workgroup); 64 (ntc 2) runs 128 channels as two workgroup groups — ANH_WGRAD_NTC_MAX
-    static const int ntc_max = getenv("ANH_WGRAD_NTC_MAX") ? std::max(1, std::min(4, atoi(getenv("ANH_WGRAD_NTC_MAX")))) : 4;
-    const int ntc_ = std::min((p.cont ? a.c_in : a.c_out) / 32, ntc_max == 3 ? 2 : ntc_max);
+    // tile channels per workgroup: up to 128 (ntc 4: nine accumulator tiles per consumer wave, 216-232 VGPRs; two workgroup groups of 64
+    // measured 3-7 us slower on the filter gradients of the 56^2 level, round 3)
+    const int ntc_ = std::min((p.cont ? a.c_in : a.c_out) / 32, 4);
     const int th = a.stride == 1 ? ((p.ws && ntc_ == 4) ? 4 : 8) : 4;
     const int lr_h = p.cont ? a.h_in : a.h_out, lr_w = p.cont ? a.w_in : a.w_out;   // the low-res (tile) tensor
     const int c_tile = p.cont ? a.c_in : a.c_out, c_patch = p.cont ? a.c_out : a.c_in;
@@ -3365,20 +2673,6 @@ bool conv_head_in_epilogue_ok(const ConvArgs& a) {
            (a.src.kind == SRC_RAW || a.src.kind == SRC_SUM2);
 }
 
-// Will the launch of `a` (every field set as for the launch) store its staged input through ConvArgs::act_out?  The warp-specialised
-// stride-1 forward form with a bn kind on its input (the MAT forms of conv3x3_ws).
-bool conv_materializes_input(const ConvArgs& a) {
-#if (defined(ANH_WS_BUFFER_LOADS) && !ANH_WS_BUFFER_LOADS) || !defined(ANH_ACT_MATERIALIZE_BUILD) || !ANH_ACT_MATERIALIZE_BUILD
-    (void)a;
-    return false;   // the storing forms are compiled out (see MAT in conv3x3_ws_kernel)
-#else
-    if (!mfma_conv_supported(a) || stem_mfma_ok(a) || a.k != 3) return false;
-    const ConvPlan p = conv_plan(a);
-    const bool fwd_form = (a.stat_partials || a.stat_acc) && !a.bnred_partials && !a.bnred_acc && !a.out_accumulate && !a.out2 && !a.out_scale;
-    return p.geo == 0 && p.form == 2 && fwd_form && (a.src.kind == SRC_ACT || a.src.kind == SRC_ACT2);
-#endif
-}
-
 int conv_fused_bnred_blocks(const ConvArgs& a) {
     if (!mfma_conv_supported(a) || stem_mfma_ok(a) || (int64_t)a.n * a.h_out * a.w_out == 0) return 0;
     static const int on = getenv("ANH_FUSE_BN_BWD_REDUCE") ? atoi(getenv("ANH_FUSE_BN_BWD_REDUCE")) : 1;
@@ -3404,16 +2698,7 @@ void launch_conv_mfma(const ConvArgs& a, hipStream_t s) {
     ANH_REQUIRE(!a.bnred_partials || (conv_fused_bnred_blocks(a) > 0 && !a.stat_partials), "conv_mfma: this layer's kernel does not fuse the bn backward reduction");
     if (p.geo == 0) {
         if (p.form == 2) {
-            // ANH_WS_TALL: the 64-output-channel inference forms on 16 x 32 tiles (GeoS1T) where two tall patches and the filter fit:
-            // 1 = at 128 reduction channels and more, 2 = wherever it fits, 0 = never
-            // MEASURED (five same-box rounds): 4,483 (0) / 4,483 (1) / 4,371 Mpx/s (2: -2.5 %; per image the 128->128 conv 332 -> 313 us,
-            // the 64->64 convs 350 -> 356 and 416 -> 432) — a third fewer LDS reads per MFMA and half the barriers buy nothing.  Off.
-            static const int tall_env = getenv("ANH_WS_TALL") ? atoi(getenv("ANH_WS_TALL")) : 0;
-            const size_t tall_x = (size_t)GeoS1T::RECS * 64, tall_w = (size_t)9 * 64 * 64, tall_tab = (size_t)a.c_red * 16 + 2 * 32 * 16;
-            const size_t n_sl = (size_t)(a.c_red >> 5);
-            const bool tall_fits = 2 * tall_x + n_sl * tall_w + tall_tab <= 160 * 1024 || 2 * (tall_x + tall_w) + tall_tab <= 160 * 1024;
             if (p.nt == 1) launch_ws<GeoS1, 1>(a, p.tiles_x, p.tiles_y, p.flip, s);
-            else if (tall_env && (tall_env == 2 || a.c_red >= 128) && a.out_scale && !a.head_out && tall_fits && (a.src.kind == SRC_RAW || a.src.kind == SRC_SUM2)) launch_ws<GeoS1T, 2>(a, p.tiles_x, (a.h_out + GeoS1T::TTH - 1) / GeoS1T::TTH, p.flip, s);
             else launch_ws<GeoS1, 2>(a, p.tiles_x, p.tiles_y, p.flip, s);
         }
         else if (a.c_out == 32) launch_s1<1, 9>(a, s);

@@ -27,12 +27,12 @@ def main():
     lab[rng.random((n, d, d)) < 0.1] = aa.LABEL_IGNORE
     wl = [aa.set_weights(l, 0.5, 0.5) for l in lab]
     losses = []
-    for _ in range(3):
+    for _ in range(int(os.environ.get("ANH_TEST_STEPS", "3"))):
         t.StartTraining(list(img), wl)
         t.synchronize()
         losses.append(t.get_last_loss())
     p, r = t.get_params()
-    np.savez(out, losses=np.array(losses), params=p, running=r)
+    np.savez(out, losses=np.array(losses), params=p, running=r, step_graph=np.array(t.step_graph_stats()))
 
 
 if __name__ == "__main__":

@@ -5,8 +5,7 @@ tests/helpers/run_train_steps.py in its own process: 3 bf16 steps on a seeded ba
   * variants that only move work between streams or kernels WITHOUT changing any summation order are bit-identical to
     the default: one stream instead of two; the stem's filter gradient queued on the second stream instead of the main one;
     the conv filter slabs streamed through LDS with every patch instead of staying resident; the gradient under the fused
-    head written to memory instead of recomputed by its bn backward pass; stream priorities; the conv kernels' producer /
-    consumer waves mapped to separate SIMDs;
+    head written to memory instead of recomputed by its bn backward pass; stream priorities; who issues the backward-data convs' stores;
   * variants that change a summation order (bn sums in accumulator tables folded by their consumers vs. per-workgroup
     partials with finalize kernels; bn statistics / bn backward sums in a conv epilogue vs. the separate kernels; the classic one-tile conv kernels; dy materialised for the stem) agree to bf16-training tolerance.
 """
@@ -40,7 +39,6 @@ def default_run(tmp_path_factory):
     ("one_stream", {"ANH_CONCURRENT_WGRAD": "0"}),
     ("head_gradient_materialised", {"ANH_HEAD_DA_VIRTUAL": "0"}),
     ("main_stream_above_filter_gradient_stream", {"ANH_STREAM_PRIORITY": "1"}),
-    ("conv_roles_on_separate_simds", {"ANH_WS_ROLE_MAP": "1"}),
     ("stem_filter_gradient_on_second_stream", {"ANH_STEM_WGRAD_MAIN": "0"}),
     ("conv_filters_streamed_with_every_patch", {"ANH_WS_WEIGHT_RESIDENT": "0"}),
     ("skip_gradient_written_to_both_sources", {"ANH_SKIP_GRAD_ONCE": "0"}),
@@ -57,18 +55,9 @@ def test_schedule_is_bit_identical(tmp_path, default_run, name, env):
 
 @pytest.mark.parametrize("name,env", [
     ("bn_sums_as_partials_with_finalize_kernels", {"ANH_BN_TABLES": "0"}),
-    ("bn_backward_sums_kept_by_the_consumer_waves", {"ANH_WS_PSTAT": "0"}),
-    ("bn_backward_sums_kept_by_the_producer_waves_wherever_they_fit", {"ANH_WS_PSTAT": "2"}),
-    ("bn_backward_sums_split_between_the_roles_stride_1", {"ANH_WS_PSTAT": "3"}),
-    ("bn_backward_sums_split_between_the_roles_every_geometry_that_can", {"ANH_WS_PSTAT": "4"}),
     ("conv_tiles_walked_with_the_grid_stride", {"ANH_WS_XCD_BANDS": "0"}),
-    ("conv_roles_meet_after_every_second_item", {"ANH_WS_IPB": "2"}),
     ("filter_gradient_tiles_walked_in_xcd_bands", {"ANH_WGRAD_XCD_BANDS": "1"}),
     ("filter_gradient_tiles_walked_with_the_grid_stride", {"ANH_WGRAD_XCD_BANDS": "0"}),
-    ("one_consumer_team_in_every_conv", {"ANH_WS_TEAMS": "0"}),
-    ("two_consumer_teams_take_turns_where_the_form_exists", {"ANH_WS_TEAMS": "1"}),
-    ("bn_backward_y_operands_staged_through_lds_by_the_producer_waves", {"ANH_WS_PSTAT": "5"}),
-    ("bn_backward_y_operands_staged_through_lds_every_geometry_that_can", {"ANH_WS_PSTAT": "6"}),
     ("separate_reduce_pass_for_the_layer_behind_the_64_channel_up_conv", {"ANH_WS_WIDE_PS": "0"}),
     ("fused_head_on_768_workgroups", {"ANH_HEAD_BLOCKS": "768"}),
     ("separate_bn_statistics", {"ANH_FUSE_BN_STATS": "0"}),
@@ -85,3 +74,18 @@ def test_schedule_agrees_within_bf16_training_tolerance(tmp_path, default_run, n
     assert np.linalg.norm(dp) <= 2e-3 * np.linalg.norm(ref), float(np.linalg.norm(dp) / np.linalg.norm(ref))
     run = default_run["running"]   # means (near zero) and variances: absolute bar relative to the largest statistic
     np.testing.assert_allclose(got["running"], run, rtol=2e-3, atol=2e-3 * np.abs(run).max())
+
+
+def test_backward_replayed_as_a_captured_graph_is_bit_identical(tmp_path):
+    """ANH_STEP_GRAPH=1: the launches behind the fused head (both streams, the dy hand-overs and the join as graph edges) captured
+    once per (shape, buffers, input pointer) and replayed.  StartTraining alternates two staging sets, so a key is captured on its
+    third use: ten steps replay each of the two graphs twice.  Same kernels, same arguments, same order: bit-identical."""
+    steps = {"ANH_TEST_STEPS": "10"}
+    eager = run_variant(tmp_path, "eager10", steps)
+    graph = run_variant(tmp_path, "graph10", dict(steps, ANH_STEP_GRAPH="1"))
+    assert tuple(eager["step_graph"]) == (0, 0)
+    captures, launches = (int(v) for v in graph["step_graph"])
+    assert captures == 2 and launches >= 4, (captures, launches)   # (a key changes once while the first steps size their scratch buffers)
+    np.testing.assert_array_equal(graph["losses"], eager["losses"])
+    np.testing.assert_array_equal(graph["params"], eager["params"])
+    np.testing.assert_array_equal(graph["running"], eager["running"])
