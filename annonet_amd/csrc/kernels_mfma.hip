@@ -1974,8 +1974,8 @@ void launch_ws(const ConvArgs& a, int tiles_x, int tiles_y, int flip, hipStream_
 // ---------------------------------------------------------------------------------------------------------------
 template <int CIN, bool BNBWD>
 __global__ __launch_bounds__(256, 2) void wgrad_stem_mfma_kernel(WgradArgs a, WgSide dy_side, int tiles_x, int tiles_y, int total_tiles, int splits) {
-    constexpr int ROWS = 25 * CIN, RT = (ROWS + 31) / 32, PLANE = 12 * 5 * 64;  // bytes of one channel plane
-    constexpr int NI = (12 * 36 * CIN + 255) / 256;   // image bytes per thread
+    constexpr int ROWS = 25 * CIN, RT = (ROWS + 31) / 32, PLANE = 12 * 5 * 64 + 64;  // bytes of one channel plane (+ 64: planes start 16 banks apart)
+    constexpr int IMG_THREADS = 12 * 4 * CIN;   // image staging: one thread per (patch row, 8-pixel segment, channel)
     constexpr int BUF = 256 * 64 + (CIN + 1) * PLANE;  // one buffer: dy tile (256 pixel records) + CIN planes + an all-zero plane
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, col = lane & 31, c16 = tid & 3;
@@ -2002,13 +2002,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_stem_mfma_kernel(WgradArgs a, Wg
 
     // ---- staging geometry, fixed per thread: image byte jj -> (channel, column, row) of the 12 x 36 patch; dy chunk jj ->
     //      row (tid >> 7) + 2 jj, column (tid >> 2) & 31 ----
-    int igeo[NI];
-#pragma unroll
-    for (int jj = 0; jj < NI; ++jj) {
-        const int i = min(tid + 256 * jj, 12 * 36 * CIN - 1);
-        const int c = i % CIN, px = (i / CIN) % 36, py = i / (CIN * 36);
-        igeo[jj] = c | (px << 4) | (py << 12);
-    }
+    // Image staging (round 5): thread (patch row, segment q, channel) loads the 12 pixels 8 q .. 8 q + 11 of its 36-pixel line — byte loads
+    // through a buffer descriptor of the image, so a pixel outside the net's input reads as zero by itself — converts them to six packed
+    // bf16 pairs and writes the five kx-shifted 8-pixel chunks as 16-byte stores (even shifts are four of the six words, odd shifts four
+    // v_alignbit).  No branch, ~50 VALU per thread and tile on 144 threads.  The form before handled one byte per thread with five
+    // predicated 2-byte stores each (hipcc emits a branch per store: ~60 instructions and 5 branches per byte, 1,296 bytes per tile).
+    const bool img_thread = tid < IMG_THREADS;
+    const int i_ci = tid % CIN, i_q = (tid / CIN) & 3, i_py = min(tid / (4 * CIN), 11);
+    const int i_dst = 256 * 64 + i_ci * PLANE + i_py * 320 + i_q * 16;   // + kx * 64
+    const int img_bytes = a.src.img_h * a.src.img_w * CIN;   // (< 2^31: stem_wgrad_mfma_ok)
     const int t_x = (tid >> 2) & 31, t_row0 = tid >> 7;
     const int gdst0 = (t_row0 * 32 + t_x) * 64 + ((c16 ^ ((t_x >> 2) & 3)) << 4);
 
@@ -2024,8 +2026,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_stem_mfma_kernel(WgradArgs a, Wg
     // chunk as soon as a chunk has been converted 1.678 -> 1.686 (noise).  The kernel is not waiting for its loads: its waves issue
     // VALU instructions for 27 % of their cycles at two waves per SIMD (profiles/r04_sq_counters.txt) — the staging arithmetic is the limit. ----
     struct Regs {
-        unsigned char ipx[NI];
-        unsigned iok, gok;
+        unsigned char ipx[12];
+        unsigned gok;
         uint4 graw[4], yraw[4];
     };
     Regs R0;
@@ -2047,14 +2049,25 @@ __global__ __launch_bounds__(256, 2) void wgrad_stem_mfma_kernel(WgradArgs a, Wg
         const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
         return TileAt{tx * 32, ty * 8, n};
     };
-    auto fetch_img = [&](Regs& R, const TileAt& t, int jj) __attribute__((always_inline)) {
-        const uint8_t* img = a.src.img + (size_t)t.n * a.src.img_sample_stride;
-        const int c = igeo[jj] & 15, px = (igeo[jj] >> 4) & 255, py = igeo[jj] >> 12;
-        const int iy = t.y0 - 2 + py, ix = t.x0 - 2 + px;
-        const int sy = min(max(a.src.win_top(t.n) + iy, 0), a.src.img_h - 1), sx = min(max(a.src.win_left(t.n) + ix, 0), a.src.img_w - 1);
-        R.ipx[jj] = img[((size_t)sy * a.src.img_w + sx) * CIN + c];
-        const unsigned ok = (iy >= 0 && iy < a.h_in && ix >= 0 && ix < a.w_in) ? 1u : 0u;
-        R.iok = (R.iok & ~(1u << jj)) | (ok << jj);
+    auto fetch_img = [&](Regs& R, const TileAt& t) __attribute__((always_inline)) {
+        if (!img_thread) return;
+        const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.src.img + (size_t)t.n * a.src.img_sample_stride), 0, img_bytes, 0x00020000);
+        const int iy = t.y0 - 2 + i_py, ix0 = t.x0 - 2 + 8 * i_q;
+        const int top = a.src.win_top(t.n), left = a.src.win_left(t.n);
+        const bool interior = iy >= 0 && iy < a.h_in && ix0 >= 0 && ix0 + 11 < a.w_in && top + iy >= 0 && top + iy < a.src.img_h && left + ix0 >= 0 && left + ix0 + 11 < a.src.img_w;
+        if (interior) {   // (nearly wave-uniform: 70 % of the tiles are interior ones)
+            const int off = ((top + iy) * a.src.img_w + left + ix0) * CIN + i_ci;
+#pragma unroll
+            for (int k = 0; k < 12; ++k) R.ipx[k] = __builtin_amdgcn_raw_buffer_load_b8(ri, off + k * CIN, 0, 0);
+        } else {
+            const int sy = min(max(top + iy, 0), a.src.img_h - 1);
+#pragma unroll
+            for (int k = 0; k < 12; ++k) {
+                const int ix = ix0 + k, sx = min(max(left + ix, 0), a.src.img_w - 1);
+                const bool ok = iy >= 0 && iy < a.h_in && ix >= 0 && ix < a.w_in;   // the conv's zero padding
+                R.ipx[k] = __builtin_amdgcn_raw_buffer_load_b8(ri, ok ? (sy * a.src.img_w + sx) * CIN + i_ci : (int)0x7FFFFFF0, 0, 0);
+            }
+        }
     };
     auto fetch_dy = [&](Regs& R, const TileAt& t, int jj) __attribute__((always_inline)) {
         const bf16* g = dyp + (size_t)t.n * dy_plane;
@@ -2067,9 +2080,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_stem_mfma_kernel(WgradArgs a, Wg
     };
     auto fetch = [&](Regs& R, int tile) __attribute__((always_inline)) {
         const TileAt t = tile_at(tile);
-        R.iok = 0; R.gok = 0;
-#pragma unroll
-        for (int jj = 0; jj < NI; ++jj) fetch_img(R, t, jj);
+        R.gok = 0;
+        fetch_img(R, t);
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) fetch_dy(R, t, jj);
     };
@@ -2079,18 +2091,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_stem_mfma_kernel(WgradArgs a, Wg
     int buf = 0;
     auto one_tile = [&](Regs& R) __attribute__((always_inline)) {
         char* lbuf = smem + buf * BUF;
-        // image patch (12 x 36 x CIN) -> five shifted bf16 copies per row; u8 / 256 is exact in bf16
+        if (img_thread) {   // image patch (12 x 36 x CIN) -> five shifted bf16 copies per row; u8 / 256 is exact in bf16
+            unsigned d[6];
 #pragma unroll
-        for (int jj = 0; jj < NI; ++jj) {
-            const int c = igeo[jj] & 15, px = (igeo[jj] >> 4) & 255, py = igeo[jj] >> 12;
-            const float v = ((R.iok >> jj) & 1u) ? (float)R.ipx[jj] * (1.0f / 256.0f) : 0.f;
-            const bf16 b = (bf16)v;
-            if (tid + 256 * jj < 12 * 36 * CIN) {
+            for (int k = 0; k < 6; ++k) d[k] = pack2((float)R.ipx[2 * k] * (1.0f / 256.0f), (float)R.ipx[2 * k + 1] * (1.0f / 256.0f));
+            char* dst = lbuf + i_dst;
 #pragma unroll
-                for (int kx = 0; kx < 5; ++kx) {
-                    const int xx = px - kx;
-                    if (xx >= 0 && xx < 32) *reinterpret_cast<bf16*>(lbuf + 256 * 64 + c * PLANE + (py * 5 + kx) * 64 + xx * 2) = b;
-                }
+            for (int kx = 0; kx < 5; ++kx) {
+                uint4 v;
+                if (kx & 1) {
+                    const int b = kx >> 1;
+                    v = make_uint4(__builtin_amdgcn_alignbit(d[b + 1], d[b], 16), __builtin_amdgcn_alignbit(d[b + 2], d[b + 1], 16),
+                                   __builtin_amdgcn_alignbit(d[b + 3], d[b + 2], 16), __builtin_amdgcn_alignbit(d[b + 4], d[b + 3], 16));
+                } else v = make_uint4(d[kx >> 1], d[(kx >> 1) + 1], d[(kx >> 1) + 2], d[(kx >> 1) + 3]);
+                *reinterpret_cast<uint4*>(dst + kx * 64) = v;
             }
         }
 #pragma unroll
@@ -2137,7 +2151,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_stem_mfma_kernel(WgradArgs a, Wg
 
 bool stem_wgrad_mfma_ok(const WgradArgs& a) {
     return a.src.kind == SRC_IMAGE && a.k == 5 && a.stride == 1 && a.pad == 2 && a.gather == 0 && a.c_out == 32 && (a.c_in == 1 || a.c_in == 3) &&
-           a.h_in == a.h_out && a.w_in == a.w_out && a.dy_dtype == DT_BF16;
+           a.h_in == a.h_out && a.w_in == a.w_out && a.dy_dtype == DT_BF16 &&
+           (int64_t)a.src.img_h * a.src.img_w * a.c_in < 0x7FFFFFF0ll;   // (one image behind a buffer descriptor, 32-bit byte offsets)
 }
 int stem_wgrad_mfma_blocks(const WgradArgs& a) {
     const int tiles = ((a.w_out + 31) / 32) * ((a.h_out + 7) / 8) * a.n;
@@ -2148,7 +2163,7 @@ void launch_wgrad_stem_mfma(const WgradArgs& a, hipStream_t s) {
     const int tiles_x = (a.w_out + 31) / 32, tiles_y = (a.h_out + 7) / 8;
     const int total = tiles_x * tiles_y * a.n, blocks = stem_wgrad_mfma_blocks(a);
     const WgSide dy{reinterpret_cast<const bf16*>(a.dy), nullptr, nullptr, nullptr, nullptr, nullptr, a.h_out, a.w_out, 32};
-    const size_t lds = 2 * (256 * 64 + (size_t)(a.c_in + 1) * 12 * 5 * 64);  // two buffers, each with its zero plane
+    const size_t lds = 2 * (256 * 64 + (size_t)(a.c_in + 1) * (12 * 5 * 64 + 64));  // two buffers, each with its zero plane
     if (a.dy_y) {
         if (a.c_in == 3) hipLaunchKernelGGL((wgrad_stem_mfma_kernel<3, true>), dim3(blocks), dim3(256), lds, s, a, dy, tiles_x, tiles_y, total, blocks);
         else hipLaunchKernelGGL((wgrad_stem_mfma_kernel<1, true>), dim3(blocks), dim3(256), lds, s, a, dy, tiles_x, tiles_y, total, blocks);
