@@ -1462,15 +1462,16 @@ __device__ __forceinline__ int find_segment(const ParamSegment* seg, int n, int6
 }
 
 // canonical index within a filter segment -> (tap-major, k-major) indices
-__device__ __forceinline__ void filter_indices(const ParamSegment& sg, int64_t local, int64_t& tm, int64_t& km) {
-    const int kk = sg.k * sg.k;
-    const int t = (int)(local % kk);
-    const int64_t r = local / kk;
-    int ci, co;
-    if (sg.type == 0) { ci = (int)(r % sg.cin); co = (int)(r / sg.cin); }   // [co][ci][t]
-    else { co = (int)(r % sg.cout); ci = (int)(r / sg.cout); }              // [ci][co][t]
-    tm = ((int64_t)t * sg.cin + ci) * sg.cout + co;
-    km = ((int64_t)t * sg.cout + co) * sg.cin + ci;
+__device__ __forceinline__ void filter_indices(const ParamSegment& sg, int64_t local64, int64_t& tm, int64_t& km) {
+    // 32-bit arithmetic: a filter segment holds k^2 cin cout < 2^31 elements (a 64-bit division by a run-time divisor is ~100
+    // instructions on this ISA, three of them per parameter were a quarter of the update kernel)
+    const unsigned local = (unsigned)local64, kk = (unsigned)(sg.k * sg.k);
+    const unsigned r = local / kk, t = local - r * kk;
+    unsigned ci, co;
+    if (sg.type == 0) { co = r / (unsigned)sg.cin; ci = r - co * (unsigned)sg.cin; }   // [co][ci][t]
+    else { ci = r / (unsigned)sg.cout; co = r - ci * (unsigned)sg.cout; }              // [ci][co][t]
+    tm = (int64_t)((t * (unsigned)sg.cin + ci) * (unsigned)sg.cout + co);
+    km = (int64_t)((t * (unsigned)sg.cout + co) * (unsigned)sg.cin + ci);
 }
 
 __global__ __launch_bounds__(256) void sgd_kernel(SgdArgs a) {

@@ -141,6 +141,21 @@ def bound_of(flops, min_bytes, seconds):
     return out
 
 
+def useful_over_issued(L, dims_li, which):
+    """Fraction of a conv launch's MFMAs that multiply pixels INSIDE the image: the kernels walk 32-pixel-wide tiles (8 rows for the
+    stride-1 geometry and the stem, 4 rows of the low-resolution side for the stride-2 geometries and for filter gradients with 128
+    tile channels), so a side that is not a multiple of the tile computes padding columns / rows (227 -> 256 x 232, 113 -> 128 x 120
+    or 116, 56 -> 64 x 56).  The padding pixels' operands are zeros: issued, not useful."""
+    h_in, h_out = dims_li
+    low = min(h_in, h_out)                       # the side the tiles partition: output of con, input of cont, = both at stride 1
+    if L.stride == 1:
+        th = 4 if (which == "wgrad" and max(L.cin, L.cout) // 32 >= 4 and L.k == 3) else 8
+    else:
+        th = 4
+    up = lambda v, m: (v + m - 1) // m * m
+    return round(low * low / float(up(low, th) * up(low, 32)), 4)
+
+
 ENTRY_RE = re.compile(r":(fwd|dgrad|wgrad)_L(\d+)_(\w+?)_(\d+)x(\d+)$")
 PASS_NAME = {"fwd": "fwd", "dgrad": "bwd-data", "wgrad": "bwd-filter"}
 
@@ -163,6 +178,7 @@ def split_entries(prof, layers, dims, n, per_steps):
             b = bound_of(flops, min_bytes, t_us * 1e-6)
             row.update(bound=b["bound"], floor_us=round(b["floor_us"], 2), frac=round(b["frac"], 4), achieved=round(b["achieved"], 1), unit=b["unit"])
             row["mfma_busy_pct"] = mfma_busy(e["name"])
+            row["useful_over_issued"] = useful_over_issued(layers[li], dims[li], m.group(1))   # tile-quantisation share of the issued MFMAs
             convs.append(row)
         else:
             other.append({"entry": e["name"], "launches_per_step": e["launches"] / per_steps, "us_per_step": round(1e3 * e["total_ms"] / per_steps, 2),
@@ -281,8 +297,10 @@ def cpu_baseline_train(aa, cfg):
     t0 = time.perf_counter()
     o.train_step(img[:4], lab[:4], w[:4], apply_update=False)  # estimate of the per-tile cost
     per_tile = (time.perf_counter() - t0) / 4
-    n_all = int(min(len(img), max(4, round(5.0 / max(per_tile, 1e-3)))))  # the whole batch when a step fits in ~5 s
-    reps = int(max(1, round(10.0 / max(per_tile * n_all, 1e-3))))        # ~10 s of CPU work
+    n_all = len(img)                                                      # the WHOLE batch of 32 tiles per step: samples of 11-15 tiles read 3.4-7.6 tiles/s box to box
+    t0 = time.perf_counter()
+    o.train_step(img[:n_all], lab[:n_all], w[:n_all])                     # one whole step, untimed: sizes the sample (and pages the batch-sized buffers in)
+    reps = int(max(1, min(6, round(12.0 / max(time.perf_counter() - t0, 1e-3)))))   # 10-30 s of CPU work in all
     t0 = time.perf_counter()
     for _ in range(reps):
         o.train_step(img[:n_all], lab[:n_all], w[:n_all])
@@ -886,7 +904,8 @@ def main():
             flops, min_bytes = row["gflop"] * 1e9, row["min_mb"] * 1e6
             roof = bound_of(flops, min_bytes, avg_s)
             roof.pop("floor_us")
-            roof.update(traffic=pmc_traffic(dominant), kernel=dominant, layer=row["layer"], **{"pass": row["pass"]},
+            roof.update(traffic=pmc_traffic(dominant), traffic_source=f"not measured in this run: HBM bytes per launch of this entry from the committed rocprofv3 --pmc passes ({os.path.basename(TRAFFIC_JSON)}; tools/pmc_traffic.py, FETCH_SIZE / WRITE_SIZE corrected as MI355X_MICROARCH.md prescribes)" if TRAFFIC_JSON else None,
+                        kernel=dominant, layer=row["layer"], **{"pass": row["pass"]},
                         avg_launch_us=avg_s * 1e6, launches=e["launches"], sampled_every_n_steps=sample_every,
                         algorithmic_flops_per_launch=flops, algorithmic_bytes_per_launch=min_bytes, arithmetic_intensity=flops / min_bytes)
         step_gflop = 3 * sum(section8d(layers, dims, li, BATCH)[0] for li in range(len(layers))) / 1e9

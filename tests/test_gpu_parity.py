@@ -479,6 +479,67 @@ def test_large_image_tiled_inference_properties(H, W, scaler, min_filters):
     assert (l16 == labels).mean() > 0.97
 
 
+def test_16384_square_image_tiled_inference_properties():
+    """BASELINE config [4]'s workload on ONE GPU: a 16384 x 16384 synthetic image, the benchmark net, 1024^2 tiles with the receptive
+    field as overlap (289 tiles; /root/reference/annonet_infer_main.cpp:300-303,423-427), image, class planes (3 GiB) and label map resident
+    in HBM.  Size-independent properties, as the 4096^2 case: fp32 planes and labels bit-exact against the oracle's forward on windows
+    deep inside five tiles (corners, centre, an edge), labels = argmax of the planes on those windows, every label a class, and the
+    bf16 mode's label map >= 97 % equal to the fp32 one on the same windows."""
+    import torch
+    H = W = 16384
+    o, net = pair(2, 3, 3, 1.0, 1, aa.ANH_FP32, seed=13)
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device=dev); gen.manual_seed(3)
+    d_img = torch.randint(0, 256, (H, W, 3), dtype=torch.uint8, device=dev, generator=gen)
+    ov = o.required_input_dim()
+    tp = aa.tiling.parameters(1024, 1024, ov, ov)
+    tiles = aa.tiling.get_tiles(W, H, tp)
+    assert len(tiles) == 289
+    d_lab = torch.zeros((H, W), dtype=torch.int16, device=dev)
+    d_pl = torch.zeros((3, H, W), dtype=torch.float32, device=dev)
+    aa.annonet_infer_device(net, d_img.data_ptr(), H, W, d_lab.data_ptr(), d_pl.data_ptr(), tiling_parameters=tp)
+    net.synchronize()
+    assert int(d_lab.view(torch.int16).max()) < 3 and int(d_lab.min()) >= 0
+    assert bool(torch.isfinite(d_pl[:, ::97, ::89]).all())
+    windows = []
+    for ti in (0, 16, 144, 272, 288, 8 * 17):      # four corners' tiles, the centre tile and a left-edge tile of the 17 x 17 grid
+        (fl, ft, fr, fb), (ul, ut, ur, ub) = tiles[ti]
+        fw, fh = fr - fl + 1, fb - ft + 1
+        win_left = fl + fw // 2 - o.recommended_input_dim(fw) // 2
+        win_top = ft + fh // 2 - o.recommended_input_dim(fh) // 2
+        d = o.recommended_input_dim(2 * ov + 41)
+        cy, cx = (ut + ub) // 2, (ul + ur) // 2
+        top = win_top + ((cy - d // 2 - win_top) // 4) * 4      # (the net is translation-equivariant for shifts that are multiples of 2^levels)
+        left = win_left + ((cx - d // 2 - win_left) // 4) * 4
+        crop = d_img[top:top + d, left:left + d].cpu().numpy()
+        want = o.forward(crop[None])[0]
+        m = ov
+        got_pl = d_pl[:, top + m:top + d - m, left + m:left + d - m].cpu().numpy()
+        got_lab = d_lab[top + m:top + d - m, left + m:left + d - m].cpu().numpy().view(np.uint16)
+        np.testing.assert_array_equal(got_pl, want[:, m:d - m, m:d - m])
+        np.testing.assert_array_equal(got_lab, want[:, m:d - m, m:d - m].argmax(0))
+        windows.append((top + m, top + d - m, left + m, left + d - m, got_lab))
+    # bf16 mode on the same image: label agreement on the windows
+    p, r = net.get_params()
+    del d_pl
+    net16 = aa.RuntimeNet(aa.net_config(2, 3, 3, 1.0, 1, aa.ANH_BF16))
+    net16.set_params(p, r)
+    d_pl16 = torch.zeros((3, H, W), dtype=torch.float32, device=dev)
+    d_lab16 = torch.zeros((H, W), dtype=torch.int16, device=dev)
+    aa.annonet_infer_device(net16, d_img.data_ptr(), H, W, d_lab16.data_ptr(), d_pl16.data_ptr(), tiling_parameters=tp)
+    net16.synchronize()
+    same = total = 0
+    for (t0, t1, l0, l1, lab32) in windows:
+        lab16 = d_lab16[t0:t1, l0:l1].cpu().numpy().view(np.uint16)
+        same += int((lab16 == lab32).sum()); total += lab32.size
+    assert same / total > 0.97, same / total
+    # ... and on a strided sample of the whole map (every tile contributes)
+    agree = float((d_lab16[::61, ::67] == d_lab[::61, ::67]).float().mean())
+    assert agree > 0.97, agree
+    del d_img, d_lab, d_lab16, d_pl16
+    torch.cuda.empty_cache()
+
+
 def test_grad_bucket_is_a_live_view_and_all_reduce_runs_on_it():
     """The gradient bucket handed to torch.distributed is the library's own HBM (zero copy), and an RCCL all-reduce on it
     (world size 1 on this box) leaves the step's result unchanged."""
