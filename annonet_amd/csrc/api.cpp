@@ -558,7 +558,12 @@ int anh_infer_device(anh_runtime* h, const uint8_t* d_image, int height, int wid
         ANH_REQUIRE(h && d_image && d_blended, "null argument");
         DeviceScope scope(h->device_of(0));
         std::vector<anh_tile> list = tiles ? std::vector<anh_tile>(tiles, tiles + n_tiles) : tiles_for(tiling, width, height);
-        h->eng->infer_device(d_image, height, width, gains, list, d_result, d_blended);
+        bool whole = tiles == nullptr;
+        if (tiles && tiling) {   // a one-rank job hands over its "share": the complete tiling
+            const std::vector<anh_tile> all = tiles_for(tiling, width, height);
+            whole = all.size() == list.size() && std::memcmp(all.data(), list.data(), all.size() * sizeof(anh_tile)) == 0;
+        }
+        h->eng->infer_device(d_image, height, width, gains, list, d_result, d_blended, whole);
     });
 }
 
@@ -776,7 +781,7 @@ int anh_infer(anh_runtime* h, const uint8_t* image, int height, int width, const
         static const bool streamed = !(getenv("ANH_INFER_STREAMED") && atoi(getenv("ANH_INFER_STREAMED")) == 0);
         if (streamed && !use_det && !blended_out) { infer_streamed(h, image, height, width, gains, tiles, result); return; }
         HIP_CHECK(hipMemcpyAsync(e.stage_image.p, image, plane * C, hipMemcpyHostToDevice, e.stream));
-        e.infer_device(e.stage_image.as<uint8_t>(), height, width, gains, tiles, e.stage_result.as<uint16_t>(), e.stage_blended.as<float>());
+        e.infer_device(e.stage_image.as<uint8_t>(), height, width, gains, tiles, e.stage_result.as<uint16_t>(), e.stage_blended.as<float>(), /*whole_image=*/true);
         if (use_det) {
             // detection-level filter (annonet_infer.cpp:187-239), on the resident planes and label map.  Seeds are looked up at
             // (row, col): the reference stores (r, c) but reads (point.y(), point.x()) — transposed (:210 vs :222); see DESIGN.md.

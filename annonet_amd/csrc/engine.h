@@ -124,8 +124,10 @@ class Engine {
     int tile_batch(int h, int w) const;
     const double* upload_gains(const double* gains_host);   // -> device pointer (or nullptr)
     void argmax_rows(const float* d_blended, int H, int W, int row0, int row1, const double* gains_host, uint16_t* d_labels);   // find_label over rows [row0, row1)
+    // whole_image: `tiles` is the image's COMPLETE tiling (then only the frames the blends accumulate into are cleared first)
     void infer_device(const uint8_t* d_image, int H, int W, const double* gains_host, const std::vector<anh_tile>& tiles,
-                      uint16_t* d_labels, float* d_blended);
+                      uint16_t* d_labels, float* d_blended, bool whole_image = false);
+    DevBuf zero_rects; int zero_rects_n = 0; uint64_t zero_rects_key = 0;   // the frames of the last whole-image tiling
 
     // ANH_STEP_GRAPH=1: the backward pass behind the head replayed as a captured HIP graph (Engine::backward)
     struct StepGraph { uint64_t key; int eager_runs; hipGraphExec_t exec; };

@@ -226,6 +226,7 @@ void launch_argmax(const float* blended, int k, int64_t pixels, const double* ga
 void launch_argmax_range(const float* blended, int k, int64_t pixels, int64_t p0, int64_t p1, const double* gains_or_null, uint16_t* labels, hipStream_t s);
 
 void launch_fill_zero(void* p, size_t bytes, hipStream_t s);
+void launch_zero_rects(float* planes, int k, int H, int W, const anh_rect* d_rects, int n, hipStream_t s);   // zero n inclusive rectangles of every plane [k][H][W]
 
 // Training crops cut on the device from full images resident in HBM (randomly_crop_image, annonet_train_main.cpp:110-232,
 // for further_downscaling_factor = 1 and given draws).  kCropMaxClasses bounds the label values the histogram covers.

@@ -2195,6 +2195,25 @@ __global__ __launch_bounds__(256) void fill_zero_kernel(uint4* p, size_t n16, un
 }
 }  // namespace
 
+// zero the pixels of `n` rectangles (inclusive, inside the image) in every one of k planes [k][H][W]: one workgroup per (rectangle, plane, slice)
+namespace {
+__global__ __launch_bounds__(256) void zero_rects_kernel(float* planes, int H, int W, const anh_rect* rects) {
+    const anh_rect r = rects[blockIdx.x];
+    const int w = (int)(r.right - r.left + 1), h = (int)(r.bottom - r.top + 1);
+    if (w <= 0 || h <= 0) return;
+    float* base = planes + ((size_t)blockIdx.y * H + r.top) * W + r.left;
+    for (int i = (int)blockIdx.z * 256 + (int)threadIdx.x; i < w * h; i += (int)gridDim.z * 256) {
+        const int y = i / w, x = i - y * w;
+        base[(size_t)y * W + x] = 0.f;
+    }
+}
+}  // namespace
+void launch_zero_rects(float* planes, int k, int H, int W, const anh_rect* d_rects, int n, hipStream_t s) {
+    if (n <= 0 || k <= 0) return;
+    hipLaunchKernelGGL(zero_rects_kernel, dim3((unsigned)n, (unsigned)k, 8), dim3(256), 0, s, planes, H, W, d_rects);
+    HIP_CHECK(hipGetLastError());
+}
+
 void launch_fill_zero(void* p, size_t bytes, hipStream_t s) {
     if (!bytes) return;
     if (bytes < (size_t)1 << 20 || (reinterpret_cast<uintptr_t>(p) & 15)) { HIP_CHECK(hipMemsetAsync(p, 0, bytes, s)); return; }
