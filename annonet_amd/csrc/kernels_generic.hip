@@ -692,18 +692,22 @@ __global__ __launch_bounds__(256) void wgrad_generic_kernel(WgradArgs a, int64_t
 // x float4) and deals the splits round-robin to its 16 lane rows; each row sums its splits in order (double), then
 // the 16 rows are summed in order.  nw is a multiple of 4 for every filter this build has (3x3 and 5x5 with >= 4
 // channel products); the scalar tail handles anything else.
-__global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __restrict__ partials, int splits, int64_t nw, float* __restrict__ out) {
-    __shared__ double sh[16][64][4];
-    const int64_t i = ((int64_t)blockIdx.x * 64 + threadIdx.x) * 4;
+// XW lanes x 4 elements per workgroup, YR rows of threads each summing every YR-th partial.  (64, 16) streams wide rows; (16, 64) — four times
+// the workgroups, a quarter of the partials per thread — is for short sums: the 32 -> 64 stride-2 layer's 18,432 elements ran as 72
+// workgroups of the wide form, 51 us beside the stem's filter gradient at the tail of a step.
+template <int XW, int YR>
+__global__ __launch_bounds__(XW * YR) void reduce_partials_kernel(const float* __restrict__ partials, int splits, int64_t nw, float* __restrict__ out) {
+    __shared__ double sh[YR][XW][4];
+    const int64_t i = ((int64_t)blockIdx.x * XW + threadIdx.x) * 4;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     if (i + 3 < nw && (nw & 3) == 0) {
 #pragma unroll 4
-        for (int k = threadIdx.y; k < splits; k += 16) {
+        for (int k = threadIdx.y; k < splits; k += YR) {
             const float4 v = *reinterpret_cast<const float4*>(partials + (size_t)k * nw + i);
             s0 += (double)v.x; s1 += (double)v.y; s2 += (double)v.z; s3 += (double)v.w;
         }
     } else {
-        for (int k = threadIdx.y; k < splits; k += 16) {
+        for (int k = threadIdx.y; k < splits; k += YR) {
             const float* row = partials + (size_t)k * nw;
             if (i < nw) s0 += (double)row[i];
             if (i + 1 < nw) s1 += (double)row[i + 1];
@@ -718,7 +722,7 @@ __global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __re
         const int e = threadIdx.y;
         double t = 0.0;
 #pragma unroll
-        for (int g = 0; g < 16; ++g) t += sh[g][threadIdx.x][e];
+        for (int g = 0; g < YR; ++g) t += sh[g][threadIdx.x][e];
         if (i + e < nw) out[i + e] = (float)t;
     }
 }
@@ -1850,7 +1854,10 @@ void launch_wgrad_generic(const WgradArgs& a, hipStream_t s) {
 }
 
 void launch_reduce_partials(const float* partials, int splits, int64_t nw, float* out, hipStream_t s) {
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(64, 16), 0, s, partials, splits, nw, out);
+    if (nw < (int64_t)256 * 256 && splits >= 64)   // fewer than one wide workgroup per CU: the narrow form (a fixed order of its own: chosen by the shape alone)
+        hipLaunchKernelGGL((reduce_partials_kernel<16, 64>), dim3((unsigned)((nw + 63) / 64)), dim3(16, 64), 0, s, partials, splits, nw, out);
+    else
+        hipLaunchKernelGGL((reduce_partials_kernel<64, 16>), dim3((unsigned)((nw + 255) / 256)), dim3(64, 16), 0, s, partials, splits, nw, out);
     HIP_CHECK(hipGetLastError());
 }
 
