@@ -576,7 +576,9 @@ def infer_one_size(args, side, with_cpu_baseline, aa, aad, torch, dist, prec, ra
             min_bytes = (bytes_1 - w_bytes) * tiles_per_launch + w_bytes
             roof = bound_of(flops, min_bytes, avg_s)
             roof.pop("floor_us")
-            roof.update(traffic=pmc_traffic(dominant, INFER_TRAFFIC_JSON) if side == 4096 and world == 1 else None, kernel=dominant, layer=li,
+            roof.update(traffic=pmc_traffic(dominant, INFER_TRAFFIC_JSON) if side == 4096 and world == 1 else None,
+                        traffic_source=(f"not measured in this run: HBM bytes per launch of this entry from the committed rocprofv3 --pmc passes ({os.path.basename(INFER_TRAFFIC_JSON)}; tools/pmc_traffic.py)" if INFER_TRAFFIC_JSON and side == 4096 and world == 1 else None),
+                        kernel=dominant, layer=li,
                         avg_launch_us=avg_s * 1e6, launches=e["launches"], tiles_per_launch=tiles_per_launch,
                         algorithmic_flops_per_launch=flops, algorithmic_bytes_per_launch=min_bytes, design_bytes_per_launch=e["bytes"] / e["launches"],
                         arithmetic_intensity=flops / min_bytes, bytes_convention="SURVEY 8d minimum: one input + output + filters (skip operand not counted)")
