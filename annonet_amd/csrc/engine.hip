@@ -964,6 +964,24 @@ void Engine::infer_tiles(const anh_tile* ts, int count, const uint8_t* d_image, 
     }
     const size_t es = elem_size(dtype);
     const hipStream_t bs = stream;   // (a batch's blends on a second stream beside the next batch's convs measured no gain in round 4: the persistent conv kernels hold every CU)
+    // the whole batch's tiles by ONE blend launch (round 5): unique-rectangle pixels are assignments, a frame pixel is gathered by the first
+    // tile of the batch that covers it, contributions in list order — bit for bit what `count` launches in list order leave
+    static const bool batch_blend = !(getenv("ANH_BLEND_BATCH") && atoi(getenv("ANH_BLEND_BATCH")) == 0);
+    if (batch_blend && count > 1 && !(fuse_head && !head_epi) && K <= 4 && (int64_t)H * W < 0x7fffffffll) {
+        BlendBatchArgs bb;
+        bb.logits = tout.as<float>(); bb.blended = d_blended; bb.k = K; bb.count = count; bb.tile_h = win.height; bb.tile_w = win.width; bb.img_h = H; bb.img_w = W;
+        for (int i = 0; i < count; ++i) {
+            const TileWindow wi = tile_window(ts[i], spec.cfg.levels);
+            bb.left[i] = wi.left; bb.top[i] = wi.top;
+            const anh_rect &f = ts[i].full_rect, &u = ts[i].unique_rect;
+            bb.full[i][0] = (int)f.left; bb.full[i][1] = (int)f.top; bb.full[i][2] = (int)f.right; bb.full[i][3] = (int)f.bottom;
+            bb.unique[i][0] = (int)u.left; bb.unique[i][1] = (int)u.top; bb.unique[i][2] = (int)u.right; bb.unique[i][3] = (int)u.bottom;
+        }
+        const int tok = prof.begin(bs, "blend_accumulate", 0, (double)count * K * win.height * win.width * 12);
+        launch_blend_batch(bb, bs);
+        prof.end(bs, tok);
+        return;
+    }
     for (int i = 0; i < count; ++i) {
         const anh_tile& t = ts[i];
         const TileWindow wi = tile_window(t, spec.cfg.levels);

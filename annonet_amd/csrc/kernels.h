@@ -212,6 +212,16 @@ struct BlendArgs {
     long full[4] = {0, 0, 0, 0}, unique[4] = {0, 0, 0, 0};  // l,t,r,b
 };
 void launch_blend(const BlendArgs& a, hipStream_t s);
+// The tiles of one inference batch (equal windows; logits [count][K][th][tw]) blended by ONE launch, with the result of `count` launch_blend
+// calls in list order: inside its unique rectangle a tile assigns (no order involved); a frame pixel is handled by the FIRST tile of the
+// batch that covers it, which adds the contributions of every covering tile of the batch in list order (annonet_infer.cpp:116-164).
+struct BlendBatchArgs {
+    const float* logits = nullptr; float* blended = nullptr;
+    int k = 0, count = 0, tile_h = 0, tile_w = 0, img_h = 0, img_w = 0;
+    int left[16] = {}, top[16] = {};
+    int full[16][4] = {}, unique[16][4] = {};   // l, t, r, b (inclusive, image coordinates)
+};
+void launch_blend_batch(const BlendBatchArgs& a, hipStream_t s);
 // bf16 inference: the 1x1 head (32 -> K <= 4 channels, bias) and the blend in one pass over the last hidden tensor — the tile's
 // logits never go to memory.  BlendArgs::logits_nchw is unused.  head_blend_supported() decides.
 struct HeadBlendArgs {

@@ -1549,6 +1549,37 @@ __global__ __launch_bounds__(256) void blend_kernel(BlendArgs a) {
     }
 }
 
+// One launch for the tiles of a batch (BlendBatchArgs): blockIdx.z = tile.  Same arithmetic as blend_kernel — float += double * float without
+// contraction — in the same order per pixel: tiles of EARLIER batches have been added by earlier launches, the batch's own in list order here.
+__global__ __launch_bounds__(256) void blend_batch_kernel(BlendBatchArgs a) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y, t = blockIdx.z;
+    if (x >= a.tile_w) return;
+    const int bx = a.left[t] + x, by = a.top[t] + y;
+    if (by < a.full[t][1] || by > a.full[t][3] || by < 0 || by >= a.img_h) return;
+    if (bx < a.full[t][0] || bx > a.full[t][2] || bx < 0 || bx >= a.img_w) return;
+    const size_t tile_px = (size_t)a.tile_h * a.tile_w, img_px = (size_t)a.img_h * a.img_w;
+    float* out = a.blended + (size_t)by * a.img_w + bx;
+    if (bx >= a.unique[t][0] && bx <= a.unique[t][2] && by >= a.unique[t][1] && by <= a.unique[t][3]) {
+        const float* in = a.logits + (size_t)t * a.k * tile_px + (size_t)y * a.tile_w + x;
+        for (int k = 0; k < a.k; ++k) out[(size_t)k * img_px] = in[(size_t)k * tile_px];
+        return;
+    }
+    for (int j = 0; j < t; ++j)   // an earlier tile of the batch covers this pixel: it gathers
+        if (bx >= a.full[j][0] && bx <= a.full[j][2] && by >= a.full[j][1] && by <= a.full[j][3]) return;
+    float acc[4];
+    for (int k = 0; k < a.k; ++k) acc[k] = out[(size_t)k * img_px];
+    for (int j = t; j < a.count; ++j) {
+        if (!(bx >= a.full[j][0] && bx <= a.full[j][2] && by >= a.full[j][1] && by <= a.full[j][3])) continue;
+        const double th = ramp(bx, a.full[j][0], a.unique[j][0], a.unique[j][2], a.full[j][2]);
+        const double tv = ramp(by, a.full[j][1], a.unique[j][1], a.unique[j][3], a.full[j][3]);
+        const double w = __dmul_rn(th, tv);
+        const float* in = a.logits + (size_t)j * a.k * tile_px + (size_t)(by - a.top[j]) * a.tile_w + (bx - a.left[j]);
+        for (int k = 0; k < a.k; ++k) acc[k] = (float)__dadd_rn((double)acc[k], __dmul_rn(w, (double)in[(size_t)k * tile_px]));
+    }
+    for (int k = 0; k < a.k; ++k) out[(size_t)k * img_px] = acc[k];
+}
+
 // head_blend (bf16 inference): logits = relu(bn(y)) . W + b for one tile pixel, blended straight into the resident planes.
 // Four lanes share a pixel (8 channels = one 16-byte chunk each; a wave reads 1 KiB of contiguous NHWC per instruction) and
 // combine their partial logits with two xor-shuffles, as head_train does; lane `sub` then blends class `sub`.
@@ -2073,6 +2104,13 @@ void launch_head_blend(const HeadBlendArgs& a, hipStream_t s) {
         case SRC_RAW: hipLaunchKernelGGL(head_blend_kernel<SRC_RAW>, dim3(blocks), dim3(256), 0, s, a); break;
         default: hipLaunchKernelGGL(head_blend_kernel<SRC_SUM2>, dim3(blocks), dim3(256), 0, s, a); break;
     }
+    HIP_CHECK(hipGetLastError());
+}
+
+void launch_blend_batch(const BlendBatchArgs& a, hipStream_t s) {
+    if (a.tile_w <= 0 || a.tile_h <= 0 || a.count <= 0) return;
+    ANH_REQUIRE(a.count <= 16 && a.k >= 1 && a.k <= 4, "blend_batch: at most 16 tiles of at most 4 classes");
+    hipLaunchKernelGGL(blend_batch_kernel, dim3((a.tile_w + 255) / 256, a.tile_h, a.count), dim3(256), 0, s, a);
     HIP_CHECK(hipGetLastError());
 }
 
