@@ -46,7 +46,7 @@ KERNELS = [
     (r"^bn_tables_zero$", []),                       # a runtime fill, not a kernel of this library
     (r"^bn_fold_all$", [r"bn_fold_all_kernel"]),
     (r"^head_blend_fused$", [r"head_blend_kernel"]),
-    (r"^blend_accumulate$", [r"(?<!head_)blend_kernel"]),
+    (r"^blend_accumulate$", [r"(?<!head_)blend(_batch)?_kernel"]),
     (r"^argmax_gain$", [r"argmax_kernel"]),
 ]
 OURS = re.compile(r"anh::|_ZN3anh")          # kernels of this library (everything else in the trace: runtime copies / fills)
