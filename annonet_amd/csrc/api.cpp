@@ -925,6 +925,7 @@ int anh_trainer_apply_update(anh_trainer* h, double grad_scale) {
     });
 }
 
+extern "C++" {
 namespace {
 // Packs samples of a host mini-batch into one of a replica's two pinned staging sets, uploads them on the replica's copy stream
 // and enqueues forward + backward behind the upload.  Returns once the inputs are packed (the host refills its vectors right
@@ -988,6 +989,7 @@ anh_trainer::StageSet& stage_and_run(anh_trainer* h, Engine& e, anh_trainer::Sta
     return st;
 }
 }  // namespace
+}  // extern "C++"
 
 int anh_trainer_step(anh_trainer* h, const uint8_t* const* images, const anh_wlabel* const* labels, int n, int height, int width) {
     return guarded([&] {

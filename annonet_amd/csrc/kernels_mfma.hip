@@ -265,12 +265,29 @@ __device__ __forceinline__ void store_pixel_tiles_act(const f32x16 (&acc)[NT], c
     }
 }
 
-// Inference epilogue of the layer under the 1x1 head: the activation of store_pixel_tiles_act (same rounding), not stored — after the
-// permlane swap this lane holds two of the pixel's four 8-channel chunks (channels 16 s + 8 half ...), which are exactly the chunks of
-// head_blend_kernel's four lanes: chunk sums chained over ascending channels from 0, (chunk 0 + chunk 1) + (chunk 2 + chunk 3), + bias.
-// hw[s][j][k] = head weight of channel 16 s + 8 half + j, class k (zero beyond head_k).  Half 0 stores classes 0 and 2, half 1 classes 1 and 3.
+// Inference epilogue of the layer under the 1x1 head: the activation of store_pixel_tiles_act (same rounding), not stored.  The head is
+// two more MFMAs on the matrix core the conv just used (round 5; 64 multiply-adds, 16 unpacks and 12 cross-half operations per lane
+// before: that epilogue was as long as the tile's MFMA phase).  BEFORE the permlane swap of store_pixel_tiles_act the lane (pixel `col`,
+// half h) holds, as packed pairs, channels 16 s + 8 (j >> 2) + 4 h + (j & 3), j = 0..7 of step s: a valid B operand of a 32x32x16 MFMA
+// whose reduction index is a PERMUTATION of the channels.  The A operand (head_operand below) holds the head weights in that same
+// permutation, split in two bf16 terms so that an fp32 weight keeps 16 mantissa bits: row k (k < 4) = bf16(w[.][k]), row 4 + k =
+// bf16(w - bf16(w)); every other row zero.  Rows 0..3 land in register k of the lower half, rows 4..7 in register k of the upper half:
+// logit = (hi + lo) + bias after one permlane swap per class.  Half 0 stores classes 0 and 2, half 1 classes 1 and 3.
+// (The separate head kernels sum in another order: tests compare the two forms within a tolerance, not bit for bit.)
+__device__ __forceinline__ void head_operand(bf16x8 (&ha)[2], const ConvArgs& a, int col, int half) {
+    const int k = col & 3, part = col >> 2;   // part 0: leading term, 1: remainder, >= 2: zero row
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int ch = 16 * s + 8 * (j >> 2) + 4 * half + (j & 3);
+            const float w = (k < a.head_k && part < 2) ? a.head_w[ch * a.head_k + k] : 0.f;
+            const bf16 hi = (bf16)w;
+            ha[s][j] = part == 0 ? hi : (bf16)(w - (float)hi);
+        }
+}
 __device__ __forceinline__ void store_pixel_tiles_head(const f32x16& acc, const ConvArgs& a, size_t pix, int n, bool valid, int half, const float* act, int cw,
-                                                       const float (&hw)[2][8][4], const float (&hbias)[4]) {
+                                                       const bf16x8 (&ha)[2], const float (&hbias)[4]) {
     float v[16];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -281,33 +298,21 @@ __device__ __forceinline__ void store_pixel_tiles_head(const f32x16& acc, const 
         v[4 * q + 2] = fmaf(acc[4 * q + 2], sc.z, sh.z);
         v[4 * q + 3] = fmaf(acc[4 * q + 3], sc.w, sh.w);
     }
-    float part[2][4];   // chunk sums of this lane's two chunks
+    f32x16 d;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) d[r] = 0.f;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-        const unsigned a0 = relu_bf16x2(pack2(v[8 * s + 0], v[8 * s + 1])), a1 = relu_bf16x2(pack2(v[8 * s + 2], v[8 * s + 3]));
-        const unsigned b0 = relu_bf16x2(pack2(v[8 * s + 4], v[8 * s + 5])), b1 = relu_bf16x2(pack2(v[8 * s + 6], v[8 * s + 7]));
-        auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
-        auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
-        const unsigned w4[4] = {r0[0], r1[0], r0[1], r1[1]};   // channels 16 s + 8 half + 0 .. 7, two per word
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            float sum = 0.f;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                sum = fmaf(lo_f(w4[i]), hw[s][2 * i][k], sum);
-                sum = fmaf(hi_f(w4[i]), hw[s][2 * i + 1][k], sum);
-            }
-            part[s][k] = sum;
-        }
+        const u32x4 w4 = {relu_bf16x2(pack2(v[8 * s + 0], v[8 * s + 1])), relu_bf16x2(pack2(v[8 * s + 2], v[8 * s + 3])),
+                          relu_bf16x2(pack2(v[8 * s + 4], v[8 * s + 5])), relu_bf16x2(pack2(v[8 * s + 6], v[8 * s + 7]))};
+        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ha[s], __builtin_bit_cast(bf16x8, w4), d, 0, 0, 0);
     }
     const size_t plane = (size_t)a.h_out * a.w_out;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        // the other half's chunk sums: chunk 2 s + (1 - half)
-        auto x0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(part[0][k]), __float_as_uint(part[0][k]), false, false);
-        auto x1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(part[1][k]), __float_as_uint(part[1][k]), false, false);
-        const float o0 = __uint_as_float(half ? x0[0] : x0[1]), o1 = __uint_as_float(half ? x1[0] : x1[1]);
-        const float z = ((part[0][k] + o0) + (part[1][k] + o1)) + hbias[k];
+        auto x = __builtin_amdgcn_permlane32_swap(__float_as_uint(d[k]), __float_as_uint(d[k]), false, false);
+        const float other = __uint_as_float(half ? x[0] : x[1]);
+        const float z = (half ? other + d[k] : d[k] + other) + hbias[k];   // (leading + remainder) + bias in both halves
         if (valid && k < a.head_k && (k & 1) == half) a.head_out[pix + ((size_t)n * (a.head_k - 1) + k) * plane] = z;
     }
 }
@@ -1604,16 +1609,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a, int tile
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) wb0[ks] = swz_addr(smem, col, col >> 2, ks, half);   // + the slab's block offset per item
         f32x16 acc[G::ACC][NT];
-        float hw[HEAD ? 2 : 1][HEAD ? 8 : 1][4], hbias[4] = {0.f, 0.f, 0.f, 0.f};   // HEAD: this lane's share of the 1x1 head (store_pixel_tiles_head)
+        bf16x8 hw[2];   // HEAD: this lane's rows of the 1x1 head's MFMA operand (head_operand)
+        float hbias[4] = {0.f, 0.f, 0.f, 0.f};
         if constexpr (HEAD) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                hbias[k] = k < a.head_k ? a.head_bias[k] : 0.f;
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) hw[s2][j][k] = k < a.head_k ? a.head_w[(16 * s2 + 8 * half + j) * a.head_k + k] : 0.f;
-            }
+            for (int k = 0; k < 4; ++k) hbias[k] = k < a.head_k ? a.head_bias[k] : 0.f;
+            head_operand(hw, a, col, half);
         }
         u32x4 old[FWD ? 1 : G::ACC][NT][2];   // prefetched old values of a read-modify-write destination (GeoUp)
         u32x4 yraw[FWD ? 1 : G::ACC][NT][2];  // prefetched raw outputs y of the layer whose da is written (fused bn backward reduction)
