@@ -220,8 +220,9 @@ struct BlendBatchArgs {
     int k = 0, count = 0, tile_h = 0, tile_w = 0, img_h = 0, img_w = 0;
     int left[16] = {}, top[16] = {};
     int full[16][4] = {}, unique[16][4] = {};   // l, t, r, b (inclusive, image coordinates)
+    unsigned nbr[16] = {};                       // bit j: tile j's full rectangle intersects this tile's (launch_blend_batch fills it)
 };
-void launch_blend_batch(const BlendBatchArgs& a, hipStream_t s);
+void launch_blend_batch(BlendBatchArgs a, hipStream_t s);
 // bf16 inference: the 1x1 head (32 -> K <= 4 channels, bias) and the blend in one pass over the last hidden tensor — the tile's
 // logits never go to memory.  BlendArgs::logits_nchw is unused.  head_blend_supported() decides.
 struct HeadBlendArgs {

@@ -1565,11 +1565,17 @@ __global__ __launch_bounds__(256) void blend_batch_kernel(BlendBatchArgs a) {
         for (int k = 0; k < a.k; ++k) out[(size_t)k * img_px] = in[(size_t)k * tile_px];
         return;
     }
-    for (int j = 0; j < t; ++j)   // an earlier tile of the batch covers this pixel: it gathers
+    // only the tiles whose full rectangles intersect this one's can cover the pixel (a.nbr[t]: at most eight on a regular tiling, against
+    // `count` candidates per loop before: the frame path — 16 % of the pixels, a third of the waves — was most of this kernel's instructions)
+    const unsigned near = a.nbr[t];
+    for (unsigned e = near & ((1u << t) - 1u); e; e &= e - 1u) {   // an earlier tile of the batch covers this pixel: it gathers
+        const int j = __builtin_ctz(e);
         if (bx >= a.full[j][0] && bx <= a.full[j][2] && by >= a.full[j][1] && by <= a.full[j][3]) return;
+    }
     float acc[4];
     for (int k = 0; k < a.k; ++k) acc[k] = out[(size_t)k * img_px];
-    for (int j = t; j < a.count; ++j) {
+    for (unsigned e = (near | (1u << t)) & ~((1u << t) - 1u); e; e &= e - 1u) {   // this tile, then the later ones, in list order
+        const int j = __builtin_ctz(e);
         if (!(bx >= a.full[j][0] && bx <= a.full[j][2] && by >= a.full[j][1] && by <= a.full[j][3])) continue;
         const double th = ramp(bx, a.full[j][0], a.unique[j][0], a.unique[j][2], a.full[j][2]);
         const double tv = ramp(by, a.full[j][1], a.unique[j][1], a.unique[j][3], a.full[j][3]);
@@ -1679,8 +1685,57 @@ __global__ __launch_bounds__(256) void head_blend_kernel(HeadBlendArgs a) {
 }
 
 // find_label (annonet_infer.cpp:170-185): strict '>' from -inf, start label 65535, gain added in double
+__device__ __forceinline__ uint16_t find_label(const float* v, int k, const double* gains) {
+    uint16_t label = ANH_LABEL_IGNORE;
+    float best = -INFINITY;
+    for (int c = 0; c < k; ++c) {
+        const float value = (float)__dadd_rn((double)v[c], gains ? gains[c] : 0.0);
+        if (value > best) { label = (uint16_t)c; best = value; }
+    }
+    return label;
+}
+// four pixels per thread while the class count allows (k <= 8: 16-byte plane loads, dword-aligned; one 8-byte label store)
+typedef float f32x4a4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef unsigned short u16x4a2 __attribute__((ext_vector_type(4), aligned(2)));
 __global__ __launch_bounds__(256) void argmax_kernel(const float* blended, int k, int64_t pixels, int64_t p0, int64_t p1, const double* gains, uint16_t* labels) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    if (k <= 8) {
+        double g[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) g[c] = (gains && c < k) ? gains[c] : 0.0;
+        for (int64_t p = p0 + 4 * ((int64_t)blockIdx.x * blockDim.x + threadIdx.x); p < p1; p += 4 * stride) {
+            if (p + 3 < p1) {
+                float v[4][8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c)
+                    if (c < k) {
+                        const f32x4a4 q = *reinterpret_cast<const f32x4a4*>(blended + (size_t)c * pixels + p);
+                        v[0][c] = q[0]; v[1][c] = q[1]; v[2][c] = q[2]; v[3][c] = q[3];
+                    }
+                u16x4a2 l;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    uint16_t label = ANH_LABEL_IGNORE;
+                    float best = -INFINITY;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c)
+                        if (c < k) {
+                            const float value = (float)__dadd_rn((double)v[i][c], g[c]);
+                            if (value > best) { label = (uint16_t)c; best = value; }
+                        }
+                    l[i] = label;
+                }
+                *reinterpret_cast<u16x4a2*>(labels + p) = l;
+            } else {
+                for (int64_t q = p; q < p1; ++q) {
+                    float v[8];
+                    for (int c = 0; c < k; ++c) v[c] = blended[(size_t)c * pixels + q];
+                    labels[q] = find_label(v, k, gains);
+                }
+            }
+        }
+        return;
+    }
     for (int64_t p = p0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < p1; p += stride) {
         uint16_t label = ANH_LABEL_IGNORE;
         float best = -INFINITY;
@@ -2107,9 +2162,14 @@ void launch_head_blend(const HeadBlendArgs& a, hipStream_t s) {
     HIP_CHECK(hipGetLastError());
 }
 
-void launch_blend_batch(const BlendBatchArgs& a, hipStream_t s) {
+void launch_blend_batch(BlendBatchArgs a, hipStream_t s) {
     if (a.tile_w <= 0 || a.tile_h <= 0 || a.count <= 0) return;
     ANH_REQUIRE(a.count <= 16 && a.k >= 1 && a.k <= 4, "blend_batch: at most 16 tiles of at most 4 classes");
+    for (int i = 0; i < a.count; ++i) {
+        a.nbr[i] = 0;
+        for (int j = 0; j < a.count; ++j)
+            if (j != i && a.full[i][0] <= a.full[j][2] && a.full[j][0] <= a.full[i][2] && a.full[i][1] <= a.full[j][3] && a.full[j][1] <= a.full[i][3]) a.nbr[i] |= 1u << j;
+    }
     hipLaunchKernelGGL(blend_batch_kernel, dim3((a.tile_w + 255) / 256, a.tile_h, a.count), dim3(256), 0, s, a);
     HIP_CHECK(hipGetLastError());
 }
@@ -2126,7 +2186,8 @@ void launch_argmax(const float* blended, int k, int64_t pixels, const double* ga
 // labels of the pixels [p0, p1) of planes that hold `pixels` pixels each
 void launch_argmax_range(const float* blended, int k, int64_t pixels, int64_t p0, int64_t p1, const double* gains_or_null, uint16_t* labels, hipStream_t s) {
     if (p1 <= p0) return;
-    const int blocks = (int)std::min<int64_t>((p1 - p0 + 255) / 256, 256 * 16);
+    const int64_t per = k <= 8 ? 1024 : 256;   // pixels per workgroup and pass
+    const int blocks = (int)std::min<int64_t>((p1 - p0 + per - 1) / per, 256 * 16);
     hipLaunchKernelGGL(argmax_kernel, dim3(blocks), dim3(256), 0, s, blended, k, pixels, p0, p1, gains_or_null, labels);
     HIP_CHECK(hipGetLastError());
 }
