@@ -173,7 +173,8 @@ def test_tile_batch_size_does_not_change_the_result(tmp_path):
     head_forms_agree(sep, runs["4"])
     # the XCD-band tile walk against the grid-stride walk, and the 32-channel conv's filter fragments in registers against LDS reads
     # every item: the same values to the same addresses
-    for env in ({"ANH_WS_XCD_BANDS": "0"}, {"ANH_WS_FILTER_REGS": "0"}):
+    # ... and one blend launch per tile against one per tile batch
+    for env in ({"ANH_WS_XCD_BANDS": "0"}, {"ANH_WS_FILTER_REGS": "0"}, {"ANH_BLEND_BATCH": "0"}):
         out = str(tmp_path / ("variant_" + "_".join(env) + ".npz"))
         r = subprocess.run([sys.executable, os.path.join(here, "helpers", "run_tiled_infer.py"), out, "1.0", "1", "3", "2"], env=dict(os.environ, **env),
                            capture_output=True, text=True, timeout=600)
