@@ -108,8 +108,8 @@ class ReplicaWorkers {
     size_t replicas() const { return devices_.size(); }
     uint64_t calls() const { return calls_.load(std::memory_order_relaxed); }   // (tests: the pool was used, and how often)
 
-    // One call at a time per pool: `call_mu_` is held for the whole call, so a second host thread on the same handle (or a nested
-    // each_replica) waits instead of overwriting job_ / pending_ — the contract stays "one thread per handle" (annonet_hip.h), this only
+    // One call at a time per pool: `call_mu_` is held for the whole call, so a second host thread on the same handle waits
+    // instead of overwriting job_ / pending_ (a NESTED call is refused: it could never finish) — the contract stays "one thread per handle" (annonet_hip.h), this only
     // makes a violation safe.  The wait for the stragglers has a DEADLINE (ANH_REPLICA_TIMEOUT_S, default 180 s — the collective
     // timeout of the one-process-per-GPU host, bench.py --collective-timeout): a worker that never comes back is a replica stuck in
     // a HIP / RCCL call; its job references this frame, so the call cannot unwind — the process ends with a message and exit code 3
@@ -118,7 +118,10 @@ class ReplicaWorkers {
     void run(F&& fn) {
         const size_t R = devices_.size();
         if (R <= 1) { if (R == 1) fn((size_t)0); return; }
+        // a job that itself calls run() — from the calling thread or from a worker — can never finish (the pool is busy with it): refuse
+        ANH_REQUIRE(!inside_job(), "ReplicaWorkers::run called from inside a replica job (each_replica does not nest)");
         std::lock_guard<std::mutex> one_call(call_mu_);
+        struct Inside { Inside() { inside_job() = true; } ~Inside() { inside_job() = false; } } inside;
         std::function<void(size_t)> job = [&fn](size_t r) { fn(r); };
         {
             std::lock_guard<std::mutex> lock(mu_);
@@ -145,8 +148,10 @@ class ReplicaWorkers {
     static int replica_timeout_s() { return replica_timeout_seconds() + 30; }   // (the workers' own device waits are bounded: let them report first)
 
   private:
+    static bool& inside_job() { static thread_local bool v = false; return v; }
     void loop(size_t r) {
         (void)hipSetDevice(devices_[r]);   // once: every DeviceScope of this replica's calls is then a no-op
+        inside_job() = true;               // a worker thread only ever runs jobs
         uint64_t seen = 0;
         for (;;) {
             const std::function<void(size_t)>* job = nullptr;
