@@ -977,10 +977,12 @@ void Engine::infer_tiles(const anh_tile* ts, int count, const uint8_t* d_image, 
             bb.full[i][0] = (int)f.left; bb.full[i][1] = (int)f.top; bb.full[i][2] = (int)f.right; bb.full[i][3] = (int)f.bottom;
             bb.unique[i][0] = (int)u.left; bb.unique[i][1] = (int)u.top; bb.unique[i][2] = (int)u.right; bb.unique[i][3] = (int)u.bottom;
         }
-        const int tok = prof.begin(bs, "blend_accumulate", 0, (double)count * K * win.height * win.width * 12);
-        launch_blend_batch(bb, bs);
-        prof.end(bs, tok);
-        return;
+        if (blend_batch_ok(bb)) {
+            const int tok = prof.begin(bs, "blend_accumulate", 0, (double)count * K * win.height * win.width * 12);
+            launch_blend_batch(bb, bs);
+            prof.end(bs, tok);
+            return;
+        }
     }
     for (int i = 0; i < count; ++i) {
         const anh_tile& t = ts[i];

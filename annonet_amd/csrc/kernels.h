@@ -222,6 +222,7 @@ struct BlendBatchArgs {
     int full[16][4] = {}, unique[16][4] = {};   // l, t, r, b (inclusive, image coordinates)
     unsigned nbr[16] = {};                       // bit j: tile j's full rectangle intersects this tile's (launch_blend_batch fills it)
 };
+bool blend_batch_ok(const BlendBatchArgs& a);   // the batch's unique rectangles are reached by no other tile of it (else: per-tile launches)
 void launch_blend_batch(BlendBatchArgs a, hipStream_t s);
 // bf16 inference: the 1x1 head (32 -> K <= 4 channels, bias) and the blend in one pass over the last hidden tensor — the tile's
 // logits never go to memory.  BlendArgs::logits_nchw is unused.  head_blend_supported() decides.

@@ -2162,6 +2162,18 @@ void launch_head_blend(const HeadBlendArgs& a, hipStream_t s) {
     HIP_CHECK(hipGetLastError());
 }
 
+// The kernel's shortcut — a pixel inside a tile's unique rectangle is assigned by that tile and by nobody else — holds when no OTHER tile's
+// full rectangle reaches into a unique rectangle, which is what tiling::get_tiles produces (the reference asserts it: `out == 0.f` before the
+// assignment, annonet_infer.cpp:158).  A caller's own tile list may break it; such a batch takes the per-tile launches, which are the
+// reference's loop literally.
+bool blend_batch_ok(const BlendBatchArgs& a) {
+    if (a.count > 16 || a.k < 1 || a.k > 4) return false;
+    for (int i = 0; i < a.count; ++i)
+        for (int j = 0; j < a.count; ++j)
+            if (j != i && a.unique[i][0] <= a.full[j][2] && a.full[j][0] <= a.unique[i][2] && a.unique[i][1] <= a.full[j][3] && a.full[j][1] <= a.unique[i][3]) return false;
+    return true;
+}
+
 void launch_blend_batch(BlendBatchArgs a, hipStream_t s) {
     if (a.tile_w <= 0 || a.tile_h <= 0 || a.count <= 0) return;
     ANH_REQUIRE(a.count <= 16 && a.k >= 1 && a.k <= 4, "blend_batch: at most 16 tiles of at most 4 classes");

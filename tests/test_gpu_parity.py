@@ -84,6 +84,29 @@ def test_fp32_tiled_infer_is_bit_exact(H, W, max_tile):
                                   o.infer(img, gains=gains, max_tile=(max_tile, max_tile), overlap=ov))
 
 
+def test_caller_tile_list_whose_frames_reach_into_unique_rectangles_is_blended_sequentially():
+    """tiling::get_tiles never lets a tile's full rectangle reach into another tile's unique rectangle (the reference asserts `out == 0.f`
+    before an assignment, annonet_infer.cpp:158), and the one-launch-per-batch blend relies on it.  A caller's own tile list may break it:
+    such a batch must take the per-tile launches — the reference's loop literally (assign, then the later tile's ramp added on top)."""
+    import torch
+    o, net = pair(1, 3, 3, 0.25, 4, aa.ANH_FP32, seed=9)
+    H, W = 40, 90
+    img = np.random.default_rng(5).integers(0, 256, (H, W, 3), dtype=np.uint8)
+    # two tiles with equal windows (one batch); the second one's frame (x = 40..59) covers x = 40..49 of the first one's unique rectangle
+    tiles = [((0, 0, 49, H - 1), (0, 0, 49, H - 1)), ((40, 0, W - 1, H - 1), (60, 0, W - 1, H - 1))]
+    want_labels, want_bl = o.infer(img, tiles=tiles, want_blended=True)
+    assert np.abs(want_bl[:, :, 40:50] - o.infer(img, tiles=tiles[:1], want_blended=True)[1][:, :, 40:50]).max() > 0   # the case is not vacuous
+    dev = torch.device("cuda", 0)
+    d_img = torch.from_numpy(img).to(dev)
+    d_lab = torch.zeros((H, W), dtype=torch.int16, device=dev)
+    d_bl = torch.full((3, H, W), 7.0, dtype=torch.float32, device=dev)   # dirty planes: the call clears what it must
+    torch.cuda.synchronize()
+    aa.annonet_infer_device(net, d_img.data_ptr(), H, W, d_lab.data_ptr(), d_bl.data_ptr(), tiles=tiles)
+    net.synchronize()
+    np.testing.assert_array_equal(d_bl.cpu().numpy(), want_bl)
+    np.testing.assert_array_equal(d_lab.cpu().numpy().view(np.uint16), want_labels)
+
+
 def test_infer_detection_levels_and_nan():
     o, net = pair(1, 3, 3, 0.25, 4, aa.ANH_FP32, seed=9)
     img = np.random.default_rng(4).integers(0, 256, (31, 31, 3), dtype=np.uint8)
