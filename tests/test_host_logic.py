@@ -97,6 +97,23 @@ def test_tiler_contract_and_oracle_agreement(w, h, mw, mh, ov):
     assert tiles == orc.get_tiles(w, h, mw, mh, ov, ov)
 
 
+def test_tiler_contract_on_random_sizes():
+    """The two shortcuts of tiled inference rest on the tiler's contract: the class planes are cleared in the blend frames only, and a batch's
+    blend assigns inside unique rectangles without looking at the other tiles — both need "a unique-rectangle pixel is covered by exactly one
+    full rectangle" (check_tiles) on every tiling, not just the benchmark's."""
+    rng = np.random.default_rng(0)
+    get = lambda *a: aa.tiling.get_tiles(a[0], a[1], aa.tiling.parameters(a[2], a[3], a[4], a[5]))
+    done = 0
+    while done < 150:
+        w, h = int(rng.integers(1, 600)), int(rng.integers(1, 600))
+        mw, mh, ov = int(rng.integers(40, 400)), int(rng.integers(40, 400)), int(rng.integers(0, 39))
+        if mw <= 2 * ov or mh <= 2 * ov:
+            continue
+        tiles = check_tiles(get, w, h, mw, mh, ov, ov)
+        assert tiles == orc.get_tiles(w, h, mw, mh, ov, ov)
+        done += 1
+
+
 def test_tiler_rejects_impossible_overlap():
     with pytest.raises(aa.AnnonetHipError):
         aa.tiling.get_tiles(500, 500, aa.tiling.parameters(60, 60, 35, 35))
